@@ -1,0 +1,165 @@
+"""Pins the CPU oracle (oracle/vince_oracle.py) to the reference's own outputs (tests/golden/*.npz,
+produced by oracle/make_golden.py from the imported reference).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vince_oracle as vo
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+# ------------------------------------------------------------------------------------------ G1 queue indices: bit-exact
+@pytest.mark.parametrize("name", ["k512", "k96"])
+def test_g1_queue_indices_bit_exact(name):
+    g = load("g1_queue.npz")
+    K = int(g[name + "_K"])
+    q = vo.OracleQueue(K, 4, init=-np.ones((K, 4), np.float32))
+    nid = 0
+    for step, n in enumerate(g[name + "_sizes"]):
+        items = np.repeat((nid + np.arange(n, dtype=np.float32))[:, None], 4, 1)
+        q.enqueue(items)
+        nid += int(n)
+        assert q.current_tail == int(g[name + "_tails"][step])
+        assert q.full == bool(g[name + "_fulls"][step])
+        np.testing.assert_array_equal(q.vectors[:, 0].astype(np.int64), g[name + "_owners"][step])
+        np.testing.assert_array_equal(q.owner, g[name + "_owners"][step])
+
+
+def test_probe_case_from_survey():
+    # K=512, enqueue 300 then 300 -> tail 88, full True
+    segs, tail, wrapped = vo.enqueue_segments(0, 300, 512)
+    assert (segs, tail, wrapped) == ([(0, 0, 300)], 300, False)
+    segs, tail, wrapped = vo.enqueue_segments(300, 300, 512)
+    assert (segs, tail, wrapped) == ([(300, 0, 212), (0, 212, 88)], 88, True)
+
+
+# ------------------------------------------------------------------------------------------ G2 loss / metrics / dq
+def _unit_rows(n, d, seed):
+    return torch.nn.functional.normalize(torch.randn(n, d, generator=torch.Generator().manual_seed(seed)), dim=1)
+
+
+def g2_case_inputs(ci, B, K, D):
+    q = _unit_rows(B, D, 100 + ci)
+    k = torch.nn.functional.normalize(q + 0.5 * _unit_rows(B, D, 200 + ci), dim=1)
+    queue = _unit_rows(K, D, 300 + ci)
+    return q, k, queue
+
+
+def test_g2_loss_metrics_grad():
+    g = load("g2_loss.npz")
+    for ci in range(int(g["n_cases"])):
+        p = "c%d_" % ci
+        B, K, D, F_, inter, selfb = [int(v) for v in g[p + "cfg"]]
+        T = float(g[p + "T"])
+        q, k, queue = g2_case_inputs(ci, B, K, D)
+        q.requires_grad_(True)
+        sims, mask = vo.similarities(q, k, queue, bool(inter), F_)
+        np.testing.assert_allclose(vo.tensor_checksum(sims), g[p + "sims_checksum"], rtol=1e-5, atol=1e-4)
+        ld = vo.similarity_cross_entropy(sims, T, mask)
+        np.testing.assert_allclose(ld["dists"].detach().numpy(), g[p + "dists"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(float(ld["dist"]), float(g[p + "dist"]), rtol=1e-5)
+        np.testing.assert_allclose(float(ld["softmax_weight"]), float(g[p + "softmax_weight"]), rtol=1e-4, atol=1e-7)
+        met = vo.nce_metrics(sims.detach(), mask, ld["softmax_weight"])
+        for kk in ["nce_accuracy_mean", "cosine_sim", "cosine_sim_neg_max"]:
+            np.testing.assert_allclose(float(met[kk]), float(g[p + "m_" + kk]), rtol=1e-5, atol=1e-6)
+        total = ld["dist"]
+        if selfb:
+            ssims = q @ q.t()
+            sl = vo.similarity_cross_entropy(ssims, 0.03, mask[:, :B])
+            np.testing.assert_allclose(float(sl["dist"]), float(g[p + "self_dist"]), rtol=1e-5)
+            total = total + sl["dist"]
+        total.backward()
+        np.testing.assert_allclose(q.grad.numpy(), g[p + "dq"], rtol=1e-4, atol=1e-6)
+
+
+def test_multi_positive_is_not_plain_softmax():
+    # per-positive denominators differ from softmax over all columns
+    q, k, queue = g2_case_inputs(0, 8, 64, 64)
+    sims, mask = vo.similarities(q, k, queue, True, 4)
+    ours = float(vo.similarity_cross_entropy(sims, 0.07, mask)["dist"])
+    s = sims / 0.07
+    plain = -(torch.log_softmax(s, 1)[mask]).mean()
+    assert abs(ours - float(plain)) > 1e-4
+
+
+# ------------------------------------------------------------------------------------------ G3/G4 trunk + head
+@pytest.mark.parametrize("arch,embed", [("ResNet18", 64), ("ResNet50", 128)])
+@pytest.mark.parametrize("hw", [64, 224])
+@pytest.mark.parametrize("train", [True, False])
+def test_g3_trunk_head(arch, embed, hw, train):
+    g = load("g3_trunk.npz")
+    p = "%s_%d_%s_" % (arch, hw, "train" if train else "eval")
+    sd = vo.seeded_state(vo.model_spec(arch, embed), 11)
+    x = vo.structured_frames(2, hw, hw, seed=500 + hw)
+    with torch.no_grad():
+        o = vo.get_embeddings(sd, x, arch, train)
+    if hw == 64:
+        np.testing.assert_allclose(o["spatial_features"].numpy(), g[p + "spatial"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(vo.tensor_checksum(o["spatial_features"]), g[p + "spatial_checksum"], rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(o["extracted_features"].numpy(), g[p + "extracted"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(o["prenorm_features"].numpy(), g[p + "prenorm"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(o["embeddings"].numpy(), g[p + "embeddings"], rtol=1e-4, atol=1e-6)
+    for bn in ["feature_extractor.model.bn1", "feature_extractor.model.layer4.1.bn2",
+               "feature_extractor.model.layer2.0.downsample.1"]:
+        np.testing.assert_allclose(sd[bn + ".running_mean"].numpy(), g[p + bn + ".running_mean"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(sd[bn + ".running_var"].numpy(), g[p + bn + ".running_var"], rtol=1e-4, atol=1e-6)
+        assert int(sd[bn + ".num_batches_tracked"]) == int(g[p + bn + ".num_batches_tracked"])
+
+
+# ------------------------------------------------------------------------------------------ G5 three training iterations (C1)
+@pytest.mark.parametrize("mode", ["moco", "vince"])
+def test_g5_three_steps(mode):
+    g = load("g5_step.npz")
+    tr = vo.OracleTrainer("ResNet18", 64, 512, 32, 0.07, 0.03, inter_batch=mode == "vince",
+                          num_frames=4 if mode == "vince" else 1, self_batch=mode == "vince", seed=5)
+    for it in range(3):
+        data = vo.structured_frames(32, 64, 64, seed=1000 + it)
+        qdata = vo.structured_frames(32, 64, 64, seed=1000 + it) + 0.25 * vo.gaussian_frames(32, 64, 64, 2000 + it)
+        r = tr.step(data, qdata)
+        pre = "%s_it%d_" % (mode, it)
+        np.testing.assert_allclose(r["nce_loss"], float(g[pre + "loss_nce_loss"]), rtol=2e-4)
+        if mode == "vince":
+            np.testing.assert_allclose(r["nce_loss_self"], float(g[pre + "loss_nce_loss_self"]), rtol=2e-4)
+        np.testing.assert_allclose(r["embeddings"].numpy(), g[pre + "embeddings"], rtol=1e-3, atol=2e-5)
+        np.testing.assert_allclose(r["queue_embeddings"].numpy(), g[pre + "queue_embeddings"], rtol=1e-3, atol=2e-5)
+        for kk in ["nce_accuracy_mean", "cosine_sim", "cosine_sim_neg_max"]:
+            np.testing.assert_allclose(r[kk], float(g[pre + "m_" + kk]), rtol=1e-3, atol=1e-5)
+        assert r["tail"] == int(g[pre + "tail"]) and r["full"] == bool(g[pre + "full"])
+        # Stem gradients are ill-conditioned after the first SGD step on this synthetic problem: an fp64 run of this
+        # same oracle differs from its fp32 run by ~4% of the max |grad| at iteration 1 (5e-6 relative at iteration
+        # 0), and the reference's fp32 run sits inside the same band.  Tight at it 0, conditioning-bounded later.
+        gb = g[pre + "grad_bn1w"]
+        tol = 1e-3 if it == 0 else 0.1
+        np.testing.assert_allclose(r["grads"]["feature_extractor.model.bn1.weight"].numpy(), gb,
+                                   rtol=0, atol=tol * np.abs(gb).max())
+        pcs = np.array([vo.tensor_checksum(tr.q[n]) for n in tr.pnames])
+        np.testing.assert_allclose(pcs[:, 2], g[pre + "param_checksums"][:, 2], rtol=1e-5 if it == 0 else 1e-3)
+        kcs = np.array([vo.tensor_checksum(tr.k[n]) for n in tr.pnames])
+        np.testing.assert_allclose(kcs[:, 2], g[pre + "key_checksums"][:, 2], rtol=1e-6)
+        np.testing.assert_allclose(vo.tensor_checksum(torch.from_numpy(tr.queue.vectors)), g[pre + "queue_checksum"],
+                                   rtol=1e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ G6 jigsaw
+@pytest.mark.parametrize("hw", [66, 64])
+def test_g6_jigsaw(hw):
+    g = load("g6_jigsaw.npz")
+    p = "hw%d_" % hw
+    n = 2
+    ramp = torch.arange(n * 3 * hw * hw, dtype=torch.float32).reshape(n, 3, hw, hw)
+    tiles = vo.jigsaw_tile(ramp)
+    assert list(tiles.shape) == list(g[p + "ramp_tiles_shape"])
+    np.testing.assert_array_equal(torch.stack([tiles[:, :, 0, 0], tiles[:, :, -1, -1]]).numpy(), g[p + "ramp_tiles_corner"])
+    sd = vo.seeded_state(vo.model_spec("ResNet18", 64, jigsaw=True), 21)
+    x = vo.structured_frames(n, hw, hw, seed=900 + hw)
+    with torch.no_grad():
+        o = vo.get_embeddings(sd, x, "ResNet18", True, jigsaw=True, jigsaw_orders=torch.from_numpy(g[p + "orders"]))
+    np.testing.assert_allclose(o["embeddings"].numpy(), g[p + "embeddings"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(o["extracted_features"].numpy(), g[p + "extracted"], rtol=1e-4, atol=1e-5)
