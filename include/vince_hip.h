@@ -1,0 +1,241 @@
+/* vince_hip.h -- flat C ABI of libvince_hip.so: the MI355X (gfx950) kernels behind the VINCE
+ * encoder + contrastive hot path.
+ *
+ * The reference (danielgordon10/vince) has no FFI of its own: every "kernel" is a torch op call
+ * site inside models/vince_model.py, models/building_blocks/resnet.py, utils/loss_util.py and
+ * utils/storage_queue.py (SURVEY.md section 2.3 lists them as K1..K21).  Each entry point below
+ * names the reference call site(s) it replaces.  The Python host (vince_amd/) binds these with
+ * ctypes and keeps the reference's class API on top.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; all pointers are DEVICE pointers unless marked host.
+ *  - nothing here allocates or frees caller-visible memory; scratch is passed in (workspace).
+ *  - every function returns 0 (VINCE_OK) or a negative VINCE_E_* code and never throws;
+ *    vince_last_error() returns a thread-local message.  No kernel silently clamps a shape.
+ *  - every launch goes to the hipStream_t passed as `stream` (void*; NULL = default stream);
+ *    no host synchronisation inside any export.
+ *  - activations are NHWC; `dtype` is VINCE_F32 or VINCE_BF16 (raw bfloat16 bits, uint16).
+ */
+#ifndef VINCE_HIP_H
+#define VINCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VINCE_OK 0
+#define VINCE_E_SHAPE (-1)
+#define VINCE_E_DTYPE (-2)
+#define VINCE_E_ALIGN (-3)
+#define VINCE_E_HIP (-4)
+#define VINCE_E_ARG (-5)
+#define VINCE_E_UNSUPPORTED (-6)
+
+#define VINCE_F32 0
+#define VINCE_BF16 1
+
+const char* vince_last_error(void);
+int vince_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generalised tap convolution as implicit GEMM on MFMA (K1-K3, K8 forward; dgrad of the same).
+ *
+ *   out[n, ho*osh+oh0, wo*osw+ow0, co] (+)= sum_{a<TA, b<TB, ci<Ci}
+ *        w[co, wt0 + a*wta + b*wtb, ci] * in[n, ho*sh + dh0 + a*dhs, wo*sw + dw0 + b*dws, ci]
+ *
+ * with out-of-range input pixels reading as zero.  One descriptor covers
+ *  - forward conv2d (models/building_blocks/resnet.py:34-50,170): dh0=-pad, dhs=dil, sh=stride;
+ *  - dgrad of a stride-1 conv: input = dY, weights = W^T ([Ci][T][Co]), dh0=+pad, dhs=-1;
+ *  - dgrad of a stride-2 conv: one launch per output-pixel parity class (osh=osw=2, oh0/ow0 = parity);
+ *  - nn.Linear forward / input-gradient (models/vince_model.py:38-42): N=batch, H=W=1, one tap.
+ * Requirements: Ci multiple of 16 bytes worth of elements (8 bf16 / 4 f32), Co multiple of 8,
+ * Ci/chunk a power of two unless TA*TB == 1.
+ */
+typedef struct vince_conv_desc {
+    int32_t N, Hi, Wi, Ci;      /* input tensor [N][Hi][Wi][Ci] */
+    int32_t Ho, Wo, Co;         /* output grid and channels */
+    int32_t sh, sw;             /* grid -> input stride */
+    int32_t TA, TB;             /* tap grid */
+    int32_t dh0, dhs, dw0, dws; /* input offset of tap (a,b) */
+    int32_t wt0, wta, wtb, WT;  /* weight tap index; weights are [Co][WT][Ci] */
+    int32_t OH, OW;             /* output tensor [N][OH][OW][Co] */
+    int32_t osh, osw, oh0, ow0; /* grid -> output pixel */
+} vince_conv_desc;
+
+/* epilogue flags */
+#define VINCE_EPI_ACCUMULATE 1 /* out += result (residual-gradient add) */
+#define VINCE_EPI_RELU 2       /* max(.,0) after bias */
+
+/* in/w/out have element type `dtype`; `out_f32 != 0` stores float output regardless of dtype (f32 only today).
+ * bias: optional float[Co].  stats: optional double[Co][2] -- per-channel (sum, sum of squares) of the STORED
+ * output values, atomically accumulated (feeds vince_bn_finalize; nn.BatchNorm2d train mode, resnet.py:69). */
+int vince_conv_igemm(const vince_conv_desc* d, int dtype, const void* in, const void* w, void* out,
+                     const float* bias, double* stats, int flags, void* stream);
+
+/* Weight gradient (wgrad) of the same generalised conv, reduction over output pixels:
+ *   dw[co, wt(a,b), ci] += sum_{n,ho,wo} dy[n,ho,wo,co] * in[n, ho*sh+dh0+a*dhs, wo*sw+dw0+b*dws, ci]
+ * dw is float[Co][WT][Ci_dw] accumulated with fp32 atomics (zero it first); only ci < Ci_dw is written
+ * (the stem pads Ci 3 -> 4/8).  dy is [N][Ho][Wo][Co] dense.  Also nn.Linear weight gradient (one tap).
+ * `variant`: 0 = default operand fetch (ds_read_b64_tr_b16 for bf16), 1 = scalar-gather fallback. */
+int vince_conv_wgrad(const vince_conv_desc* d, int dtype, const void* in, const void* dy, float* dw,
+                     int32_t Ci_dw, int variant, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d (K4/K5; resnet.py:69,72,110,112,171; eps 1e-5, momentum 0.1)
+ */
+/* train != 0: (sum,sumsq) -> batch mean / biased var -> scale = gamma*invstd, shift = beta - mean*scale;
+ * running stats updated with the UNBIASED variance, num_batches_tracked += 1.
+ * train == 0: scale/shift from the running stats (VinceSolver.run_val, vince_solver.py:522). */
+int vince_bn_finalize(const double* stats, int64_t count, int32_t C, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                      float eps, int train, float* scale, float* shift, float* save_mean, float* save_invstd,
+                      void* stream);
+
+/* out = [relu]( y*scale + shift + (identity ? (id_scale ? identity*id_scale + id_shift : identity) : 0) ) */
+int vince_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* identity,
+                   const float* id_scale, const float* id_shift, void* out, int64_t rows, int32_t C, int relu,
+                   void* stream);
+
+/* Backward pass 1: g = dz * (mask_src > 0 if mask_src else 1);  sums[c] += (sum g, sum g*xhat),
+ * xhat = (y - mean)*invstd.  sums is double[C][2], zeroed by the caller. */
+int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_src, const void* y, const float* mean,
+                        const float* invstd, double* sums, int64_t rows, int32_t C, void* stream);
+
+/* Backward pass 2: dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count); optional g_out = g (the
+ * residual branch's gradient); dgamma += sum_gx, dbeta += sum_g (float[C], atomically exclusive per channel). */
+int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_src, const void* y, const float* mean,
+                       const float* invstd, const float* gamma, const double* sums, int64_t count, void* dy,
+                       void* g_out, float* dgamma, float* dbeta, int64_t rows, int32_t C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pooling (K6 MaxPool2d 3x3/s2/p1 resnet.py:173, fused with the stem's BN-apply + ReLU; K7 AdaptiveAvgPool2d
+ * vince_model.py:33)
+ */
+int vince_stem_pool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out,
+                        uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* g[n,h,w,c] = sum of dpool over the windows whose argmax is (h,w)  (zero where relu(bn(y)) == 0) */
+int vince_stem_pool_bwd(int dtype, const void* dpool, const uint8_t* argmax, void* g, int32_t N, int32_t H,
+                        int32_t W, int32_t C, void* stream);
+int vince_avgpool_fwd(int dtype, const void* x, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
+int vince_avgpool_bwd(int dtype, const float* dout, void* dx, int32_t N, int32_t HW, int32_t C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout transforms
+ */
+/* float NCHW [N][3][H][W] -> dtype NHWC [N][H][W][Cp] with channels 3..Cp-1 zero (Cp = 4 f32 / 8 bf16).
+ * `perm` (optional int64[N]) gathers source images: out[i] = in[perm[i]] (batch shuffle, vince_model.py:137-142). */
+int vince_input_nchw_to_nhwc(int dtype, const float* in, const int64_t* perm, void* out, int32_t N, int32_t C,
+                             int32_t H, int32_t W, int32_t Cp, void* stream);
+/* jigsaw tiling (vince_model.py:144-155): float NCHW [N][C][H][W] -> dtype NHWC [9N][th][tw][Cp], zero pad */
+int vince_jigsaw_nchw_to_nhwc(int dtype, const float* in, void* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                              int32_t th, int32_t tw, int32_t Cp, void* stream);
+/* fp32 master weights [Co][T][Ci] -> compute copy [Co][T][Cip] (dtype) and, if wt != NULL, the dgrad copy
+ * [Ci][T][Co] (dtype). */
+int vince_prepare_weight(int dtype, const float* w, void* wk, void* wt, int32_t Co, int32_t T, int32_t Ci,
+                         int32_t Cip, void* stream);
+/* dtype NHWC -> float NCHW (spatial_features for callers that want the reference layout) */
+int vince_nhwc_to_nchw_f32(int dtype, const void* in, float* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Head pieces (K8 bias/ReLU glue, K9 F.normalize vince_model.py:180)
+ */
+int vince_l2norm_fwd(const float* x, float* out, float* norms, int32_t rows, int32_t D, float eps, void* stream);
+int vince_l2norm_bwd(const float* x, const float* norms, const float* dout, float* dx, int32_t rows, int32_t D,
+                     float eps, void* stream);
+int vince_relu_bwd(const float* dout, const float* act, float* dx, int64_t n, void* stream);
+int vince_colsum(const float* x, float* out, int32_t rows, int32_t cols, void* stream); /* out[c] += sum_r x[r][c] */
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused similarity + InfoNCE + metrics (K10-K14; vince_model.py:198-349, utils/loss_util.py:7-62)
+ *
+ * Column space of row i: [ in-batch columns 0..Bk-1 from `inb` | queue columns 0..K-1 ].
+ * Positives of row i: in-batch columns j with j / frames == i / frames (block diagonal; frames = 1 -> diagonal).
+ * offdiag_neg != 0 (inter-batch mode, vince_model.py:207-225): other in-batch columns are negatives.
+ * offdiag_neg == 0 (MoCo mode, :227-233): they are ignored, i.e. logits = [q_i.k_i | q_i.queue].
+ * K == 0 with inb == q gives the self-similarity term (:213-222).
+ * All arithmetic fp32 on the f32 MFMA; logits are never materialised.
+ */
+typedef struct vince_infonce_desc {
+    int32_t B, D, Bk, K;
+    int32_t frames;
+    int32_t offdiag_neg;
+    float inv_temperature;
+} vince_infonce_desc;
+
+size_t vince_infonce_workspace_bytes(const vince_infonce_desc* d);
+/* outputs: pos[B][P] raw cosines of the positives (P = frames), row_max[B], neg_sum[B] (sum of exp(s - row_max)
+ * over negatives), dists[B][P], softmax_weights[B][P], scalars[8] = {loss mean, softmax_weight mean,
+ * accuracy mean, mean positive cosine, mean row-max negative cosine, 0,0,0}. */
+int vince_infonce_fwd(const vince_infonce_desc* d, const float* q, const float* inb, const float* queue,
+                      float* pos, float* row_max, float* neg_sum, float* dists, float* softmax_weights,
+                      float* scalars, void* workspace, void* stream);
+/* dq[B][D] += dloss/dq (atomic fp32; zero it first).  grad_scale: device pointer to the upstream scalar gradient.
+ * wmat: optional float[B][Bk] receiving dloss/dlogit for the in-batch columns (self-similarity column-side grad). */
+int vince_infonce_bwd(const vince_infonce_desc* d, const float* q, const float* inb, const float* queue,
+                      const float* pos, const float* row_max, const float* neg_sum, const float* grad_scale,
+                      float* dq, float* wmat, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Queue, momentum encoder, optimiser (K18-K21)
+ */
+/* StorageQueue.enqueue (utils/storage_queue.py:31-49): writes n rows at *tail with split-on-wrap (and repeated
+ * laps when n > K); tail/full are HOST ints updated in place.  Index arithmetic is exact integer. */
+int vince_queue_enqueue(float* queue, int64_t K, int64_t D, const float* items, int64_t n, int64_t* tail,
+                        int32_t* full, void* stream);
+/* theta_k = theta_k*m + (1-m)*theta_q  (VinceQueueModel.param_update, vince_model.py:587-592) over a flat range */
+int vince_ema_flat(float* key, const float* query, int64_t n, float momentum, void* stream);
+/* torch.optim.SGD(momentum, weight_decay), dampening 0, no nesterov (vince_solver.py:256,469) over a flat range:
+ * d = g + wd*p; buf = buf*mom + d; p -= lr*buf.  grad_scale multiplies g first (1/world for DP mean). */
+int vince_sgd_flat(float* param, const float* grad, float* buf, int64_t n, float lr, float momentum,
+                   float weight_decay, float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Trunk engine: the ResNet-18/50 trunk (conv1..layer4, backbone_models.py:39-54 with final_layer=-2) + average
+ * pool as one object that sequences the kernels above on a stream.  One engine per (arch, N, H, W, dtype).
+ */
+typedef struct vince_trunk* vince_trunk_t;
+
+typedef struct vince_trunk_cfg {
+    int32_t arch;   /* 18 or 50 */
+    int32_t N, H, W;
+    int32_t dtype;  /* VINCE_F32 / VINCE_BF16 */
+} vince_trunk_cfg;
+
+int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out);
+void vince_trunk_destroy(vince_trunk_t t);
+/* parameter table: conv weights and BN (gamma, beta) in reference state-dict order, fc excluded */
+int32_t vince_trunk_num_params(vince_trunk_t t);
+int32_t vince_trunk_num_bn(vince_trunk_t t);
+/* kind: 0 conv weight (shape = Co,Ci,kh,kw; memory [Co][kh][kw][Ci] = torch channels_last), 1 bn gamma, 2 bn beta */
+int vince_trunk_param_info(vince_trunk_t t, int32_t idx, char* name, int32_t name_cap, int32_t* kind,
+                           int32_t shape[4], int32_t* bn_index);
+int vince_trunk_bn_info(vince_trunk_t t, int32_t bn_index, char* name, int32_t name_cap, int32_t* channels);
+int32_t vince_trunk_out_channels(vince_trunk_t t);
+int32_t vince_trunk_out_hw(vince_trunk_t t, int32_t* h, int32_t* w);
+size_t vince_trunk_workspace_bytes(vince_trunk_t t);       /* activations + saved tensors + gradient scratch */
+size_t vince_trunk_weight_cache_bytes(vince_trunk_t t);    /* compute-dtype weight copies (per encoder) */
+
+/* fp32 master weights -> compute copies in `wcache`.  Call after every parameter update. */
+int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* params, void* wcache, void* stream);
+
+/* input: float NCHW (perm optional, see vince_input_nchw_to_nhwc) or, when input_is_tiles != 0, jigsaw source
+ * (N/9 images [3][srcH][srcW]).  bn_buffers: per BN {running_mean, running_var} float pointers; nbt: int64 ptrs.
+ * train_bn: batch statistics + running-stat update.  save: keep what backward needs in the workspace.
+ * Outputs: pooled float[N][C]; spatial (the trunk output, dtype NHWC) stays in the workspace:
+ * vince_trunk_spatial_ptr(). */
+int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void* wcache, float* const* bn_running,
+                        int64_t* const* bn_nbt, const float* input, const int64_t* perm, int32_t jigsaw_src_h,
+                        int32_t jigsaw_src_w, void* workspace, float* pooled, int32_t train_bn, void* stream);
+const void* vince_trunk_spatial_ptr(vince_trunk_t t, const void* workspace);
+/* grads: float pointers parallel to params (accumulated into; zero them first).  dpooled: float[N][C]. */
+int vince_trunk_backward(vince_trunk_t t, const float* const* params, const void* wcache, void* workspace,
+                         const float* dpooled, float* const* grads, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VINCE_HIP_H */

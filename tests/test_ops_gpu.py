@@ -1,0 +1,379 @@
+"""GPU parity of every HIP kernel behind the C ABI against torch-CPU restatements of the reference ops
+(the oracle for float ops is torch CPU fp32).  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vince_oracle as vo  # noqa: E402
+
+
+def _ops():
+    from vince_amd import ops
+    return ops
+
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def to_nhwc(x, dtype, cpad=None):
+    """CPU NCHW fp32 -> GPU NHWC dtype (channels zero-padded to cpad)."""
+    x = x.permute(0, 2, 3, 1).contiguous()
+    if cpad is not None and cpad > x.shape[-1]:
+        x = F.pad(x, (0, cpad - x.shape[-1]))
+    return x.to(DEV).to(dtype).contiguous()
+
+
+def from_nhwc(x):
+    return x.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def q(x, dtype):
+    """Round a CPU fp32 tensor through `dtype` (so that the only GPU/CPU difference is accumulation order)."""
+    return x.to(dtype).float()
+
+
+def tol(dtype, f32=2e-5, bf16=2e-2):
+    return f32 if dtype == torch.float32 else bf16
+
+
+def assert_close(a, b, dtype, f32=2e-5, bf16=2e-2, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item() / scale
+    assert err < tol(dtype, f32, bf16), "%s: max err / max|ref| = %.3e (dtype %s)" % (what, err, dtype)
+
+
+CONVS = [
+    # N, H, W, Ci, Co, k, stride, pad
+    (2, 14, 14, 64, 64, 3, 1, 1),
+    (3, 9, 11, 64, 256, 1, 1, 0),
+    (2, 15, 15, 128, 128, 3, 2, 1),
+    (2, 14, 14, 256, 512, 1, 2, 0),
+    (2, 7, 7, 512, 512, 3, 1, 1),
+    (1, 38, 38, 64, 64, 3, 1, 1),
+]
+
+
+def weights_krsc(w, dtype, cip=None):
+    """OIHW fp32 CPU -> GPU [Co][T][Ci] master (fp32) -> compute copies."""
+    ops = _ops()
+    Co, Ci, kh, kw = w.shape
+    master = w.permute(0, 2, 3, 1).reshape(Co, kh * kw, Ci).contiguous().to(DEV)
+    return ops.prepare_weight(master, dtype, cip=cip, want_transposed=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_fwd_stats(cfg, dtype):
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, p = cfg
+    x = q(rnd(N, Ci, H, W, seed=1), dtype)
+    w = q(rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k)) ** 0.5), dtype)
+    ref = F.conv2d(x, w, None, s, p)
+    wk, _ = weights_krsc(w, dtype)
+    d = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
+    out = torch.empty(N, d.Ho, d.Wo, Co, device=DEV, dtype=dtype)
+    stats = torch.zeros(Co, 2, device=DEV, dtype=torch.float64)
+    ops.conv_igemm(d, to_nhwc(x, dtype), wk, out, stats=stats)
+    assert_close(from_nhwc(out), ref, dtype, what="conv fwd")
+    o = out.float().cpu().reshape(-1, Co).double()
+    np.testing.assert_allclose(stats[:, 0].cpu().numpy(), o.sum(0).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(stats[:, 1].cpu().numpy(), (o * o).sum(0).numpy(), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_stem(dtype):
+    ops = _ops()
+    N, H, W = 2, 40, 36
+    x = q(rnd(N, 3, H, W, seed=3), dtype)
+    w = q(rnd(64, 3, 7, 7, seed=4, scale=0.1), dtype)
+    ref = F.conv2d(x, w, None, 2, 3)
+    cp = 4 if dtype == torch.float32 else 8
+    xin = ops.input_nchw_to_nhwc(x.to(DEV), dtype)
+    assert xin.shape[-1] == cp
+    torch.testing.assert_close(xin[..., :3].float().cpu(), x.permute(0, 2, 3, 1), rtol=0, atol=0)
+    assert float(xin[..., 3:].abs().max()) == 0.0
+    wk, _ = weights_krsc(w, dtype, cip=cp)
+    d = ops.conv_desc(N, H, W, cp, 64, 7, 2, 3)
+    out = torch.empty(N, d.Ho, d.Wo, 64, device=DEV, dtype=dtype)
+    ops.conv_igemm(d, xin, wk, out)
+    assert_close(from_nhwc(out), ref, dtype, what="stem conv")
+    # stem wgrad: only the 3 real input channels are written
+    dy = q(rnd(N, 64, d.Ho, d.Wo, seed=5), dtype)
+    xr = x.clone().requires_grad_(False)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, 2, 3).backward(dy)
+    dw = torch.zeros(64, 49, 3, device=DEV)
+    ops.conv_wgrad(d, xin, to_nhwc(dy, dtype), dw, ci_dw=3)
+    ref_dw = wr.grad.permute(0, 2, 3, 1).reshape(64, 49, 3)
+    assert_close(dw, ref_dw, dtype, f32=1e-4, what="stem wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_dgrad_wgrad(cfg, dtype):
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, p = cfg
+    x = q(rnd(N, Ci, H, W, seed=6), dtype).requires_grad_(True)
+    w = q(rnd(Co, Ci, k, k, seed=7, scale=(2.0 / (Ci * k * k)) ** 0.5), dtype).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = q(rnd(*y.shape, seed=8), dtype)
+    y.backward(dy)
+    wk, wt = weights_krsc(w.detach(), dtype)
+    dyg = to_nhwc(dy, dtype)
+    # dgrad (store) then a second pass with ACCUMULATE must double it
+    dx = torch.full((N, H, W, Ci), float("nan"), device=DEV, dtype=dtype)
+    descs = ops.dgrad_descs(N, H, W, Ci, Co, k, s, p)
+    if len(descs) < s * s:
+        dx.zero_()
+    for d in descs:
+        ops.conv_igemm(d, dyg, wt, dx)
+    assert_close(from_nhwc(dx), x.grad, dtype, what="dgrad")
+    for d in descs:
+        ops.conv_igemm(d, dyg, wt, dx, flags=ops.EPI_ACCUMULATE)
+    assert_close(from_nhwc(dx), 2 * x.grad, dtype, bf16=3e-2, what="dgrad accumulate")
+    # wgrad, both operand-fetch variants
+    fd = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(Co, k * k, Ci)
+    for variant in ([0, 1] if dtype == torch.bfloat16 else [0]):
+        dw = torch.zeros(Co, k * k, Ci, device=DEV)
+        ops.conv_wgrad(fd, to_nhwc(x.detach(), dtype), dyg, dw, variant=variant)
+        assert_close(dw, ref_dw, dtype, f32=1e-4, what="wgrad variant %d" % variant)
+
+
+def test_linear_fwd_bwd():
+    ops = _ops()
+    rows, cin, cout = 37, 512, 64
+    x = rnd(rows, cin, seed=9).requires_grad_(True)
+    w = rnd(cout, cin, seed=10, scale=cin ** -0.5).requires_grad_(True)
+    b = rnd(cout, seed=11).requires_grad_(True)
+    y = F.relu(F.linear(x, w, b))
+    dy = rnd(rows, cout, seed=12)
+    y.backward(dy)
+    xg, wg, bg = x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV)
+    out = ops.linear_fwd(xg, wg, bg, relu=True)
+    assert_close(out, y.detach(), torch.float32, what="linear fwd")
+    dpre = ops.relu_bwd(dy.to(DEV), out)
+    dwg, dbg = torch.zeros_like(wg), torch.zeros_like(bg)
+    dx = ops.linear_bwd(xg, wg.t().contiguous(), dpre, dwg, dbg)
+    assert_close(dx, x.grad, torch.float32, what="linear dx")
+    assert_close(dwg, w.grad, torch.float32, f32=1e-4, what="linear dw")
+    assert_close(dbg, b.grad, torch.float32, f32=1e-4, what="linear db")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,shape", [(64, (4, 9, 9)), (256, (2, 5, 5)), (2048, (3, 2, 2))])
+def test_bn_train_fwd_bwd(C, shape, dtype):
+    ops = _ops()
+    N, H, W = shape
+    y = q(rnd(N, C, H, W, seed=13) * 1.5 + 0.3, dtype).requires_grad_(True)
+    idn = q(rnd(N, C, H, W, seed=14), dtype).requires_grad_(True)
+    gamma = (1 + 0.1 * rnd(C, seed=15)).requires_grad_(True)
+    beta = (0.1 * rnd(C, seed=16)).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    z = F.relu(F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5) + idn)
+    dz = q(rnd(N, C, H, W, seed=17), dtype)
+    z.backward(dz)
+    # GPU: statistics come from the conv epilogue in production; here from the values directly
+    yg = to_nhwc(y.detach(), dtype)
+    yy = yg.float().reshape(-1, C).double()
+    stats = torch.stack([yy.sum(0), (yy * yy).sum(0)], 1).contiguous()
+    rmg, rvg = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    consts = ops.bn_finalize(stats, N * H * W, gamma.detach().to(DEV), beta.detach().to(DEV), rmg, rvg, nbt, True)
+    np.testing.assert_allclose(rmg.cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rvg.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-5)
+    assert int(nbt) == 1
+    zg = ops.bn_apply(yg, consts[0], consts[1], identity=to_nhwc(idn.detach(), dtype), relu=True)
+    assert_close(from_nhwc(zg), z.detach(), dtype, what="bn apply")
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dy, g = ops.bn_bwd(to_nhwc(dz, dtype), zg, yg, consts[2], consts[3], gamma.detach().to(DEV), dgam, dbet, want_g=True)
+    assert_close(from_nhwc(dy), y.grad, dtype, f32=1e-4, bf16=3e-2, what="bn dy")
+    assert_close(from_nhwc(g), idn.grad, dtype, what="residual g")
+    assert_close(dgam, gamma.grad, dtype, f32=1e-4, bf16=3e-2, what="dgamma")
+    assert_close(dbet, beta.grad, dtype, f32=1e-4, bf16=3e-2, what="dbeta")
+
+
+def test_bn_eval_and_downsample_identity():
+    ops = _ops()
+    C = 128
+    y, yd = rnd(2, C, 4, 4, seed=18), rnd(2, C, 4, 4, seed=19)
+    g1, b1, g2, b2 = 1 + 0.1 * rnd(C, seed=20), 0.1 * rnd(C, seed=21), 1 + 0.1 * rnd(C, seed=22), 0.1 * rnd(C, seed=23)
+    rm1, rv1, rm2, rv2 = 0.2 * rnd(C, seed=24), 1 + 0.1 * rnd(C, seed=25).abs(), 0.2 * rnd(C, seed=26), 1 + 0.1 * rnd(C, seed=27).abs()
+    ref = F.relu(F.batch_norm(y, rm1, rv1, g1, b1, False) + F.batch_norm(yd, rm2, rv2, g2, b2, False))
+    c1 = ops.bn_finalize(None, 0, g1.to(DEV), b1.to(DEV), rm1.to(DEV), rv1.to(DEV), None, False)
+    c2 = ops.bn_finalize(None, 0, g2.to(DEV), b2.to(DEV), rm2.to(DEV), rv2.to(DEV), None, False)
+    out = ops.bn_apply(to_nhwc(y, torch.float32), c1[0], c1[1], identity=to_nhwc(yd, torch.float32), id_scale=c2[0],
+                       id_shift=c2[1], relu=True)
+    assert_close(from_nhwc(out), ref, torch.float32, what="eval bn + downsample identity")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hw", [(16, 16), (19, 13)])
+def test_stem_pool(dtype, hw):
+    ops = _ops()
+    N, C = 2, 64
+    H, W = hw
+    y = q(rnd(N, C, H, W, seed=28), dtype).requires_grad_(True)
+    scale, shift = 1 + 0.2 * rnd(C, seed=29), 0.3 * rnd(C, seed=30)
+    a = F.relu(y * scale[None, :, None, None] + shift[None, :, None, None])
+    pooled = F.max_pool2d(a, 3, 2, 1)
+    dp = q(rnd(*pooled.shape, seed=31), dtype)
+    a.retain_grad()
+    pooled.backward(dp)
+    out, amax = ops.stem_pool_fwd(to_nhwc(y.detach(), dtype), scale.to(DEV), shift.to(DEV))
+    assert_close(from_nhwc(out), pooled.detach(), dtype, bf16=1e-2, what="stem pool fwd")
+    g = ops.stem_pool_bwd(to_nhwc(dp, dtype), amax, H, W)
+    # reference gradient wrt the BN output (after the ReLU mask) = a.grad * (a > 0)
+    ref_g = a.grad * (a.detach() > 0)
+    if dtype == torch.float32:
+        assert_close(from_nhwc(g), ref_g, dtype, what="stem pool bwd")
+    else:  # bf16 rounding of the pre-pool activation can move an argmax between tied neighbours: compare totals
+        assert abs(float(g.float().sum()) - float(ref_g.sum())) < 2e-2 * float(ref_g.abs().sum())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_avgpool(dtype):
+    ops = _ops()
+    x = q(rnd(5, 512, 3, 2, seed=32), dtype)
+    out = ops.avgpool_fwd(to_nhwc(x, dtype))
+    assert_close(out, x.mean(dim=(2, 3)), dtype, f32=1e-6, bf16=1e-6, what="avgpool")
+    dout = rnd(5, 512, seed=33)
+    dx = ops.avgpool_bwd(dout.to(DEV), 3, 2, dtype)
+    assert_close(from_nhwc(dx), (dout / 6)[:, :, None, None].expand(5, 512, 3, 2), dtype, bf16=5e-3, what="avgpool bwd")
+
+
+def test_l2norm():
+    ops = _ops()
+    x = rnd(33, 128, seed=34).requires_grad_(True)
+    y = F.normalize(x, dim=1)
+    dy = rnd(33, 128, seed=35)
+    y.backward(dy)
+    out, norms = ops.l2norm_fwd(x.detach().to(DEV))
+    assert_close(out, y.detach(), torch.float32, f32=1e-6, what="l2norm")
+    dx = ops.l2norm_bwd(x.detach().to(DEV), norms, dy.to(DEV))
+    assert_close(dx, x.grad, torch.float32, f32=1e-5, what="l2norm bwd")
+
+
+def test_jigsaw_and_layouts():
+    ops = _ops()
+    for hw in [66, 64]:
+        x = torch.arange(2 * 3 * hw * hw, dtype=torch.float32).reshape(2, 3, hw, hw) / 100.0
+        ref = vo.jigsaw_tile(x)
+        out = ops.jigsaw_nchw_to_nhwc(x.to(DEV), torch.float32)
+        assert list(out.shape[:3]) == [18, ref.shape[2], ref.shape[3]]
+        torch.testing.assert_close(from_nhwc(out)[:, :3], ref, rtol=0, atol=0)
+    x = rnd(3, 3, 10, 12, seed=36)
+    perm = torch.tensor([2, 0, 1])
+    out = ops.input_nchw_to_nhwc(x.to(DEV), torch.float32, perm=perm.to(DEV))
+    torch.testing.assert_close(from_nhwc(out)[:, :3], x[perm], rtol=0, atol=0)
+    y = rnd(2, 5, 6, 16, seed=37)
+    torch.testing.assert_close(ops.nhwc_to_nchw_f32(y.to(DEV)).cpu(), y.permute(0, 3, 1, 2).contiguous(), rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------- InfoNCE
+def unit_rows(n, d, seed):
+    return F.normalize(rnd(n, d, seed=seed), dim=1)
+
+
+@pytest.mark.parametrize("B,K,D", [(8, 64, 64), (32, 512, 128), (256, 4096, 64), (64, 1000, 128)])
+@pytest.mark.parametrize("mode", ["moco", "inter1", "inter4"])
+@pytest.mark.parametrize("T", [0.07, 0.2])
+def test_infonce_vs_oracle(B, K, D, mode, T):
+    ops = _ops()
+    frames = 4 if mode == "inter4" else 1
+    inter = mode != "moco"
+    qq = unit_rows(B, D, 40).requires_grad_(True)
+    kk = F.normalize(qq.detach() + 0.5 * unit_rows(B, D, 41), dim=1)
+    queue = unit_rows(K, D, 42)
+    sims, mask = vo.similarities(qq, kk, queue, inter, frames)
+    ld = vo.similarity_cross_entropy(sims, T, mask)
+    met = vo.nce_metrics(sims.detach(), mask, ld["softmax_weight"])
+    (ld["dist"] * 1.7).backward()
+    qg, kg, queueg = qq.detach().to(DEV), kk.to(DEV), queue.to(DEV)
+    r = ops.infonce_fwd(qg, kg, queueg, T, frames=frames, offdiag_neg=inter)
+    sc = r.scalars.cpu().numpy()
+    np.testing.assert_allclose(sc[0], float(ld["dist"]), rtol=1e-4)
+    np.testing.assert_allclose(sc[1], float(ld["softmax_weight"]), rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(sc[2], float(met["nce_accuracy_mean"]), atol=1e-6)
+    np.testing.assert_allclose(sc[3], float(met["cosine_sim"]), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sc[4], float(met["cosine_sim_neg_max"]), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(r.dists.cpu().numpy(), ld["dists"].detach().numpy().reshape(B, frames), rtol=1e-3, atol=1e-4)
+    dq = torch.zeros(B, D, device=DEV)
+    ops.infonce_bwd(r, qg, kg, queueg, torch.tensor([1.7], device=DEV), dq)
+    assert_close(dq, qq.grad, torch.float32, f32=2e-4, what="infonce dq")
+
+
+def test_infonce_self_similarity():
+    ops = _ops()
+    B, D, T = 32, 64, 0.03
+    qq = unit_rows(B, D, 43).requires_grad_(True)
+    ssims = qq @ qq.t()
+    mask = vo.positive_mask(B, 4, B)
+    sl = vo.similarity_cross_entropy(ssims, T, mask)
+    sl["dist"].backward()
+    qg = qq.detach().to(DEV)
+    r = ops.infonce_fwd(qg, qg, None, T, frames=4, offdiag_neg=True)
+    np.testing.assert_allclose(float(r.scalars[0]), float(sl["dist"]), rtol=1e-4)
+    dq = torch.zeros(B, D, device=DEV)
+    wmat = ops.infonce_bwd(r, qg, qg, None, torch.ones(1, device=DEV), dq, want_wmat=True)
+    # column-side gradient: dq_j += sum_i w_ij q_i  == wgrad form (rows = i as the reduced axis)
+    ops.conv_wgrad(ops.linear_desc(B, D, B), qg, wmat, dq)
+    assert_close(dq, qq.grad, torch.float32, f32=2e-4, what="self-sim dq")
+
+
+# ---------------------------------------------------------------------------------------------- queue / EMA / SGD
+@pytest.mark.parametrize("name", ["k512", "k96"])
+def test_queue_indices_bit_exact_vs_golden(name, golden_dir):
+    import os
+    ops = _ops()
+    g = np.load(os.path.join(golden_dir, "g1_queue.npz"))
+    K = int(g[name + "_K"])
+    queue = torch.full((K, 4), -1.0, device=DEV)
+    tail, full, nid = 0, False, 0
+    for step, n in enumerate(g[name + "_sizes"]):
+        n = int(n)
+        items = (nid + torch.arange(n, dtype=torch.float32))[:, None].repeat(1, 4).to(DEV)
+        tail, full = ops.queue_enqueue(queue, items, tail, full)
+        nid += n
+        assert tail == int(g[name + "_tails"][step]) and full == bool(g[name + "_fulls"][step])
+        np.testing.assert_array_equal(queue[:, 0].cpu().numpy().astype(np.int64), g[name + "_owners"][step])
+        np.testing.assert_array_equal(queue[:, 3].cpu().numpy().astype(np.int64), g[name + "_owners"][step])
+
+
+def test_ema_sgd_flat():
+    ops = _ops()
+    n = 100003
+    k, qv, g = rnd(n, seed=50), rnd(n, seed=51), rnd(n, seed=52)
+    kd, qd = {"p": k.clone()}, {"p": qv.clone()}
+    vo.ema_update(kd, qd, ["p"], 0.999)
+    kg = torch.zeros(n + 1, device=DEV)[:n]
+    kg.copy_(k)
+    ops.ema_flat(kg, qv.to(DEV), 0.999)
+    np.testing.assert_allclose(kg.cpu().numpy(), kd["p"].numpy(), rtol=1e-6, atol=1e-7)
+    # momentum 0 -> exact copy (param_update(model, 0), vince_solver.py:296,318)
+    ops.ema_flat(kg, qv.to(DEV), 0.0)
+    torch.testing.assert_close(kg.cpu(), qv, rtol=0, atol=0)
+    p = {"p": qv.clone()}
+    bufs = {}
+    pg, bg = qv.clone().to(DEV), torch.zeros(n, device=DEV)
+    for it in range(3):
+        gi = g * (it + 1)
+        vo.sgd_step(p, {"p": gi}, bufs, 0.03)
+        ops.sgd_flat(pg, gi.to(DEV), bg, 0.03)
+    np.testing.assert_allclose(pg.cpu().numpy(), p["p"].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bg.cpu().numpy(), bufs["p"].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_cpu_tensor_is_rejected():
+    ops = _ops()
+    with pytest.raises(RuntimeError):
+        ops.l2norm_fwd(torch.randn(4, 64))

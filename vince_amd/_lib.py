@@ -1,0 +1,105 @@
+"""ctypes binding of libvince_hip.so (include/vince_hip.h).  Fails loudly: no library -> RuntimeError."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvince_hip.so")
+
+VINCE_F32, VINCE_BF16 = 0, 1
+EPI_ACCUMULATE, EPI_RELU = 1, 2
+
+c_void_p, c_int, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,
+                                                        ctypes.c_float, ctypes.c_size_t)
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "sh", "sw", "TA", "TB", "dh0", "dhs", "dw0", "dws",
+        "wt0", "wta", "wtb", "WT", "OH", "OW", "osh", "osw", "oh0", "ow0")]
+
+
+class InfoNCEDesc(ctypes.Structure):
+    _fields_ = [("B", c_int32), ("D", c_int32), ("Bk", c_int32), ("K", c_int32), ("frames", c_int32),
+                ("offdiag_neg", c_int32), ("inv_temperature", c_float)]
+
+
+class TrunkCfg(ctypes.Structure):
+    _fields_ = [("arch", c_int32), ("N", c_int32), ("H", c_int32), ("W", c_int32), ("dtype", c_int32)]
+
+
+P = ctypes.POINTER
+# name -> (restype, argtypes); every symbol declared in include/vince_hip.h
+PROTOTYPES = {
+    "vince_last_error": (ctypes.c_char_p, []),
+    "vince_abi_version": (c_int, []),
+    "vince_conv_igemm": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vince_conv_wgrad": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_void_p]),
+    "vince_bn_finalize": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                  c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vince_bn_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                               c_int32, c_int, c_void_p]),
+    "vince_bn_bwd_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                    c_void_p]),
+    "vince_bn_bwd_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "vince_stem_pool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                    c_int32, c_void_p]),
+    "vince_stem_pool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "vince_avgpool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "vince_avgpool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "vince_input_nchw_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         c_void_p]),
+    "vince_jigsaw_nchw_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                          c_int32, c_void_p]),
+    "vince_prepare_weight": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "vince_nhwc_to_nchw_f32": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "vince_l2norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
+    "vince_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
+    "vince_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vince_colsum": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "vince_infonce_workspace_bytes": (c_size_t, [P(InfoNCEDesc)]),
+    "vince_infonce_fwd": (c_int, [P(InfoNCEDesc)] + [c_void_p] * 11),
+    "vince_infonce_bwd": (c_int, [P(InfoNCEDesc)] + [c_void_p] * 10),
+    "vince_queue_enqueue": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, P(c_int64), P(c_int32), c_void_p]),
+    "vince_ema_flat": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "vince_sgd_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
+    "vince_trunk_create": (c_int, [P(TrunkCfg), P(c_void_p)]),
+    "vince_trunk_destroy": (None, [c_void_p]),
+    "vince_trunk_num_params": (c_int32, [c_void_p]),
+    "vince_trunk_num_bn": (c_int32, [c_void_p]),
+    "vince_trunk_param_info": (c_int, [c_void_p, c_int32, ctypes.c_char_p, c_int32, P(c_int32), P(c_int32 * 4), P(c_int32)]),
+    "vince_trunk_bn_info": (c_int, [c_void_p, c_int32, ctypes.c_char_p, c_int32, P(c_int32)]),
+    "vince_trunk_out_channels": (c_int32, [c_void_p]),
+    "vince_trunk_out_hw": (c_int32, [c_void_p, P(c_int32), P(c_int32)]),
+    "vince_trunk_workspace_bytes": (c_size_t, [c_void_p]),
+    "vince_trunk_weight_cache_bytes": (c_size_t, [c_void_p]),
+    "vince_trunk_prepare_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vince_trunk_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                    c_void_p, c_void_p, c_int32, c_void_p]),
+    "vince_trunk_spatial_ptr": (c_void_p, [c_void_p, c_void_p]),
+    "vince_trunk_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_LIB = None
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built (python -m vince_amd.build)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "vince_amd: %s is missing -- build the HIP extension first (python -m vince_amd.build). "
+                "There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)   # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libvince_hip error %d: %s" % (rc, lib().vince_last_error().decode()))

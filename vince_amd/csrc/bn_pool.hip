@@ -1,0 +1,505 @@
+// BatchNorm2d (train / eval), fused BN+ReLU+residual apply, BN backward, stem max-pool, global average pool.
+//
+// Reference call sites: nn.BatchNorm2d resnet.py:69,72,110,112,171; ReLU / residual add resnet.py:81,89-90,122,126,
+// 134-135; MaxPool2d(3,2,1) resnet.py:173; AdaptiveAvgPool2d vince_model.py:33.
+//
+// All of these are HBM-bound NHWC streams.  Every thread owns a fixed 16-byte channel chunk (8 bf16 / 4 f32) and
+// walks pixel rows, so a wavefront always touches whole contiguous row segments and the per-channel constants
+// (scale/shift/mean/invstd) live in registers for the whole walk.  Reductions go registers -> LDS -> one fp64
+// atomic per channel per workgroup.
+#include "common.h"
+
+namespace {
+
+// 2-D decomposition shared by the row-walking kernels.
+struct RowWalk {
+    int cpr;             // chunks per row = C / CH
+    int tpc;             // threads across chunk columns (<= 256, divides 256)
+    int rpp;             // rows per pass = 256 / tpc
+    int colgroups;       // grid.x
+    int rowblocks;       // grid.y
+    int64_t rows_per_block;
+};
+
+inline RowWalk make_rowwalk(int64_t rows, int C, int CH, int target_blocks = 2048) {
+    RowWalk w;
+    w.cpr = C / CH;
+    int tpc = 1;
+    while (tpc < w.cpr && tpc < 256) tpc <<= 1;
+    w.tpc = tpc;
+    w.rpp = 256 / tpc;
+    w.colgroups = (w.cpr + tpc - 1) / tpc;
+    int64_t want = target_blocks / w.colgroups;
+    if (want < 1) want = 1;
+    int64_t rpb = (rows + want - 1) / want;
+    int64_t minrows = (int64_t)w.rpp * 8;
+    if (rpb < minrows) rpb = minrows;
+    rpb = (rpb + w.rpp - 1) / w.rpp * w.rpp;
+    w.rows_per_block = rpb;
+    w.rowblocks = (int)((rows + rpb - 1) / rpb);
+    return w;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, int C, const float* gamma,
+                                   const float* beta, float* rmean, float* rvar, int64_t* nbt, float momentum,
+                                   float eps, int train, float* scale, float* shift, float* save_mean,
+                                   float* save_invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && train && nbt) *nbt += 1;
+    if (c >= C) return;
+    float mean, invstd;
+    if (train) {
+        double m = stats[2 * c] / count;
+        double var = stats[2 * c + 1] / count - m * m;
+        if (var < 0) var = 0;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) {
+            double unbiased = count > 1 ? var * count / (count - 1) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    } else {
+        mean = rmean[c];
+        invstd = 1.f / sqrtf(rvar[c] + eps);
+    }
+    float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (save_mean) save_mean[c] = mean;
+    if (save_invstd) save_invstd[c] = invstd;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const T* __restrict__ idn,
+                                                       const float* __restrict__ ids, const float* __restrict__ idt,
+                                                       T* __restrict__ out, int64_t rows, int C, int relu, RowWalk w) {
+    constexpr int CH = Elem<T>::CH;
+    const int col = blockIdx.x * w.tpc + (threadIdx.x % w.tpc);
+    if (col >= w.cpr) return;
+    float sc[CH], sh[CH], isc[CH], ish[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        sc[e] = scale[col * CH + e];
+        sh[e] = shift[col * CH + e];
+        isc[e] = ids ? ids[col * CH + e] : 1.f;
+        ish[e] = ids ? idt[col * CH + e] : 0.f;
+    }
+    const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + threadIdx.x / w.tpc;
+    const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
+    for (int64_t r = r0; r < r1; r += w.rpp) {
+        const size_t off = (size_t)r * C + (size_t)col * CH;
+        float f[CH];
+        Chunk<T>::unpack(*(const uint4*)(y + off), f);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) f[e] = f[e] * sc[e] + sh[e];
+        if (idn) {
+            float g[CH];
+            Chunk<T>::unpack(*(const uint4*)(idn + off), g);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) f[e] += g[e] * isc[e] + ish[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
+        }
+        *(uint4*)(out + off) = Chunk<T>::pack(f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ msk,
+                                                            const T* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, double* sums,
+                                                            int64_t rows, int C, RowWalk w) {
+    constexpr int CH = Elem<T>::CH;
+    __shared__ float red[256 * 2 * CH];
+    const int tc = threadIdx.x % w.tpc, tr = threadIdx.x / w.tpc;
+    const int col = blockIdx.x * w.tpc + tc;
+    const bool cv = col < w.cpr;
+    float mu[CH], is[CH], sg[CH], sgx[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        mu[e] = cv ? mean[col * CH + e] : 0.f;
+        is[e] = cv ? invstd[col * CH + e] : 0.f;
+        sg[e] = sgx[e] = 0.f;
+    }
+    const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + tr;
+    const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
+    if (cv) {
+        for (int64_t r = r0; r < r1; r += w.rpp) {
+            const size_t off = (size_t)r * C + (size_t)col * CH;
+            float g[CH], yy[CH];
+            Chunk<T>::unpack(*(const uint4*)(dz + off), g);
+            Chunk<T>::unpack(*(const uint4*)(y + off), yy);
+            if (msk) {
+                float m[CH];
+                Chunk<T>::unpack(*(const uint4*)(msk + off), m);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                sg[e] += g[e];
+                sgx[e] += g[e] * (yy[e] - mu[e]) * is[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        red[threadIdx.x * 2 * CH + e] = sg[e];
+        red[threadIdx.x * 2 * CH + CH + e] = sgx[e];
+    }
+    __syncthreads();
+    // thread (tc, which-slot) sums over the rpp row-threads of its column
+    for (int t = threadIdx.x; t < w.tpc * 2 * CH; t += 256) {
+        const int c_ = t / (2 * CH), slot = t % (2 * CH);
+        const int gcol = blockIdx.x * w.tpc + c_;
+        if (gcol >= w.cpr) continue;
+        float s = 0.f;
+        for (int rr = 0; rr < w.rpp; ++rr) s += red[(rr * w.tpc + c_) * 2 * CH + slot];
+        const int ch = gcol * CH + (slot % CH), which = slot / CH;
+        unsafeAtomicAdd(sums + (size_t)ch * 2 + which, (double)s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ msk,
+                                                           const T* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const double* __restrict__ sums, double inv_count,
+                                                           T* __restrict__ dy, T* __restrict__ gout, float* dgamma,
+                                                           float* dbeta, int64_t rows, int C, RowWalk w) {
+    constexpr int CH = Elem<T>::CH;
+    const int col = blockIdx.x * w.tpc + (threadIdx.x % w.tpc);
+    if (col >= w.cpr) return;
+    float mu[CH], is[CH], k1[CH], ma[CH], mb[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        const int c = col * CH + e;
+        mu[e] = mean[c];
+        is[e] = invstd[c];
+        k1[e] = gamma[c] * is[e];
+        ma[e] = (float)(sums[2 * c] * inv_count);
+        mb[e] = (float)(sums[2 * c + 1] * inv_count);
+        if (blockIdx.y == 0 && threadIdx.x / w.tpc == 0) {
+            if (dgamma) dgamma[c] += (float)sums[2 * c + 1];
+            if (dbeta) dbeta[c] += (float)sums[2 * c];
+        }
+    }
+    const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + threadIdx.x / w.tpc;
+    const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
+    for (int64_t r = r0; r < r1; r += w.rpp) {
+        const size_t off = (size_t)r * C + (size_t)col * CH;
+        float g[CH], yy[CH];
+        Chunk<T>::unpack(*(const uint4*)(dz + off), g);
+        Chunk<T>::unpack(*(const uint4*)(y + off), yy);
+        if (msk) {
+            float m[CH];
+            Chunk<T>::unpack(*(const uint4*)(msk + off), m);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+        }
+        if (gout) *(uint4*)(gout + off) = Chunk<T>::pack(g);
+        float o[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) o[e] = k1[e] * (g[e] - ma[e] - (yy[e] - mu[e]) * is[e] * mb[e]);
+        *(uint4*)(dy + off) = Chunk<T>::pack(o);
+    }
+}
+
+// ---- stem max-pool 3x3/s2/p1 over relu(bn(y)) -------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, T* __restrict__ out,
+                                                            uint8_t* __restrict__ amax, int N, int H, int W, int C,
+                                                            int Ho, int Wo) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH;
+    const int64_t total = (int64_t)N * Ho * Wo * cpr;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int col = (int)(idx % cpr);
+        int64_t pix = idx / cpr;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        float sc[CH], sh[CH], best[CH];
+        int bi[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            sc[e] = scale[col * CH + e];
+            sh[e] = shift[col * CH + e];
+            best[e] = -INFINITY;
+            bi[e] = 255;
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = ho * 2 - 1 + kh;
+            if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w_ = wo * 2 - 1 + kw;
+                if ((unsigned)w_ >= (unsigned)W) continue;
+                float f[CH];
+                Chunk<T>::unpack(*(const uint4*)(y + (((size_t)n * H + h) * W + w_) * C + (size_t)col * CH), f);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const float v = fmaxf(f[e] * sc[e] + sh[e], 0.f);
+                    if (v > best[e]) { best[e] = v; bi[e] = kh * 3 + kw; }
+                }
+            }
+        }
+        const size_t ooff = (((size_t)n * Ho + ho) * Wo + wo) * C + (size_t)col * CH;
+        *(uint4*)(out + ooff) = Chunk<T>::pack(best);
+        // a window whose max is 0 passes no gradient (ReLU backward kills it): mark with 255
+        uint32_t packed[CH / 4];
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+            packed[q] = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                packed[q] |= (uint32_t)(best[4 * q + e] > 0.f ? bi[4 * q + e] : 255) << (8 * e);
+        }
+        if constexpr (CH == 8) *(uint2*)(amax + ooff) = make_uint2(packed[0], packed[1]);
+        else *(uint32_t*)(amax + ooff) = packed[0];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const T* __restrict__ dpool,
+                                                            const uint8_t* __restrict__ amax, T* __restrict__ g,
+                                                            int N, int H, int W, int C, int Ho, int Wo) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH;
+    const int64_t total = (int64_t)N * H * W * cpr;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int col = (int)(idx % cpr);
+        int64_t pix = idx / cpr;
+        const int w_ = (int)(pix % W);
+        pix /= W;
+        const int h = (int)(pix % H);
+        const int n = (int)(pix / H);
+        float acc[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+        // windows (ho, wo) that contain (h, w): ho*2-1 <= h <= ho*2+1
+        const int ho_lo = h >> 1, ho_hi = (h + 1) >> 1;   // floor(h/2) .. floor((h+1)/2)
+        const int wo_lo = w_ >> 1, wo_hi = (w_ + 1) >> 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho >= Ho) continue;
+            const int kh = h - (ho * 2 - 1);
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                if (wo >= Wo) continue;
+                const int kw = w_ - (wo * 2 - 1);
+                const int code = kh * 3 + kw;
+                const size_t ooff = (((size_t)n * Ho + ho) * Wo + wo) * C + (size_t)col * CH;
+                float d[CH];
+                Chunk<T>::unpack(*(const uint4*)(dpool + ooff), d);
+                if constexpr (CH == 8) {
+                    const uint2 a = *(const uint2*)(amax + ooff);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (((a.x >> (8 * e)) & 0xff) == (uint32_t)code) acc[e] += d[e];
+                        if (((a.y >> (8 * e)) & 0xff) == (uint32_t)code) acc[4 + e] += d[4 + e];
+                    }
+                } else {
+                    const uint32_t a = *(const uint32_t*)(amax + ooff);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (((a >> (8 * e)) & 0xff) == (uint32_t)code) acc[e] += d[e];
+                }
+            }
+        }
+        *(uint4*)(g + (((size_t)n * H + h) * W + w_) * C + (size_t)col * CH) = Chunk<T>::pack(acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ out, int N,
+                                                          int HW, int C) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * cpr) return;
+    const int n = idx / cpr, col = idx % cpr;
+    float s[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) s[e] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+        float f[CH];
+        Chunk<T>::unpack(*(const uint4*)(x + ((size_t)n * HW + p) * C + (size_t)col * CH), f);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) s[e] += f[e];
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) out[(size_t)n * C + col * CH + e] = s[e] * inv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dout, T* __restrict__ dx, int N,
+                                                          int HW, int C) {
+    constexpr int CH = Elem<T>::CH;
+    const int cpr = C / CH;
+    const int64_t total = (int64_t)N * HW * cpr;
+    const float inv = 1.f / (float)HW;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int col = (int)(idx % cpr);
+        const int64_t pix = idx / cpr;
+        const int n = (int)(pix / HW);
+        float f[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) f[e] = dout[(size_t)n * C + col * CH + e] * inv;
+        *(uint4*)(dx + (size_t)pix * C + (size_t)col * CH) = Chunk<T>::pack(f);
+    }
+}
+
+inline int grid_for(int64_t total_threads) {
+    int64_t b = (total_threads + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+#define DTYPE_OK(fn) VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, fn ": bad dtype %d", dtype)
+#define CH_OF(dtype) ((dtype) == VINCE_F32 ? 4 : 8)
+
+extern "C" int vince_bn_finalize(const double* stats, int64_t count, int32_t C, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                                 int train, float* scale, float* shift, float* save_mean, float* save_invstd,
+                                 void* stream) {
+    VINCE_CHECK_ARG(C > 0 && gamma && beta && scale && shift, VINCE_E_ARG, "vince_bn_finalize: bad arguments");
+    VINCE_CHECK_ARG(train ? (stats != nullptr && count > 0) : (running_mean && running_var), VINCE_E_ARG,
+                    "vince_bn_finalize: missing statistics");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats,
+                       (double)count, C, gamma, beta, running_mean, running_var, nbt, momentum, eps, train, scale, shift,
+                       save_mean, save_invstd);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* identity,
+                              const float* id_scale, const float* id_shift, void* out, int64_t rows, int32_t C,
+                              int relu, void* stream) {
+    DTYPE_OK("vince_bn_apply");
+    VINCE_CHECK_ARG(y && scale && shift && out && rows > 0, VINCE_E_ARG, "vince_bn_apply: bad arguments");
+    VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
+    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 4096);
+    dim3 grid(w.colgroups, w.rowblocks);
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, scale, shift,
+                           (const float*)identity, id_scale, id_shift, (float*)out, rows, C, relu, w);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, scale,
+                           shift, (const bf16_t*)identity, id_scale, id_shift, (bf16_t*)out, rows, C, relu, w);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_src, const void* y, const float* mean,
+                                   const float* invstd, double* sums, int64_t rows, int32_t C, void* stream) {
+    DTYPE_OK("vince_bn_bwd_reduce");
+    VINCE_CHECK_ARG(dz && y && mean && invstd && sums && rows > 0, VINCE_E_ARG, "vince_bn_bwd_reduce: bad arguments");
+    VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_bwd_reduce: C=%d not a multiple of %d", C, CH_OF(dtype));
+    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 2048);
+    dim3 grid(w.colgroups, w.rowblocks);
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
+                           (const float*)mask_src, (const float*)y, mean, invstd, sums, rows, C, w);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz,
+                           (const bf16_t*)mask_src, (const bf16_t*)y, mean, invstd, sums, rows, C, w);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_src, const void* y, const float* mean,
+                                  const float* invstd, const float* gamma, const double* sums, int64_t count, void* dy,
+                                  void* g_out, float* dgamma, float* dbeta, int64_t rows, int32_t C, void* stream) {
+    DTYPE_OK("vince_bn_bwd_apply");
+    VINCE_CHECK_ARG(dz && y && mean && invstd && gamma && sums && dy && rows > 0 && count > 0, VINCE_E_ARG,
+                    "vince_bn_bwd_apply: bad arguments");
+    VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_bwd_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
+    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 4096);
+    dim3 grid(w.colgroups, w.rowblocks);
+    const double inv_count = 1.0 / (double)count;
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
+                           (const float*)mask_src, (const float*)y, mean, invstd, gamma, sums, inv_count, (float*)dy,
+                           (float*)g_out, dgamma, dbeta, rows, C, w);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz,
+                           (const bf16_t*)mask_src, (const bf16_t*)y, mean, invstd, gamma, sums, inv_count, (bf16_t*)dy,
+                           (bf16_t*)g_out, dgamma, dbeta, rows, C, w);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_stem_pool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out,
+                                   uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    DTYPE_OK("vince_stem_pool_fwd");
+    VINCE_CHECK_ARG(y && scale && shift && out && argmax && N > 0 && H > 0 && W > 0, VINCE_E_ARG, "vince_stem_pool_fwd: bad arguments");
+    VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_stem_pool_fwd: C=%d not a multiple of %d", C, CH_OF(dtype));
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / CH_OF(dtype));
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(stem_pool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)y, scale, shift, (float*)out, argmax, N, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(stem_pool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)y, scale, shift, (bf16_t*)out, argmax, N, H, W, C, Ho, Wo);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_stem_pool_bwd(int dtype, const void* dpool, const uint8_t* argmax, void* g, int32_t N, int32_t H,
+                                   int32_t W, int32_t C, void* stream) {
+    DTYPE_OK("vince_stem_pool_bwd");
+    VINCE_CHECK_ARG(dpool && argmax && g && N > 0 && H > 0 && W > 0, VINCE_E_ARG, "vince_stem_pool_bwd: bad arguments");
+    VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_stem_pool_bwd: C=%d not a multiple of %d", C, CH_OF(dtype));
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * H * W * (C / CH_OF(dtype));
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(stem_pool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)dpool, argmax, (float*)g, N, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(stem_pool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dpool, argmax, (bf16_t*)g, N, H, W, C, Ho, Wo);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_avgpool_fwd(int dtype, const void* x, float* out, int32_t N, int32_t HW, int32_t C, void* stream) {
+    DTYPE_OK("vince_avgpool_fwd");
+    VINCE_CHECK_ARG(x && out && N > 0 && HW > 0, VINCE_E_ARG, "vince_avgpool_fwd: bad arguments");
+    VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_avgpool_fwd: C=%d not a multiple of %d", C, CH_OF(dtype));
+    const int total = N * (C / CH_OF(dtype));
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, out, N, HW, C);
+    else
+        hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, out, N, HW, C);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_avgpool_bwd(int dtype, const float* dout, void* dx, int32_t N, int32_t HW, int32_t C, void* stream) {
+    DTYPE_OK("vince_avgpool_bwd");
+    VINCE_CHECK_ARG(dout && dx && N > 0 && HW > 0, VINCE_E_ARG, "vince_avgpool_bwd: bad arguments");
+    VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_avgpool_bwd: C=%d not a multiple of %d", C, CH_OF(dtype));
+    const int64_t total = (int64_t)N * HW * (C / CH_OF(dtype));
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout,
+                           (float*)dx, N, HW, C);
+    else
+        hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout,
+                           (bf16_t*)dx, N, HW, C);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}

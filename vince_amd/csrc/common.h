@@ -1,0 +1,146 @@
+// Shared device/host helpers for the VINCE MI355X (gfx950) kernels.
+// wave = 64 lanes, 256 CUs in 8 XCDs, MFMA 32x32 tiles, 16-byte vector memory ops everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/vince_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define VINCE_NUM_XCD 8
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: every export returns int, never throws; message kept thread-local
+// ---------------------------------------------------------------------------------------------
+void vince_set_error(const char* fmt, ...);
+
+#define VINCE_CHECK_ARG(cond, code, ...)   \
+    do {                                   \
+        if (!(cond)) {                     \
+            vince_set_error(__VA_ARGS__);  \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+#define VINCE_CHECK_HIP(expr)                                                                   \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            vince_set_error("HIP error %s at %s:%d", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return VINCE_E_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+#define VINCE_CHECK_LAUNCH() VINCE_CHECK_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------
+// bf16 <-> f32 (round-to-nearest-even), element traits
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline float bf16_to_f32(bf16_t h) {
+    union { uint32_t u; float f; } v;
+    v.u = ((uint32_t)h) << 16;
+    return v.f;
+}
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } v;
+    v.f = f;
+    uint32_t u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int CH = 4;  // elements per 16-byte chunk
+    static constexpr int LOG2_CH = 2;
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int CH = 8;
+    static constexpr int LOG2_CH = 3;
+};
+
+// A 16-byte chunk viewed as CH elements of T, converted to/from float.
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    __device__ static inline void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+        f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Chunk<bf16_t> {
+    __device__ static inline void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// division by a runtime constant (host precomputes); exact for n < 2^31, d < 2^31
+// ---------------------------------------------------------------------------------------------
+struct FastDiv {
+    uint32_t mul, shift, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d == 1) { f.mul = 0; f.shift = 0; return f; }
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;                       // l = ceil(log2 d)
+    uint64_t m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+    f.mul = (uint32_t)m;
+    f.shift = l;
+    return f;
+}
+__host__ __device__ inline uint32_t fastdiv(uint32_t n, const FastDiv& f) {
+    if (f.d == 1) return n;
+#ifdef __HIP_DEVICE_COMPILE__
+    uint32_t t = __umulhi(n, f.mul);
+#else
+    uint32_t t = (uint32_t)(((uint64_t)n * f.mul) >> 32);
+#endif
+    // (t + ((n - t) >> 1)) >> (shift - 1)   -- Granlund-Montgomery round-up method
+    return (t + ((n - t) >> 1)) >> (f.shift - 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// XCD-aware block remap: blocks that the dispatcher round-robins over the 8 XCDs are remapped so every XCD
+// works on one contiguous range of tiles (its private 4 MiB L2 then sees the operand reuse).  Bijective for any
+// grid size (cdna_hip_programming.md T1).
+// ---------------------------------------------------------------------------------------------
+__device__ inline uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
+    uint32_t xcd = bid % VINCE_NUM_XCD, s = bid / VINCE_NUM_XCD;
+    uint32_t q = nblk / VINCE_NUM_XCD, r = nblk % VINCE_NUM_XCD;
+    uint32_t base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + s;
+}
+
+// wave-level helpers (64 lanes)
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

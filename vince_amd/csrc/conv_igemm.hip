@@ -1,0 +1,327 @@
+// Generalised tap convolution as an implicit GEMM on the gfx950 matrix cores.
+//
+// Replaces the reference's conv2d / nn.Linear call sites (models/building_blocks/resnet.py:34-50,170;
+// models/vince_model.py:38-42) and their input-gradient halves.  See include/vince_hip.h for the op definition.
+//
+// Mapping to the hardware
+//   GEMM:  D[co][pix] = sum_k  W[co][k] * X[pix][k],   k = (tap, ci) with ci fastest -> both operands are
+//          K-contiguous in HBM (weights [Co][T][Ci], activations NHWC), so every global access is a 16-byte
+//          chunk (8 bf16 / 4 f32) and a wavefront reads whole 64-byte row segments.
+//   Tile:  128 pixels x CT (64|128) output channels per 256-thread workgroup (4 waves as 2x2), K step = 64 bytes.
+//          Each wave owns 64 pixels x CT/2 channels as 32x32 MFMA tiles: v_mfma_f32_32x32x16_bf16 (bf16) or
+//          4 x v_mfma_f32_32x32x2_f32 per 16-byte fragment (exact fp32).  A and B fragments are the same 16 bytes
+//          per lane at row (lane&31), k-offset (lane>>5)*16 B, so the dtype only changes the MFMA, not the loads.
+//   LDS:   register-staged double buffer (global -> VGPR -> ds_write_b128), rows padded 64 -> 80 B so the
+//          ds_read_b128 fragment reads of 16 consecutive rows land on 16 distinct 16-B slots (conflict free).
+//   Store: accumulators hold one pixel per lane and 4 consecutive channels per register group; the tile is
+//          transposed through LDS and written as full 16-byte chunks along the channel axis (coalesced NHWC rows).
+//          The optional BatchNorm statistics (per-channel sum / sum of squares of the values just stored) are
+//          reduced in registers -> shuffles -> LDS -> one fp64 atomic per channel per workgroup.
+//   Grid:  1-D, remapped so that each XCD (private L2) owns a contiguous range of tiles; channel tiles of the
+//          same pixel tile are adjacent and re-read the activation tile from that L2.
+#include "common.h"
+
+namespace {
+
+struct ConvParams {
+    vince_conv_desc d;
+    int log2_cpt, cpt_mask, total_chunks, nkt, M, ptiles, ctiles;
+    uint32_t tb_mul;
+    FastDiv div_howo, div_wo;
+    const void* in;
+    const void* w;
+    void* out;
+    const float* bias;
+    double* stats;
+    int flags;
+};
+
+constexpr int PT = 128;   // pixels per workgroup tile
+constexpr int RS = 80;    // LDS row stride in bytes for the 64-byte K slices
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static inline void run(const uint4& a, const uint4& b, f32x16_t& c) {
+        bf16x8_t av, bv;
+        __builtin_memcpy(&av, &a, 16);
+        __builtin_memcpy(&bv, &b, 16);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // the 4 floats of a fragment are 4 different k; lanes 0-31 / 32-63 carry k and k+4 -- any pairing of k between
+    // the two halves is fine as long as A and B use the same one.
+    __device__ static inline void run(const uint4& a, const uint4& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int CT>
+struct Smem {
+    static constexpr int MAIN = 2 * (CT + PT) * RS;
+    static constexpr int CRS = CT * (int)sizeof(T) + 16;   // epilogue tile row stride (bytes)
+    static constexpr int EPI = PT * CRS + 4 * CT * 2 * 4;   // + statistics scratch
+    static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
+};
+
+template <typename T, int CT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int CH = Elem<T>::CH;
+    constexpr int CJ = CT / 64;          // 32-channel MFMA tiles per wave
+    constexpr int WROWS = CT / 64;       // weight rows staged per thread (64 rows per pass)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Smem<T, CT>::BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wp = wave >> 1;
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int ptile = tile / p.ctiles, ctile = tile - ptile * p.ctiles;
+    const int p0 = ptile * PT, c0 = ctile * CT;
+    const vince_conv_desc& d = p.d;
+
+    // ---- per-thread staging assignment: chunk column cj of rows r and r+64 --------------------------------
+    const int cj = tid & 3, r = tid >> 2;
+    int hb[2], wb[2];
+    size_t nb[2];
+    bool rv[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        uint32_t m = p0 + r + e * 64;
+        rv[e] = m < (uint32_t)p.M;
+        uint32_t mm = rv[e] ? m : 0;
+        uint32_t n = fastdiv(mm, p.div_howo);
+        uint32_t rem = mm - n * p.div_howo.d;
+        uint32_t ho = fastdiv(rem, p.div_wo);
+        uint32_t wo = rem - ho * p.div_wo.d;
+        hb[e] = ho * d.sh;
+        wb[e] = wo * d.sw;
+        nb[e] = (size_t)n * d.Hi * d.Wi;
+    }
+    const T* __restrict__ in = (const T*)p.in;
+    const T* __restrict__ wgt = (const T*)p.w;
+
+    uint4 xr[2], wr[WROWS];
+    auto load_tile = [&](int kt) {
+        const int q = kt * 4 + cj;
+        const int tap = q >> p.log2_cpt, cc = q & p.cpt_mask;
+        const int a = (int)(((uint32_t)tap * p.tb_mul) >> 16), b = tap - a * d.TB;
+        const int dh = d.dh0 + a * d.dhs, dw = d.dw0 + b * d.dws;
+        const int widx = d.wt0 + a * d.wta + b * d.wtb;
+        const bool qv = q < p.total_chunks;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int hi = hb[e] + dh, wi = wb[e] + dw;
+            const bool ok = rv[e] && qv && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *(const uint4*)(in + (nb[e] + (size_t)hi * d.Wi + wi) * d.Ci + (size_t)cc * CH);
+            xr[e] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < WROWS; ++e) {
+            const int co = c0 + r + e * 64;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (qv && co < d.Co) v = *(const uint4*)(wgt + ((size_t)co * d.WT + widx) * d.Ci + (size_t)cc * CH);
+            wr[e] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* ws = smem + buf * (CT + PT) * RS;
+        unsigned char* xs = ws + CT * RS;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) *(uint4*)(xs + (r + e * 64) * RS + cj * 16) = xr[e];
+#pragma unroll
+        for (int e = 0; e < WROWS; ++e) *(uint4*)(ws + (r + e * 64) * RS + cj * 16) = wr[e];
+    };
+
+    f32x16_t acc[CJ][2];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int frag_off = (lane & 31) * RS + (lane >> 5) * 16;
+    for (int kt = 0; kt < p.nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < p.nkt) load_tile(kt + 1);
+        const unsigned char* ws = smem + buf * (CT + PT) * RS + (wc * (CT / 2)) * RS + frag_off;
+        const unsigned char* xs = smem + buf * (CT + PT) * RS + CT * RS + (wp * 64) * RS + frag_off;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 wf[CJ], xf[2];
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) wf[j] = *(const uint4*)(ws + j * 32 * RS + s * 32);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xf[i] = *(const uint4*)(xs + i * 32 * RS + s * 32);
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+        }
+        if (kt + 1 < p.nkt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS [pixel][channel] as T -> coalesced 16-byte stores --------------------
+    constexpr int CRS = Smem<T, CT>::CRS;
+#pragma unroll
+    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pix = wp * 64 + i * 32 + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = wc * (CT / 2) + j * 32 + 8 * g + 4 * (lane >> 5);
+                unsigned char* dst = smem + pix * CRS + ch * (int)sizeof(T);
+                if constexpr (sizeof(T) == 4) {
+                    *(float4*)dst = make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2],
+                                                acc[j][i][4 * g + 3]);
+                } else {
+                    *(uint2*)dst = make_uint2(pack_bf16x2(acc[j][i][4 * g], acc[j][i][4 * g + 1]),
+                                              pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]));
+                }
+            }
+        }
+    __syncthreads();
+
+    constexpr int CPR = CT * (int)sizeof(T) / 16;   // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CPR;                  // rows per pass
+    const int chunk = tid % CPR, row0 = tid / CPR;
+    const int cbase = c0 + chunk * CH;
+    const bool cvalid = cbase < d.Co;
+    float bias_v[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) bias_v[e] = (p.bias && cvalid) ? p.bias[cbase + e] : 0.f;
+    float ssum[CH], ssq[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) ssum[e] = ssq[e] = 0.f;
+    T* __restrict__ out = (T*)p.out;
+    const bool identity_map = (d.osh == 1 && d.osw == 1 && d.oh0 == 0 && d.ow0 == 0 && d.OH == d.Ho && d.OW == d.Wo);
+    for (int row = row0; row < PT; row += RPP) {
+        const uint32_t m = p0 + row;
+        if (m >= (uint32_t)p.M || !cvalid) continue;
+        size_t opix = m;
+        if (!identity_map) {
+            uint32_t n = fastdiv(m, p.div_howo);
+            uint32_t rem = m - n * p.div_howo.d;
+            uint32_t ho = fastdiv(rem, p.div_wo);
+            uint32_t wo = rem - ho * p.div_wo.d;
+            opix = ((size_t)n * d.OH + (ho * d.osh + d.oh0)) * d.OW + (wo * d.osw + d.ow0);
+        }
+        uint4 v = *(const uint4*)(smem + row * CRS + chunk * 16);
+        T* optr = out + opix * d.Co + cbase;
+        if (p.bias || (p.flags & (VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU))) {
+            float f[CH];
+            Chunk<T>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) f[e] += bias_v[e];
+            if (p.flags & VINCE_EPI_ACCUMULATE) {
+                float o[CH];
+                Chunk<T>::unpack(*(const uint4*)optr, o);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) f[e] += o[e];
+            }
+            if (p.flags & VINCE_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
+            }
+            v = Chunk<T>::pack(f);
+        }
+        *(uint4*)optr = v;
+        if (p.stats) {
+            float f[CH];
+            Chunk<T>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) { ssum[e] += f[e]; ssq[e] += f[e] * f[e]; }
+        }
+    }
+    if (p.stats) {   // uniform branch
+        float* red = (float*)(smem + PT * CRS);      // [4 waves][CPR][CH][2]
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], o, 64);
+                ssq[e] += __shfl_xor(ssq[e], o, 64);
+            }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                red[((wave * CPR + lane) * CH + e) * 2 + 0] = ssum[e];
+                red[((wave * CPR + lane) * CH + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        // CPR <= 32: chunk column ck sits in lane ck of every wave; thread t finalises (channel, which) = (t>>1, t&1)
+        static_assert(CPR <= 32, "statistics reduction assumes at most 32 chunks per tile row");
+        for (int t = tid; t < CT * 2; t += 256) {
+            const int ch = t >> 1, which = t & 1;
+            const int ck = ch / CH, e = ch % CH;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += red[((w * CPR + ck) * CH + e) * 2 + which];
+            if (c0 + ch < d.Co) unsafeAtomicAdd(p.stats + (size_t)(c0 + ch) * 2 + which, (double)s);
+        }
+    }
+}
+
+template <typename T, int CT>
+int launch(const ConvParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL((conv_igemm_kernel<T, CT>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+}  // namespace
+
+extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void* in, const void* w, void* out,
+                                const float* bias, double* stats, int flags, void* stream) {
+    VINCE_CHECK_ARG(dd && in && w && out, VINCE_E_ARG, "vince_conv_igemm: null pointer");
+    VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_igemm: bad dtype %d", dtype);
+    const vince_conv_desc& d = *dd;
+    const int CH = dtype == VINCE_F32 ? 4 : 8;
+    VINCE_CHECK_ARG(d.N > 0 && d.Hi > 0 && d.Wi > 0 && d.Ho > 0 && d.Wo > 0 && d.Co > 0 && d.Ci > 0, VINCE_E_SHAPE,
+                    "vince_conv_igemm: non-positive dimension");
+    VINCE_CHECK_ARG(d.Ci % CH == 0, VINCE_E_SHAPE, "vince_conv_igemm: Ci=%d not a multiple of %d", d.Ci, CH);
+    VINCE_CHECK_ARG(d.Co % CH == 0, VINCE_E_SHAPE, "vince_conv_igemm: Co=%d not a multiple of %d", d.Co, CH);
+    VINCE_CHECK_ARG(d.TA >= 1 && d.TB >= 1 && d.TB <= 8 && d.TA * d.TB <= 64, VINCE_E_SHAPE,
+                    "vince_conv_igemm: tap grid %dx%d unsupported", d.TA, d.TB);
+    VINCE_CHECK_ARG((long long)d.N * d.Ho * d.Wo < (1ll << 31), VINCE_E_SHAPE, "vince_conv_igemm: too many output pixels");
+    VINCE_CHECK_ARG((((uintptr_t)in | (uintptr_t)w | (uintptr_t)out) & 15) == 0, VINCE_E_ALIGN,
+                    "vince_conv_igemm: pointers must be 16-byte aligned");
+    ConvParams p;
+    p.d = d;
+    const int T = d.TA * d.TB, cpt = d.Ci / CH;
+    if (T == 1) {
+        p.log2_cpt = 31;
+        p.cpt_mask = 0x7fffffff;
+    } else {
+        VINCE_CHECK_ARG((cpt & (cpt - 1)) == 0, VINCE_E_SHAPE,
+                        "vince_conv_igemm: Ci/%d = %d must be a power of two for multi-tap convs", CH, cpt);
+        int l = 0;
+        while ((1 << l) < cpt) ++l;
+        p.log2_cpt = l;
+        p.cpt_mask = cpt - 1;
+    }
+    p.total_chunks = T * cpt;
+    p.nkt = (p.total_chunks + 3) / 4;
+    p.M = d.N * d.Ho * d.Wo;
+    p.tb_mul = (65536 + d.TB - 1) / d.TB;
+    p.div_howo = make_fastdiv((uint32_t)(d.Ho * d.Wo));
+    p.div_wo = make_fastdiv((uint32_t)d.Wo);
+    p.in = in; p.w = w; p.out = out; p.bias = bias; p.stats = stats; p.flags = flags;
+    p.ptiles = (p.M + PT - 1) / PT;
+    const bool narrow = d.Co <= 64;
+    const int CT = narrow ? 64 : 128;
+    p.ctiles = (d.Co + CT - 1) / CT;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VINCE_F32) return narrow ? launch<float, 64>(p, s) : launch<float, 128>(p, s);
+    return narrow ? launch<bf16_t, 64>(p, s) : launch<bf16_t, 128>(p, s);
+}

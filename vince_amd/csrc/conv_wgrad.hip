@@ -1,0 +1,279 @@
+// Weight gradient of the generalised tap convolution: a "TN" GEMM whose reduction axis is the output pixel.
+//
+//   dw[co][tap][ci] += sum_pix dy[pix][co] * x[pix @ tap][ci]
+//
+// Replaces the weight-gradient half of the reference's conv2d / nn.Linear autograd (resnet.py:34-50,170;
+// vince_model.py:38-42 under loss.backward(), solvers/vince_solver.py:463-468).
+//
+// Both operands are contiguous along the NON-reduced axis (channels), the opposite of what an MFMA fragment
+// wants (8 consecutive k per lane).  The tiles are staged [pixel][channel] in LDS exactly as they sit in HBM
+// (16-byte coalesced chunks) and the fragments are fetched with the gfx950 LDS transpose read
+// ds_read_b64_tr_b16 (bf16) or with conflict-free ds_read_b32 (f32: one k per lane per v_mfma_f32_32x32x2_f32).
+// Work split: (Co tile) x (tap*Ci tile) x (split of the pixel range); partial tiles are accumulated with
+// fp32 atomics straight into the gradient buffer (rows of 32 consecutive floats per wave instruction).
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+    vince_conv_desc d;
+    int log2_cpt, cpt_mask, log2_ci, total_nchunks, M, nkt_total, kt_per_split, ctiles, ntiles, Ci_dw, variant;
+    uint32_t tb_mul;
+    FastDiv div_howo, div_wo;
+    const void* in;
+    const void* dy;
+    float* dw;
+};
+
+constexpr int KP = 32;  // pixels per K tile
+
+template <typename T, int CT, int NT>
+struct WSmem {
+    static constexpr int YRS = CT * (int)sizeof(T) + 16;
+    static constexpr int XRS = NT * (int)sizeof(T) + 16;
+    static constexpr int BUF = KP * (YRS + XRS);
+    static constexpr int BYTES = 2 * BUF;
+};
+
+// 32(k=16.. see below) fragment fetch: returns the 16 bytes an MFMA lane needs for column `col0 + (lane&31)`
+// and k-group (lane>>5) of k-step ks, from an LDS tile stored [k][column] with row stride rs bytes.
+template <typename T> struct FragT;
+template <> struct FragT<bf16_t> {
+    static constexpr int KSTEPS = KP / 16;
+    __device__ static inline uint4 load(const unsigned char* tile, int rs, int col0, int ks, int lane, int variant) {
+        uint4 out;
+        if (variant == 0) {
+            const int g = lane >> 4, t = lane & 15;
+            const int col = col0 + 16 * (g & 1) + (t & 3) * 4;
+            const int row = ks * 16 + (g >> 1) * 8 + (t >> 2);
+            const unsigned char* a0 = tile + row * rs + col * 2;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 4 * rs));
+            __builtin_memcpy(&out.x, &lo, 8);
+            __builtin_memcpy(&out.z, &hi, 8);
+        } else {
+            const unsigned char* a0 = tile + (ks * 16 + (lane >> 5) * 8) * rs + (col0 + (lane & 31)) * 2;
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *(const uint16_t*)(a0 + k * rs);
+            out = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+        }
+        return out;
+    }
+    __device__ static inline void mma(const uint4& a, const uint4& b, f32x16_t& c) {
+        bf16x8_t av, bv;
+        __builtin_memcpy(&av, &a, 16);
+        __builtin_memcpy(&bv, &b, 16);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+    }
+};
+template <> struct FragT<float> {
+    static constexpr int KSTEPS = KP / 8;   // 4 x (32x32x2) per fetch of 4 k
+    __device__ static inline uint4 load(const unsigned char* tile, int rs, int col0, int ks, int lane, int) {
+        // lane reads k = ks*8 + (lane>>5)*4 + {0..3} for column col0 + (lane&31): 4 conflict-free ds_read_b32
+        const unsigned char* a0 = tile + (ks * 8 + (lane >> 5) * 4) * rs + (col0 + (lane & 31)) * 4;
+        return make_uint4(*(const uint32_t*)a0, *(const uint32_t*)(a0 + rs), *(const uint32_t*)(a0 + 2 * rs),
+                          *(const uint32_t*)(a0 + 3 * rs));
+    }
+    __device__ static inline void mma(const uint4& a, const uint4& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int CT, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int CH = Elem<T>::CH;
+    using S = WSmem<T, CT, NT>;
+    constexpr int CPRY = CT / CH, CPRX = NT / CH;          // 16-byte chunks per tile row
+    constexpr int NY = (KP * CPRY) / 256 > 0 ? (KP * CPRY) / 256 : 1;
+    constexpr int NX = (KP * CPRX) / 256 > 0 ? (KP * CPRX) / 256 : 1;
+    constexpr int RPY = 256 / CPRY, RPX = 256 / CPRX;       // rows covered per pass
+    constexpr int CJ = CT / 64, NJ = NT / 64;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wn = wave >> 1;
+    const int ctile = blockIdx.x % p.ctiles, ntile = blockIdx.x / p.ctiles;
+    const int c0 = ctile * CT, n0 = ntile * NT;
+    const vince_conv_desc& d = p.d;
+    const int kt_begin = blockIdx.y * p.kt_per_split;
+    const int kt_end = min(kt_begin + p.kt_per_split, p.nkt_total);
+    if (kt_begin >= kt_end) return;
+
+    const T* __restrict__ in = (const T*)p.in;
+    const T* __restrict__ dy = (const T*)p.dy;
+
+    // dy staging: chunk column ycol, rows yrow + e*RPY
+    const int ycol = tid % CPRY, yrow = tid / CPRY;
+    const bool yvalid_c = (c0 + ycol * CH) < d.Co && yrow < KP;
+    // x staging: chunk column xcol -> fixed (tap, ci chunk)
+    const int xcol = tid % CPRX, xrow = tid / CPRX;
+    const int qn = n0 / CH + xcol;
+    const int tap = qn >> p.log2_cpt, cc = qn & p.cpt_mask;
+    const int ta = (int)(((uint32_t)tap * p.tb_mul) >> 16), tb = tap - ta * d.TB;
+    const int dh = d.dh0 + ta * d.dhs, dw_ = d.dw0 + tb * d.dws;
+    const bool xvalid_c = qn < p.total_nchunks && xrow < KP;
+
+    uint4 yr[NY], xr[NX];
+    auto load_tile = [&](int kt) {
+        const uint32_t pix0 = (uint32_t)kt * KP;
+#pragma unroll
+        for (int e = 0; e < NY; ++e) {
+            const uint32_t pix = pix0 + yrow + e * RPY;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (yvalid_c && pix < (uint32_t)p.M) v = *(const uint4*)(dy + (size_t)pix * d.Co + c0 + ycol * CH);
+            yr[e] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < NX; ++e) {
+            const uint32_t pix = pix0 + xrow + e * RPX;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (xvalid_c && pix < (uint32_t)p.M) {
+                const uint32_t n = fastdiv(pix, p.div_howo);
+                const uint32_t rem = pix - n * p.div_howo.d;
+                const uint32_t ho = fastdiv(rem, p.div_wo);
+                const uint32_t wo = rem - ho * p.div_wo.d;
+                const int hi = (int)(ho * d.sh) + dh, wi = (int)(wo * d.sw) + dw_;
+                if ((unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi)
+                    v = *(const uint4*)(in + (((size_t)n * d.Hi + hi) * d.Wi + wi) * d.Ci + (size_t)cc * CH);
+            }
+            xr[e] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* ys = smem + buf * S::BUF;
+        unsigned char* xs = ys + KP * S::YRS;
+#pragma unroll
+        for (int e = 0; e < NY; ++e)
+            if (yrow + e * RPY < KP) *(uint4*)(ys + (yrow + e * RPY) * S::YRS + ycol * 16) = yr[e];
+#pragma unroll
+        for (int e = 0; e < NX; ++e)
+            if (xrow + e * RPX < KP) *(uint4*)(xs + (xrow + e * RPX) * S::XRS + xcol * 16) = xr[e];
+    };
+
+    f32x16_t acc[CJ][NJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+
+    load_tile(kt_begin);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+        const unsigned char* ys = smem + buf * S::BUF;
+        const unsigned char* xs = ys + KP * S::YRS;
+#pragma unroll
+        for (int ks = 0; ks < FragT<T>::KSTEPS; ++ks) {
+            uint4 af[CJ], bf[NJ];
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) af[j] = FragT<T>::load(ys, S::YRS, wc * (CT / 2) + j * 32, ks, lane, p.variant);
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) bf[i] = FragT<T>::load(xs, S::XRS, wn * (NT / 2) + i * 32, ks, lane, p.variant);
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) FragT<T>::mma(af[j], bf[i], acc[j][i]);
+        }
+        if (kt + 1 < kt_end) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- accumulate the partial tile into dw (fp32 atomics; 32 consecutive floats per row per instruction) ----
+    const int T_ = d.TA * d.TB;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        const int n = n0 + wn * (NT / 2) + i * 32 + (lane & 31);
+        const int tp = (T_ == 1) ? 0 : (n >> p.log2_ci);
+        const int ci = (T_ == 1) ? n : (n & ((1 << p.log2_ci) - 1));
+        if (tp >= T_ || ci >= p.Ci_dw || (T_ == 1 && n >= d.Ci)) continue;
+        const int a = (int)(((uint32_t)tp * p.tb_mul) >> 16), b = tp - a * d.TB;
+        const int widx = d.wt0 + a * d.wta + b * d.wtb;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = c0 + wc * (CT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < d.Co) unsafeAtomicAdd(p.dw + ((size_t)co * d.WT + widx) * p.Ci_dw + ci, acc[j][i][r]);
+            }
+        }
+    }
+}
+
+template <typename T, int CT, int NT>
+int launch(const WgradParams& p, int splits, hipStream_t stream) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, CT, NT>), dim3(p.ctiles * p.ntiles, splits), dim3(256), 0, stream, p);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+template <typename T>
+int dispatch(WgradParams& p, hipStream_t stream) {
+    const vince_conv_desc& d = p.d;
+    const int ntot = d.TA * d.TB * d.Ci;
+    const int CT = d.Co <= 64 ? 64 : 128, NT = ntot <= 64 ? 64 : 128;
+    p.ctiles = (d.Co + CT - 1) / CT;
+    p.ntiles = (ntot + NT - 1) / NT;
+    p.nkt_total = (p.M + KP - 1) / KP;
+    // enough workgroups to fill 256 CUs a few times over, but at least 8 K-tiles (256 pixels) per split
+    const int tiles = p.ctiles * p.ntiles;
+    int splits = (1536 + tiles - 1) / tiles;
+    const int max_splits = (p.nkt_total + 7) / 8;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.kt_per_split = (p.nkt_total + splits - 1) / splits;
+    splits = (p.nkt_total + p.kt_per_split - 1) / p.kt_per_split;
+    if (CT == 64 && NT == 64) return launch<T, 64, 64>(p, splits, stream);
+    if (CT == 64) return launch<T, 64, 128>(p, splits, stream);
+    if (NT == 64) return launch<T, 128, 64>(p, splits, stream);
+    return launch<T, 128, 128>(p, splits, stream);
+}
+
+}  // namespace
+
+extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void* in, const void* dy, float* dw,
+                                int32_t Ci_dw, int variant, void* stream) {
+    VINCE_CHECK_ARG(dd && in && dy && dw, VINCE_E_ARG, "vince_conv_wgrad: null pointer");
+    VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_wgrad: bad dtype %d", dtype);
+    const vince_conv_desc& d = *dd;
+    const int CH = dtype == VINCE_F32 ? 4 : 8;
+    VINCE_CHECK_ARG(d.N > 0 && d.Hi > 0 && d.Wi > 0 && d.Ho > 0 && d.Wo > 0 && d.Co > 0 && d.Ci > 0, VINCE_E_SHAPE,
+                    "vince_conv_wgrad: non-positive dimension");
+    VINCE_CHECK_ARG(d.Ci % CH == 0 && d.Co % CH == 0, VINCE_E_SHAPE, "vince_conv_wgrad: Ci=%d / Co=%d not multiples of %d",
+                    d.Ci, d.Co, CH);
+    VINCE_CHECK_ARG(Ci_dw >= 1 && Ci_dw <= d.Ci, VINCE_E_SHAPE, "vince_conv_wgrad: Ci_dw=%d out of range", Ci_dw);
+    VINCE_CHECK_ARG(d.TA >= 1 && d.TB >= 1 && d.TB <= 8 && d.TA * d.TB <= 64, VINCE_E_SHAPE,
+                    "vince_conv_wgrad: tap grid %dx%d unsupported", d.TA, d.TB);
+    VINCE_CHECK_ARG((long long)d.N * d.Ho * d.Wo < (1ll << 31), VINCE_E_SHAPE, "vince_conv_wgrad: too many pixels");
+    VINCE_CHECK_ARG((((uintptr_t)in | (uintptr_t)dy) & 15) == 0, VINCE_E_ALIGN, "vince_conv_wgrad: pointers must be 16-byte aligned");
+    WgradParams p;
+    p.d = d;
+    const int T = d.TA * d.TB, cpt = d.Ci / CH;
+    if (T == 1) {
+        p.log2_cpt = 31;
+        p.cpt_mask = 0x7fffffff;
+        p.log2_ci = 30;
+    } else {
+        VINCE_CHECK_ARG((cpt & (cpt - 1)) == 0, VINCE_E_SHAPE, "vince_conv_wgrad: Ci/%d = %d must be a power of two", CH, cpt);
+        int l = 0;
+        while ((1 << l) < cpt) ++l;
+        p.log2_cpt = l;
+        p.cpt_mask = cpt - 1;
+        p.log2_ci = l + (dtype == VINCE_F32 ? 2 : 3);
+    }
+    p.total_nchunks = T * cpt;
+    p.M = d.N * d.Ho * d.Wo;
+    p.tb_mul = (65536 + d.TB - 1) / d.TB;
+    p.div_howo = make_fastdiv((uint32_t)(d.Ho * d.Wo));
+    p.div_wo = make_fastdiv((uint32_t)d.Wo);
+    p.in = in; p.dy = dy; p.dw = dw; p.Ci_dw = Ci_dw; p.variant = variant;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == VINCE_F32 ? dispatch<float>(p, s) : dispatch<bf16_t>(p, s);
+}

@@ -1,0 +1,329 @@
+// Layout transforms, head glue (L2 normalise, ReLU backward, bias gradient), FIFO queue write, momentum (EMA) update
+// and SGD -- the bandwidth-bound odds and ends of the path.
+//
+// Reference call sites: batch shuffle gather vince_model.py:137-142; jigsaw tiling :144-155; F.normalize :180;
+// StorageQueue.enqueue utils/storage_queue.py:31-49; VinceQueueModel.param_update vince_model.py:587-592;
+// optim.SGD vince_solver.py:256,469.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void input_to_nhwc_kernel(const float* __restrict__ in, const int64_t* __restrict__ perm,
+                                                            T* __restrict__ out, int N, int C, int H, int W, int Cp) {
+    const int64_t total = (int64_t)N * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t hw = idx % ((int64_t)H * W);
+        const int n = (int)(idx / ((int64_t)H * W));
+        const int64_t src_n = perm ? perm[n] : n;
+        float f[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[c] = (c < C) ? in[((size_t)src_n * C + c) * H * W + hw] : 0.f;
+        if constexpr (sizeof(T) == 4) {
+            *(float4*)((float*)out + (size_t)idx * Cp) = make_float4(f[0], f[1], f[2], f[3]);
+        } else {
+            *(uint4*)((bf16_t*)out + (size_t)idx * Cp) = Chunk<bf16_t>::pack(f);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void jigsaw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int N,
+                                                             int C, int H, int W, int th, int tw, int Cp) {
+    // out image index = n*9 + ty*3 + tx (vince_model.py:151-155: permute(0,2,4,1,3,5) then merge dims 0,1,2)
+    const int64_t total = (int64_t)N * 9 * th * tw;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int x = (int)(idx % tw);
+        int64_t r = idx / tw;
+        const int y = (int)(r % th);
+        r /= th;
+        const int tile = (int)(r % 9);
+        const int n = (int)(r / 9);
+        const int sy = (tile / 3) * th + y, sx = (tile % 3) * tw + x;
+        float f[8];
+        const bool inside = sy < H && sx < W;   // zero padding on the bottom/right (F.pad, vince_model.py:146)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[c] = (c < C && inside) ? in[(((size_t)n * C + c) * H + sy) * W + sx] : 0.f;
+        if constexpr (sizeof(T) == 4) {
+            *(float4*)((float*)out + (size_t)idx * Cp) = make_float4(f[0], f[1], f[2], f[3]);
+        } else {
+            *(uint4*)((bf16_t*)out + (size_t)idx * Cp) = Chunk<bf16_t>::pack(f);
+        }
+    }
+}
+
+template <typename T> __device__ inline T cvt_from_f32(float f);
+template <> __device__ inline float cvt_from_f32<float>(float f) { return f; }
+template <> __device__ inline bf16_t cvt_from_f32<bf16_t>(float f) { return f32_to_bf16(f); }
+template <typename T> __device__ inline float cvt_to_f32(T v);
+template <> __device__ inline float cvt_to_f32<float>(float v) { return v; }
+template <> __device__ inline float cvt_to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void prepare_weight_kernel(const float* __restrict__ w, T* __restrict__ wk,
+                                                             T* __restrict__ wt, int Co, int Tt, int Ci, int Cip) {
+    const int64_t total = (int64_t)Co * Tt * Cip;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(idx % Cip);
+        const int64_t r = idx / Cip;
+        const int t = (int)(r % Tt);
+        const int co = (int)(r / Tt);
+        const float v = ci < Ci ? w[((size_t)co * Tt + t) * Ci + ci] : 0.f;
+        const T o = cvt_from_f32<T>(v);
+        wk[idx] = o;
+        if (wt && ci < Ci) wt[((size_t)ci * Tt + t) * Co + co] = o;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int N,
+                                                           int C, int H, int W) {
+    const int64_t total = (int64_t)N * C * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t hw = idx % ((int64_t)H * W);
+        const int64_t r = idx / ((int64_t)H * W);
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        out[idx] = cvt_to_f32<T>(in[((size_t)n * H * W + hw) * C + c]);
+    }
+}
+
+// one wavefront per row
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                         float* __restrict__ norms, int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) { const float v = x[(size_t)row * D + i]; s += v * v; }
+    s = wave_sum(s);
+    const float nrm = sqrtf(s), den = fmaxf(nrm, eps);   // F.normalize: x / max(||x||, eps)
+    for (int i = lane; i < D; i += 64) out[(size_t)row * D + i] = x[(size_t)row * D + i] / den;
+    if (lane == 0 && norms) norms[row] = nrm;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ norms,
+                                                         const float* __restrict__ dout, float* __restrict__ dx,
+                                                         int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float nrm = norms[row];
+    if (nrm > eps) {
+        float dot = 0.f;
+        for (int i = lane; i < D; i += 64) dot += dout[(size_t)row * D + i] * x[(size_t)row * D + i];
+        dot = wave_sum(dot);
+        const float inv = 1.f / nrm, k = dot * inv * inv * inv;
+        for (int i = lane; i < D; i += 64) dx[(size_t)row * D + i] = dout[(size_t)row * D + i] * inv - x[(size_t)row * D + i] * k;
+    } else {
+        for (int i = lane; i < D; i += 64) dx[(size_t)row * D + i] = dout[(size_t)row * D + i] / eps;
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ act,
+                                                       float* __restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i] = act[i] > 0.f ? dout[i] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
+                                                     int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += x[(size_t)r * cols + c];
+    out[c] += s;
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ k, const float* __restrict__ q, int64_t n, float m,
+                                                  float one_minus_m) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 a = ((float4*)k)[i];
+        const float4 b = ((const float4*)q)[i];
+        // mul_(m) then add_(alpha=1-m): round the product first, then a fused multiply-add like torch's CPU kernel
+        a.x = fmaf(one_minus_m, b.x, a.x * m); a.y = fmaf(one_minus_m, b.y, a.y * m);
+        a.z = fmaf(one_minus_m, b.z, a.z * m); a.w = fmaf(one_minus_m, b.w, a.w * m);
+        ((float4*)k)[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        k[i] = fmaf(one_minus_m, q[i], k[i] * m);
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  int64_t n, float lr, float mom, float wd, float gs) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pv = ((float4*)p)[i];
+        const float4 gv = ((const float4*)g)[i];
+        float4 bv = ((float4*)buf)[i];
+        float d;
+        d = fmaf(wd, pv.x, gv.x * gs); bv.x = fmaf(bv.x, mom, d); pv.x = fmaf(-lr, bv.x, pv.x);
+        d = fmaf(wd, pv.y, gv.y * gs); bv.y = fmaf(bv.y, mom, d); pv.y = fmaf(-lr, bv.y, pv.y);
+        d = fmaf(wd, pv.z, gv.z * gs); bv.z = fmaf(bv.z, mom, d); pv.z = fmaf(-lr, bv.z, pv.z);
+        d = fmaf(wd, pv.w, gv.w * gs); bv.w = fmaf(bv.w, mom, d); pv.w = fmaf(-lr, bv.w, pv.w);
+        ((float4*)p)[i] = pv;
+        ((float4*)buf)[i] = bv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float d = fmaf(wd, p[i], g[i] * gs);
+        const float b = fmaf(buf[i], mom, d);
+        buf[i] = b;
+        p[i] = fmaf(-lr, b, p[i]);
+    }
+}
+
+inline int grid_for(int64_t total_threads) {
+    int64_t b = (total_threads + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+#define DTYPE_OK(fn) VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, fn ": bad dtype %d", dtype)
+
+extern "C" int vince_input_nchw_to_nhwc(int dtype, const float* in, const int64_t* perm, void* out, int32_t N, int32_t C,
+                                        int32_t H, int32_t W, int32_t Cp, void* stream) {
+    DTYPE_OK("vince_input_nchw_to_nhwc");
+    VINCE_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0, VINCE_E_ARG, "vince_input_nchw_to_nhwc: bad arguments");
+    VINCE_CHECK_ARG(C >= 1 && C <= Cp && Cp == (dtype == VINCE_F32 ? 4 : 8), VINCE_E_SHAPE,
+                    "vince_input_nchw_to_nhwc: C=%d Cp=%d unsupported", C, Cp);
+    const int64_t total = (int64_t)N * H * W;
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(input_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, perm,
+                           (float*)out, N, C, H, W, Cp);
+    else
+        hipLaunchKernelGGL(input_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, perm,
+                           (bf16_t*)out, N, C, H, W, Cp);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_jigsaw_nchw_to_nhwc(int dtype, const float* in, void* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                                         int32_t th, int32_t tw, int32_t Cp, void* stream) {
+    DTYPE_OK("vince_jigsaw_nchw_to_nhwc");
+    VINCE_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0 && th > 0 && tw > 0, VINCE_E_ARG, "vince_jigsaw_nchw_to_nhwc: bad arguments");
+    VINCE_CHECK_ARG(C >= 1 && C <= Cp && Cp == (dtype == VINCE_F32 ? 4 : 8), VINCE_E_SHAPE,
+                    "vince_jigsaw_nchw_to_nhwc: C=%d Cp=%d unsupported", C, Cp);
+    VINCE_CHECK_ARG(3 * th >= H && 3 * tw >= W, VINCE_E_SHAPE, "vince_jigsaw_nchw_to_nhwc: tiles %dx%d do not cover %dx%d", th, tw, H, W);
+    const int64_t total = (int64_t)N * 9 * th * tw;
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(jigsaw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                           (float*)out, N, C, H, W, th, tw, Cp);
+    else
+        hipLaunchKernelGGL(jigsaw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                           (bf16_t*)out, N, C, H, W, th, tw, Cp);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_prepare_weight(int dtype, const float* w, void* wk, void* wt, int32_t Co, int32_t T, int32_t Ci,
+                                    int32_t Cip, void* stream) {
+    DTYPE_OK("vince_prepare_weight");
+    VINCE_CHECK_ARG(w && wk && Co > 0 && T > 0 && Ci > 0 && Cip >= Ci, VINCE_E_ARG, "vince_prepare_weight: bad arguments");
+    const int64_t total = (int64_t)Co * T * Cip;
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(prepare_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w,
+                           (float*)wk, (float*)wt, Co, T, Ci, Cip);
+    else
+        hipLaunchKernelGGL(prepare_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w,
+                           (bf16_t*)wk, (bf16_t*)wt, Co, T, Ci, Cip);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_nhwc_to_nchw_f32(int dtype, const void* in, float* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                                      void* stream) {
+    DTYPE_OK("vince_nhwc_to_nchw_f32");
+    VINCE_CHECK_ARG(in && out && N > 0 && C > 0 && H > 0 && W > 0, VINCE_E_ARG, "vince_nhwc_to_nchw_f32: bad arguments");
+    const int64_t total = (int64_t)N * C * H * W;
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)in, out, N, C, H, W);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)in, out, N, C, H, W);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_l2norm_fwd(const float* x, float* out, float* norms, int32_t rows, int32_t D, float eps, void* stream) {
+    VINCE_CHECK_ARG(x && out && rows > 0 && D > 0, VINCE_E_ARG, "vince_l2norm_fwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, out, norms, rows, D, eps);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_l2norm_bwd(const float* x, const float* norms, const float* dout, float* dx, int32_t rows, int32_t D,
+                                float eps, void* stream) {
+    VINCE_CHECK_ARG(x && norms && dout && dx && rows > 0 && D > 0, VINCE_E_ARG, "vince_l2norm_bwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, norms, dout, dx, rows, D, eps);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_relu_bwd(const float* dout, const float* act, float* dx, int64_t n, void* stream) {
+    VINCE_CHECK_ARG(dout && act && dx && n > 0, VINCE_E_ARG, "vince_relu_bwd: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dout, act, dx, n);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_colsum(const float* x, float* out, int32_t rows, int32_t cols, void* stream) {
+    VINCE_CHECK_ARG(x && out && rows > 0 && cols > 0, VINCE_E_ARG, "vince_colsum: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, rows, cols);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_queue_enqueue(float* queue, int64_t K, int64_t D, const float* items, int64_t n, int64_t* tail,
+                                   int32_t* full, void* stream) {
+    VINCE_CHECK_ARG(queue && items && tail && full && K > 0 && D > 0 && n >= 0, VINCE_E_ARG, "vince_queue_enqueue: bad arguments");
+    VINCE_CHECK_ARG(*tail >= 0 && *tail <= K, VINCE_E_ARG, "vince_queue_enqueue: tail %lld outside [0, %lld]", (long long)*tail, (long long)K);
+    // utils/storage_queue.py:31-49 -- integer index arithmetic restated exactly: a write that would cross the end fills
+    // [tail, K), resets tail to 0, marks the queue full and recurses on the remainder (possibly several laps).
+    int64_t t = *tail, src = 0;
+    while (true) {
+        if (t + n > K) {
+            const int64_t num_start = K - t;
+            if (num_start > 0)
+                VINCE_CHECK_HIP(hipMemcpyAsync(queue + t * D, items + src * D, (size_t)num_start * D * sizeof(float),
+                                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            t = 0;
+            *full = 1;
+            src += num_start;
+            n -= num_start;
+        } else {
+            if (n > 0)
+                VINCE_CHECK_HIP(hipMemcpyAsync(queue + t * D, items + src * D, (size_t)n * D * sizeof(float),
+                                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            t += n;
+            break;
+        }
+    }
+    *tail = t;
+    return VINCE_OK;
+}
+
+extern "C" int vince_ema_flat(float* key, const float* query, int64_t n, float momentum, void* stream) {
+    VINCE_CHECK_ARG(key && query && n > 0, VINCE_E_ARG, "vince_ema_flat: bad arguments");
+    VINCE_CHECK_ARG((((uintptr_t)key | (uintptr_t)query) & 15) == 0, VINCE_E_ALIGN, "vince_ema_flat: pointers must be 16-byte aligned");
+    const float omm = (float)(1.0 - (double)momentum);
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, key, query, n, momentum, omm);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_sgd_flat(float* param, const float* grad, float* buf, int64_t n, float lr, float momentum,
+                              float weight_decay, float grad_scale, void* stream) {
+    VINCE_CHECK_ARG(param && grad && buf && n > 0, VINCE_E_ARG, "vince_sgd_flat: bad arguments");
+    VINCE_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)buf) & 15) == 0, VINCE_E_ALIGN,
+                    "vince_sgd_flat: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad, buf, n, lr,
+                       momentum, weight_decay, grad_scale);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}

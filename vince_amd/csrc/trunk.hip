@@ -1,0 +1,457 @@
+// Trunk engine: sequences the ResNet-18/50 trunk (conv1 .. layer4, i.e. the first 8 children that
+// models/building_blocks/backbone_models.py:39-54 runs for final_layer=-2) plus the global average pool
+// (vince_model.py:33) forward and backward on one HIP stream.  Pure host-side planning + launches of the kernels
+// in conv_igemm.hip / conv_wgrad.hip / bn_pool.hip / misc.hip; no device code here.
+//
+// Memory plan (all inside one caller-provided workspace, sized for 288 GB parts: nothing is recomputed):
+//   x0                      input as NHWC with channels padded 3 -> 4 (f32) / 8 (bf16)
+//   per conv: y             raw conv output (BatchNorm input), kept for backward
+//   per BN+ReLU: a / z      activation, kept for backward (ReLU mask + next conv's wgrad operand)
+//   stats / sums            fp64 [C][2] per BN for the forward statistics and the backward reductions
+//   consts                  per BN: scale, shift, batch mean, invstd (float[C] each)
+//   4 gradient scratch buffers of the largest activation size (dZ, dY, dA, dX roles rotate)
+#include <array>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct ConvL {
+    int Ci, Cip, Co, k, stride, pad, Hi, Wi, Ho, Wo;
+    int param;          // index into params[]
+    size_t wk, wt;      // byte offsets in the weight cache (wt == SIZE_MAX: none)
+    std::string name;
+};
+struct BnL {
+    int C, gamma, beta, index;   // param indices + bn index
+    size_t stats, sums, consts;  // stats/sums: offset in doubles; consts: offset in floats
+    std::string name;
+};
+struct Blk {
+    int nconv;
+    ConvL c[3];
+    BnL b[3];
+    bool has_ds;
+    ConvL cd;
+    BnL bd;
+    size_t x_in, y[3], a[2], yd, z;   // byte offsets in workspace
+};
+
+constexpr size_t NONE = (size_t)-1;
+
+}  // namespace
+
+struct vince_trunk {
+    vince_trunk_cfg cfg;
+    int esize, CH, Cp;
+    std::vector<Blk> blocks;
+    ConvL stem;
+    BnL stem_bn;
+    int sH, sW, pH, pW;   // stem conv output, pool output
+    int outC, outH, outW;
+    int nparams, nbn;
+    std::vector<std::string> pnames;
+    std::vector<int> pkind, pbn;
+    std::vector<std::array<int, 4>> pshape;
+    std::vector<std::string> bnnames;
+    std::vector<int> bnC;
+    size_t off_x0, off_ystem, off_amax, off_p0, off_stats, off_sums, off_consts, off_g[4];
+    size_t n_stats_doubles, n_consts_floats, max_act, ws_bytes, wc_bytes;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Planner {
+    vince_trunk* t;
+    size_t ws = 0, wc = 0, nd = 0, nf = 0;
+    size_t alloc_act(size_t elems) {
+        size_t off = ws;
+        size_t bytes = elems * t->esize;
+        if (bytes > t->max_act) t->max_act = bytes;
+        ws = align_up(ws + bytes);
+        return off;
+    }
+    ConvL conv(const std::string& name, int Ci, int Co, int k, int stride, int pad, int Hi, int Wi, bool want_wt) {
+        ConvL c;
+        c.name = name;
+        c.Ci = Ci;
+        c.Cip = Ci < t->CH ? t->Cp : Ci;
+        c.Co = Co; c.k = k; c.stride = stride; c.pad = pad; c.Hi = Hi; c.Wi = Wi;
+        c.Ho = (Hi + 2 * pad - k) / stride + 1;
+        c.Wo = (Wi + 2 * pad - k) / stride + 1;
+        c.param = (int)t->pnames.size();
+        t->pnames.push_back(name + ".weight");
+        t->pkind.push_back(0);
+        t->pbn.push_back(-1);
+        t->pshape.push_back({Co, Ci, k, k});
+        c.wk = wc;
+        wc = align_up(wc + (size_t)Co * k * k * c.Cip * t->esize);
+        if (want_wt) {
+            c.wt = wc;
+            wc = align_up(wc + (size_t)Ci * k * k * Co * t->esize);
+        } else {
+            c.wt = NONE;
+        }
+        return c;
+    }
+    BnL bn(const std::string& name, int C) {
+        BnL b;
+        b.name = name;
+        b.C = C;
+        b.index = (int)t->bnnames.size();
+        t->bnnames.push_back(name);
+        t->bnC.push_back(C);
+        b.gamma = (int)t->pnames.size();
+        t->pnames.push_back(name + ".weight");
+        t->pkind.push_back(1);
+        t->pbn.push_back(b.index);
+        t->pshape.push_back({C, 0, 0, 0});
+        b.beta = (int)t->pnames.size();
+        t->pnames.push_back(name + ".bias");
+        t->pkind.push_back(2);
+        t->pbn.push_back(b.index);
+        t->pshape.push_back({C, 0, 0, 0});
+        b.stats = nd; b.sums = nd;   // sums live in a parallel region of the same size
+        nd += (size_t)2 * C;
+        b.consts = nf;
+        nf += (size_t)4 * C;
+        return b;
+    }
+};
+
+vince_conv_desc fwd_desc(const vince_trunk* t, const ConvL& c) {
+    vince_conv_desc d;
+    d.N = t->cfg.N; d.Hi = c.Hi; d.Wi = c.Wi; d.Ci = c.Cip;
+    d.Ho = c.Ho; d.Wo = c.Wo; d.Co = c.Co;
+    d.sh = d.sw = c.stride;
+    d.TA = d.TB = c.k;
+    d.dh0 = d.dw0 = -c.pad; d.dhs = d.dws = 1;
+    d.wt0 = 0; d.wta = c.k; d.wtb = 1; d.WT = c.k * c.k;
+    d.OH = c.Ho; d.OW = c.Wo; d.osh = d.osw = 1; d.oh0 = d.ow0 = 0;
+    return d;
+}
+
+// dgrad descriptors (one per output-pixel parity class for stride 2): input = dY, "weights" = W^T [Ci][T][Co]
+int dgrad_descs(const vince_trunk* t, const ConvL& c, vince_conv_desc out[4]) {
+    int n = 0;
+    const int s = c.stride, k = c.k, p = c.pad;
+    for (int ph = 0; ph < s; ++ph)
+        for (int pw = 0; pw < s; ++pw) {
+            const int r0 = (ph + p) % s, s0 = (pw + p) % s;
+            const int TA = r0 < k ? (k - r0 + s - 1) / s : 0, TB = s0 < k ? (k - s0 + s - 1) / s : 0;
+            const int gh = c.Hi > ph ? (c.Hi - ph + s - 1) / s : 0, gw = c.Wi > pw ? (c.Wi - pw + s - 1) / s : 0;
+            if (TA == 0 || TB == 0 || gh == 0 || gw == 0) continue;
+            vince_conv_desc d;
+            d.N = t->cfg.N; d.Hi = c.Ho; d.Wi = c.Wo; d.Ci = c.Co;
+            d.Ho = gh; d.Wo = gw; d.Co = c.Ci;
+            d.sh = d.sw = 1;
+            d.TA = TA; d.TB = TB;
+            d.dh0 = (ph + p - r0) / s; d.dhs = -1;
+            d.dw0 = (pw + p - s0) / s; d.dws = -1;
+            d.wt0 = r0 * k + s0; d.wta = s * k; d.wtb = s; d.WT = k * k;
+            d.OH = c.Hi; d.OW = c.Wi; d.osh = d.osw = s; d.oh0 = ph; d.ow0 = pw;
+            out[n++] = d;
+        }
+    return n;
+}
+
+inline unsigned char* at(void* ws, size_t off) { return (unsigned char*)ws + off; }
+
+}  // namespace
+
+extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out) {
+    VINCE_CHECK_ARG(cfg && out, VINCE_E_ARG, "vince_trunk_create: null pointer");
+    VINCE_CHECK_ARG(cfg->arch == 18 || cfg->arch == 50, VINCE_E_UNSUPPORTED, "vince_trunk_create: arch %d (18 or 50)", cfg->arch);
+    VINCE_CHECK_ARG(cfg->dtype == VINCE_F32 || cfg->dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_trunk_create: bad dtype");
+    VINCE_CHECK_ARG(cfg->N > 0 && cfg->H >= 8 && cfg->W >= 8, VINCE_E_SHAPE, "vince_trunk_create: bad input shape");
+    vince_trunk* t = new vince_trunk();
+    t->cfg = *cfg;
+    t->esize = cfg->dtype == VINCE_F32 ? 4 : 2;
+    t->CH = cfg->dtype == VINCE_F32 ? 4 : 8;
+    t->Cp = t->CH;
+    t->max_act = 0;
+    Planner P{t};
+    const int N = cfg->N;
+    t->off_x0 = P.alloc_act((size_t)N * cfg->H * cfg->W * t->Cp);
+    t->stem = P.conv("conv1", 3, 64, 7, 2, 3, cfg->H, cfg->W, false);
+    t->stem_bn = P.bn("bn1", 64);
+    t->sH = t->stem.Ho; t->sW = t->stem.Wo;
+    t->pH = (t->sH + 2 - 3) / 2 + 1; t->pW = (t->sW + 2 - 3) / 2 + 1;
+    t->off_ystem = P.alloc_act((size_t)N * t->sH * t->sW * 64);
+    t->off_p0 = P.alloc_act((size_t)N * t->pH * t->pW * 64);
+    t->off_amax = P.ws;
+    P.ws = align_up(P.ws + (size_t)N * t->pH * t->pW * 64);
+
+    const bool bottleneck = cfg->arch == 50;
+    const int layers18[4] = {2, 2, 2, 2}, layers50[4] = {3, 4, 6, 3};
+    const int* layers = bottleneck ? layers50 : layers18;
+    const int expansion = bottleneck ? 4 : 1;
+    int inpl = 64, H = t->pH, W = t->pW;
+    size_t cur = t->off_p0;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = 64 << li;
+        for (int bi = 0; bi < layers[li]; ++bi) {
+            const int stride = (li > 0 && bi == 0) ? 2 : 1;
+            const std::string pre = "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+            const int outp = planes * expansion;
+            Blk b;
+            b.x_in = cur;
+            b.a[0] = b.a[1] = b.yd = NONE;
+            b.y[0] = b.y[1] = b.y[2] = NONE;
+            if (!bottleneck) {   // resnet.py:53-92
+                b.nconv = 2;
+                b.c[0] = P.conv(pre + "conv1", inpl, planes, 3, stride, 1, H, W, true);
+                b.b[0] = P.bn(pre + "bn1", planes);
+                b.c[1] = P.conv(pre + "conv2", planes, planes, 3, 1, 1, b.c[0].Ho, b.c[0].Wo, true);
+                b.b[1] = P.bn(pre + "bn2", planes);
+            } else {             // resnet.py:95-137, stride on the 3x3
+                b.nconv = 3;
+                b.c[0] = P.conv(pre + "conv1", inpl, planes, 1, 1, 0, H, W, true);
+                b.b[0] = P.bn(pre + "bn1", planes);
+                b.c[1] = P.conv(pre + "conv2", planes, planes, 3, stride, 1, H, W, true);
+                b.b[1] = P.bn(pre + "bn2", planes);
+                b.c[2] = P.conv(pre + "conv3", planes, outp, 1, 1, 0, b.c[1].Ho, b.c[1].Wo, true);
+                b.b[2] = P.bn(pre + "bn3", outp);
+            }
+            b.has_ds = (bi == 0) && (stride != 1 || inpl != outp);   // resnet.py:205-208
+            if (b.has_ds) {
+                b.cd = P.conv(pre + "downsample.0", inpl, outp, 1, stride, 0, H, W, true);
+                b.bd = P.bn(pre + "downsample.1", outp);
+            }
+            const int Ho = b.c[b.nconv - 1].Ho, Wo = b.c[b.nconv - 1].Wo;
+            for (int ci = 0; ci < b.nconv; ++ci) {
+                b.y[ci] = P.alloc_act((size_t)N * b.c[ci].Ho * b.c[ci].Wo * b.c[ci].Co);
+                if (ci < b.nconv - 1) b.a[ci] = P.alloc_act((size_t)N * b.c[ci].Ho * b.c[ci].Wo * b.c[ci].Co);
+            }
+            if (b.has_ds) b.yd = P.alloc_act((size_t)N * Ho * Wo * outp);
+            b.z = P.alloc_act((size_t)N * Ho * Wo * outp);
+            cur = b.z;
+            inpl = outp; H = Ho; W = Wo;
+            t->blocks.push_back(b);
+        }
+    }
+    t->outC = inpl; t->outH = H; t->outW = W;
+    t->nparams = (int)t->pnames.size();
+    t->nbn = (int)t->bnnames.size();
+    t->n_stats_doubles = P.nd;
+    t->n_consts_floats = P.nf;
+    t->off_stats = P.ws; P.ws = align_up(P.ws + P.nd * sizeof(double));
+    t->off_sums = P.ws; P.ws = align_up(P.ws + P.nd * sizeof(double));
+    t->off_consts = P.ws; P.ws = align_up(P.ws + P.nf * sizeof(float));
+    for (int i = 0; i < 4; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
+    t->ws_bytes = P.ws;
+    t->wc_bytes = P.wc;
+    *out = t;
+    return VINCE_OK;
+}
+
+extern "C" void vince_trunk_destroy(vince_trunk_t t) { delete t; }
+extern "C" int32_t vince_trunk_num_params(vince_trunk_t t) { return t ? t->nparams : 0; }
+extern "C" int32_t vince_trunk_num_bn(vince_trunk_t t) { return t ? t->nbn : 0; }
+extern "C" int32_t vince_trunk_out_channels(vince_trunk_t t) { return t ? t->outC : 0; }
+extern "C" int32_t vince_trunk_out_hw(vince_trunk_t t, int32_t* h, int32_t* w) {
+    if (!t) return VINCE_E_ARG;
+    if (h) *h = t->outH;
+    if (w) *w = t->outW;
+    return VINCE_OK;
+}
+extern "C" size_t vince_trunk_workspace_bytes(vince_trunk_t t) { return t ? t->ws_bytes : 0; }
+extern "C" size_t vince_trunk_weight_cache_bytes(vince_trunk_t t) { return t ? t->wc_bytes : 0; }
+
+extern "C" int vince_trunk_param_info(vince_trunk_t t, int32_t idx, char* name, int32_t name_cap, int32_t* kind,
+                                      int32_t shape[4], int32_t* bn_index) {
+    VINCE_CHECK_ARG(t && idx >= 0 && idx < t->nparams, VINCE_E_ARG, "vince_trunk_param_info: bad index %d", idx);
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", t->pnames[idx].c_str());
+    if (kind) *kind = t->pkind[idx];
+    if (shape) for (int i = 0; i < 4; ++i) shape[i] = t->pshape[idx][i];
+    if (bn_index) *bn_index = t->pbn[idx];
+    return VINCE_OK;
+}
+
+extern "C" int vince_trunk_bn_info(vince_trunk_t t, int32_t bn_index, char* name, int32_t name_cap, int32_t* channels) {
+    VINCE_CHECK_ARG(t && bn_index >= 0 && bn_index < t->nbn, VINCE_E_ARG, "vince_trunk_bn_info: bad index %d", bn_index);
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", t->bnnames[bn_index].c_str());
+    if (channels) *channels = t->bnC[bn_index];
+    return VINCE_OK;
+}
+
+extern "C" const void* vince_trunk_spatial_ptr(vince_trunk_t t, const void* workspace) {
+    if (!t || !workspace) return nullptr;
+    return (const unsigned char*)workspace + t->blocks.back().z;
+}
+
+namespace {
+
+int prep_one(vince_trunk* t, const ConvL& c, const float* const* params, void* wcache, void* stream) {
+    return vince_prepare_weight(t->cfg.dtype, params[c.param], at(wcache, c.wk), c.wt == NONE ? nullptr : at(wcache, c.wt),
+                                c.Co, c.k * c.k, c.Ci, c.Cip, stream);
+}
+
+struct Ctx {
+    vince_trunk* t;
+    const float* const* params;
+    const void* wcache;
+    void* ws;
+    void* stream;
+    int dtype;
+    float* consts(const BnL& b, int which) { return (float*)at(ws, t->off_consts) + b.consts + (size_t)which * b.C; }
+    double* stats(const BnL& b) { return (double*)at(ws, t->off_stats) + b.stats; }
+    double* sums(const BnL& b) { return (double*)at(ws, t->off_sums) + b.sums; }
+};
+
+#define RC(expr) do { int _rc = (expr); if (_rc != VINCE_OK) return _rc; } while (0)
+
+int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_off, float* const* bn_running,
+                int64_t* const* bn_nbt, int train_bn) {
+    vince_conv_desc d = fwd_desc(c.t, cv);
+    RC(vince_conv_igemm(&d, c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), nullptr,
+                        train_bn ? c.stats(bn) : nullptr, 0, c.stream));
+    const int64_t count = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
+    RC(vince_bn_finalize(c.stats(bn), count, bn.C, c.params[bn.gamma], c.params[bn.beta], bn_running[2 * bn.index],
+                         bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr, 0.1f, 1e-5f, train_bn,
+                         c.consts(bn, 0), c.consts(bn, 1), c.consts(bn, 2), c.consts(bn, 3), c.stream));
+    return VINCE_OK;
+}
+
+int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate) {
+    vince_conv_desc ds[4];
+    const int n = dgrad_descs(c.t, cv, ds);
+    const int classes = cv.stride * cv.stride;
+    if (!accumulate && n < classes)   // some pixel classes receive no gradient (1x1 stride 2): zero them
+        VINCE_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)c.t->cfg.N * cv.Hi * cv.Wi * cv.Ci * c.t->esize, (hipStream_t)c.stream));
+    for (int i = 0; i < n; ++i)
+        RC(vince_conv_igemm(&ds[i], c.dtype, dy, at((void*)c.wcache, cv.wt), dx, nullptr, nullptr,
+                            accumulate ? VINCE_EPI_ACCUMULATE : 0, c.stream));
+    return VINCE_OK;
+}
+
+int wgrad(Ctx& c, const ConvL& cv, const void* in, const void* dy, float* dw) {
+    vince_conv_desc d = fwd_desc(c.t, cv);
+    return vince_conv_wgrad(&d, c.dtype, in, dy, dw, cv.Ci, 0, c.stream);
+}
+
+// BN backward for y (conv output) given the gradient dz wrt the post-BN(+ReLU) activation `act` (mask source).
+int bn_bwd(Ctx& c, const BnL& bn, const void* dz, const void* mask_src, size_t y_off, int64_t rows, void* dy, void* g_out,
+           float* const* grads, bool reduce_done = false) {
+    if (!reduce_done)
+        RC(vince_bn_bwd_reduce(c.dtype, dz, mask_src, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3), c.sums(bn), rows, bn.C,
+                               c.stream));
+    RC(vince_bn_bwd_apply(c.dtype, dz, mask_src, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3), c.params[bn.gamma],
+                          c.sums(bn), rows, dy, g_out, grads[bn.gamma], grads[bn.beta], rows, bn.C, c.stream));
+    return VINCE_OK;
+}
+
+}  // namespace
+
+extern "C" int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* params, void* wcache, void* stream) {
+    VINCE_CHECK_ARG(t && params && wcache, VINCE_E_ARG, "vince_trunk_prepare_weights: null pointer");
+    RC(prep_one(t, t->stem, params, wcache, stream));
+    for (const Blk& b : t->blocks) {
+        for (int ci = 0; ci < b.nconv; ++ci) RC(prep_one(t, b.c[ci], params, wcache, stream));
+        if (b.has_ds) RC(prep_one(t, b.cd, params, wcache, stream));
+    }
+    return VINCE_OK;
+}
+
+extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void* wcache, float* const* bn_running,
+                                   int64_t* const* bn_nbt, const float* input, const int64_t* perm, int32_t jig_h,
+                                   int32_t jig_w, void* workspace, float* pooled, int32_t train_bn, void* stream) {
+    VINCE_CHECK_ARG(t && params && wcache && bn_running && input && workspace && pooled, VINCE_E_ARG,
+                    "vince_trunk_forward: null pointer");
+    VINCE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, VINCE_E_ALIGN,
+                    "vince_trunk_forward: workspace / weight cache must be 256-byte aligned");
+    Ctx c{t, params, wcache, workspace, stream, t->cfg.dtype};
+    const int N = t->cfg.N;
+    if (train_bn)
+        VINCE_CHECK_HIP(hipMemsetAsync(at(workspace, t->off_stats), 0, t->n_stats_doubles * sizeof(double), (hipStream_t)stream));
+    if (jig_h > 0) {
+        VINCE_CHECK_ARG(N % 9 == 0, VINCE_E_SHAPE, "vince_trunk_forward: jigsaw needs N multiple of 9");
+        RC(vince_jigsaw_nchw_to_nhwc(c.dtype, input, at(workspace, t->off_x0), N / 9, 3, jig_h, jig_w, t->cfg.H, t->cfg.W,
+                                     t->Cp, stream));
+    } else {
+        RC(vince_input_nchw_to_nhwc(c.dtype, input, perm, at(workspace, t->off_x0), N, 3, t->cfg.H, t->cfg.W, t->Cp, stream));
+    }
+    // stem: conv 7x7/s2 -> BN -> ReLU -> maxpool 3x3/s2 (resnet.py:170-173); BN-apply + ReLU are fused into the pool
+    RC(conv_bn_fwd(c, t->stem, t->stem_bn, t->off_x0, t->off_ystem, bn_running, bn_nbt, train_bn));
+    RC(vince_stem_pool_fwd(c.dtype, at(workspace, t->off_ystem), c.consts(t->stem_bn, 0), c.consts(t->stem_bn, 1),
+                           at(workspace, t->off_p0), (uint8_t*)at(workspace, t->off_amax), N, t->sH, t->sW, 64, stream));
+    for (const Blk& b : t->blocks) {
+        size_t in = b.x_in;
+        for (int ci = 0; ci < b.nconv; ++ci) {
+            RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn));
+            if (ci < b.nconv - 1) {
+                const int64_t rows = (int64_t)N * b.c[ci].Ho * b.c[ci].Wo;
+                RC(vince_bn_apply(c.dtype, at(workspace, b.y[ci]), c.consts(b.b[ci], 0), c.consts(b.b[ci], 1), nullptr, nullptr,
+                                  nullptr, at(workspace, b.a[ci]), rows, b.c[ci].Co, 1, stream));
+                in = b.a[ci];
+            }
+        }
+        const ConvL& last = b.c[b.nconv - 1];
+        const BnL& lbn = b.b[b.nconv - 1];
+        const int64_t rows = (int64_t)N * last.Ho * last.Wo;
+        if (b.has_ds) {
+            RC(conv_bn_fwd(c, b.cd, b.bd, b.x_in, b.yd, bn_running, bn_nbt, train_bn));
+            RC(vince_bn_apply(c.dtype, at(workspace, b.y[b.nconv - 1]), c.consts(lbn, 0), c.consts(lbn, 1), at(workspace, b.yd),
+                              c.consts(b.bd, 0), c.consts(b.bd, 1), at(workspace, b.z), rows, last.Co, 1, stream));
+        } else {
+            RC(vince_bn_apply(c.dtype, at(workspace, b.y[b.nconv - 1]), c.consts(lbn, 0), c.consts(lbn, 1), at(workspace, b.x_in),
+                              nullptr, nullptr, at(workspace, b.z), rows, last.Co, 1, stream));
+        }
+    }
+    RC(vince_avgpool_fwd(c.dtype, at(workspace, t->blocks.back().z), pooled, N, t->outH * t->outW, t->outC, stream));
+    return VINCE_OK;
+}
+
+extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params, const void* wcache, void* workspace,
+                                    const float* dpooled, float* const* grads, void* stream) {
+    VINCE_CHECK_ARG(t && params && wcache && workspace && dpooled && grads, VINCE_E_ARG, "vince_trunk_backward: null pointer");
+    Ctx c{t, params, wcache, workspace, stream, t->cfg.dtype};
+    const int N = t->cfg.N;
+    VINCE_CHECK_HIP(hipMemsetAsync(at(workspace, t->off_sums), 0, t->n_stats_doubles * sizeof(double), (hipStream_t)stream));
+    void* Z = at(workspace, t->off_g[0]);
+    void* DY = at(workspace, t->off_g[1]);
+    void* DA = at(workspace, t->off_g[2]);
+    void* DX = at(workspace, t->off_g[3]);
+    RC(vince_avgpool_bwd(c.dtype, dpooled, Z, N, t->outH * t->outW, t->outC, stream));
+    for (int bi = (int)t->blocks.size() - 1; bi >= 0; --bi) {
+        const Blk& b = t->blocks[bi];
+        const int L = b.nconv - 1;
+        const ConvL& last = b.c[L];
+        const int64_t rows_out = (int64_t)N * last.Ho * last.Wo;
+        const void* z = at(workspace, b.z);
+        const void* x_in = at(workspace, b.x_in);
+        // z = relu(bn_L(y_L) + identity): g = dz * (z > 0) is the gradient of both addends
+        if (b.has_ds) {
+            RC(bn_bwd(c, b.bd, Z, z, b.yd, rows_out, DY, nullptr, grads));
+            RC(wgrad(c, b.cd, x_in, DY, grads[b.cd.param]));
+            RC(dgrad(c, b.cd, DY, DX, false));
+            RC(bn_bwd(c, b.b[L], Z, z, b.y[L], rows_out, DY, nullptr, grads));
+        } else {
+            RC(bn_bwd(c, b.b[L], Z, z, b.y[L], rows_out, DY, DX, grads));   // DX <- g (identity branch)
+        }
+        for (int ci = L; ci >= 0; --ci) {
+            const void* in_act = ci == 0 ? x_in : at(workspace, b.a[ci - 1]);
+            RC(wgrad(c, b.c[ci], in_act, DY, grads[b.c[ci].param]));
+            if (ci > 0) {
+                RC(dgrad(c, b.c[ci], DY, DA, false));
+                const int64_t rows = (int64_t)N * b.c[ci - 1].Ho * b.c[ci - 1].Wo;
+                RC(bn_bwd(c, b.b[ci - 1], DA, at(workspace, b.a[ci - 1]), b.y[ci - 1], rows, DY, nullptr, grads));
+            } else {
+                RC(dgrad(c, b.c[0], DY, DX, true));
+            }
+        }
+        std::swap(Z, DX);
+    }
+    // stem: Z = gradient wrt the pooled stem output
+    RC(vince_stem_pool_bwd(c.dtype, Z, (const uint8_t*)at(workspace, t->off_amax), DA, N, t->sH, t->sW, 64, stream));
+    RC(bn_bwd(c, t->stem_bn, DA, nullptr, t->off_ystem, (int64_t)N * t->sH * t->sW, DY, nullptr, grads));
+    {
+        vince_conv_desc d = fwd_desc(t, t->stem);
+        RC(vince_conv_wgrad(&d, c.dtype, at(workspace, t->off_x0), DY, grads[t->stem.param], 3, 0, stream));
+    }
+    return VINCE_OK;
+}

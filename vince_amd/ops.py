@@ -1,0 +1,314 @@
+"""Tensor-level wrappers over the C ABI (include/vince_hip.h).
+
+Every function takes CUDA (ROCm) torch tensors, checks device / dtype / contiguity, and launches on torch's current
+stream.  Nothing here computes on the CPU: a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, InfoNCEDesc, VINCE_BF16, VINCE_F32, check, lib
+
+EPI_ACCUMULATE, EPI_RELU = _lib.EPI_ACCUMULATE, _lib.EPI_RELU
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return VINCE_F32
+    if t.dtype == torch.bfloat16:
+        return VINCE_BF16
+    raise TypeError("vince_amd: unsupported dtype %s (float32 or bfloat16)" % t.dtype)
+
+
+def torch_dtype(code):
+    return torch.float32 if code == VINCE_F32 else torch.bfloat16
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("vince_amd: tensor on %s -- the HIP path needs GPU tensors (no CPU fallback)" % t.device)
+        if not t.is_contiguous():
+            raise RuntimeError("vince_amd: tensor must be contiguous")
+
+
+# ------------------------------------------------------------------------------------------------ conv descriptors
+def conv_desc(N, Hi, Wi, Ci, Co, k, stride, pad):
+    """Forward descriptor of a k x k conv (also the wgrad descriptor)."""
+    Ho = (Hi + 2 * pad - k) // stride + 1
+    Wo = (Wi + 2 * pad - k) // stride + 1
+    return ConvDesc(N=N, Hi=Hi, Wi=Wi, Ci=Ci, Ho=Ho, Wo=Wo, Co=Co, sh=stride, sw=stride, TA=k, TB=k, dh0=-pad, dhs=1,
+                    dw0=-pad, dws=1, wt0=0, wta=k, wtb=1, WT=k * k, OH=Ho, OW=Wo, osh=1, osw=1, oh0=0, ow0=0)
+
+
+def dgrad_descs(N, Hi, Wi, Ci, Co, k, stride, pad):
+    """Input-gradient descriptors of the same conv: one per output-pixel parity class (csrc/trunk.hip dgrad_descs)."""
+    Ho = (Hi + 2 * pad - k) // stride + 1
+    Wo = (Wi + 2 * pad - k) // stride + 1
+    s = stride
+    out = []
+    for ph in range(s):
+        for pw in range(s):
+            r0, s0 = (ph + pad) % s, (pw + pad) % s
+            TA = (k - r0 + s - 1) // s if r0 < k else 0
+            TB = (k - s0 + s - 1) // s if s0 < k else 0
+            gh = (Hi - ph + s - 1) // s if Hi > ph else 0
+            gw = (Wi - pw + s - 1) // s if Wi > pw else 0
+            if not (TA and TB and gh and gw):
+                continue
+            out.append(ConvDesc(N=N, Hi=Ho, Wi=Wo, Ci=Co, Ho=gh, Wo=gw, Co=Ci, sh=1, sw=1, TA=TA, TB=TB,
+                                dh0=(ph + pad - r0) // s, dhs=-1, dw0=(pw + pad - s0) // s, dws=-1,
+                                wt0=r0 * k + s0, wta=s * k, wtb=s, WT=k * k, OH=Hi, OW=Wi, osh=s, osw=s, oh0=ph, ow0=pw))
+    return out
+
+
+def linear_desc(rows, cin, cout):
+    return conv_desc(rows, 1, 1, cin, cout, 1, 1, 0)
+
+
+def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0):
+    require_gpu(x, w, out, bias, stats)
+    check(lib().vince_conv_igemm(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(stats),
+                                 flags, stream_ptr()))
+    return out
+
+
+def conv_wgrad(desc, x, dy, dw, ci_dw=None, variant=0):
+    require_gpu(x, dy, dw)
+    if dw.dtype != torch.float32:
+        raise TypeError("vince_amd: weight gradients are float32")
+    check(lib().vince_conv_wgrad(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(dy), _ptr(dw),
+                                 desc.Ci if ci_dw is None else ci_dw, variant, stream_ptr()))
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------ linear layer helpers (fp32)
+def linear_fwd(x, weight, bias, relu=False):
+    """y = [relu](x @ weight.T + bias) on the fp32 MFMA path (vince_model.py:38-42)."""
+    rows, cin = x.shape
+    cout = weight.shape[0]
+    out = torch.empty(rows, cout, device=x.device, dtype=torch.float32)
+    conv_igemm(linear_desc(rows, cin, cout), x, weight, out, bias=bias, flags=EPI_RELU if relu else 0)
+    return out
+
+
+def linear_bwd(x, weight_t, dy, dweight, dbias, need_dx=True):
+    """dweight += dy.T @ x ; dbias += dy.sum(0) ; returns dx = dy @ weight (weight_t = weight.T contiguous)."""
+    rows, cin = x.shape
+    cout = dy.shape[1]
+    conv_wgrad(linear_desc(rows, cin, cout), x, dy, dweight)
+    require_gpu(dbias)
+    check(lib().vince_colsum(_ptr(dy), _ptr(dbias), rows, cout, stream_ptr()))
+    if not need_dx:
+        return None
+    dx = torch.empty(rows, cin, device=x.device, dtype=torch.float32)
+    conv_igemm(linear_desc(rows, cout, cin), dy, weight_t, dx)
+    return dx
+
+
+def relu_bwd(dout, act):
+    require_gpu(dout, act)
+    dx = torch.empty_like(dout)
+    check(lib().vince_relu_bwd(_ptr(dout), _ptr(act), _ptr(dx), dout.numel(), stream_ptr()))
+    return dx
+
+
+def l2norm_fwd(x, eps=1e-12):
+    require_gpu(x)
+    out = torch.empty_like(x)
+    norms = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+    check(lib().vince_l2norm_fwd(_ptr(x), _ptr(out), _ptr(norms), x.shape[0], x.shape[1], eps, stream_ptr()))
+    return out, norms
+
+
+def l2norm_bwd(x, norms, dout, eps=1e-12):
+    require_gpu(x, norms, dout)
+    dx = torch.empty_like(x)
+    check(lib().vince_l2norm_bwd(_ptr(x), _ptr(norms), _ptr(dout), _ptr(dx), x.shape[0], x.shape[1], eps, stream_ptr()))
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ batch norm / pooling
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, nbt, train, momentum=0.1, eps=1e-5):
+    C = gamma.numel()
+    consts = torch.empty(4, C, device=gamma.device, dtype=torch.float32)
+    require_gpu(stats, gamma, beta, running_mean, running_var, nbt)
+    check(lib().vince_bn_finalize(_ptr(stats), count, C, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                  _ptr(nbt), momentum, eps, int(train), _ptr(consts[0]), _ptr(consts[1]), _ptr(consts[2]),
+                                  _ptr(consts[3]), stream_ptr()))
+    return consts  # scale, shift, mean, invstd
+
+
+def bn_apply(y, scale, shift, identity=None, id_scale=None, id_shift=None, relu=True):
+    require_gpu(y, scale, shift, identity, id_scale, id_shift)
+    out = torch.empty_like(y)
+    C = y.shape[-1]
+    check(lib().vince_bn_apply(dtype_code(y), _ptr(y), _ptr(scale), _ptr(shift), _ptr(identity), _ptr(id_scale),
+                               _ptr(id_shift), _ptr(out), y.numel() // C, C, int(relu), stream_ptr()))
+    return out
+
+
+def bn_bwd(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, want_g=False):
+    require_gpu(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta)
+    C = y.shape[-1]
+    rows = y.numel() // C
+    sums = torch.zeros(C, 2, device=y.device, dtype=torch.float64)
+    check(lib().vince_bn_bwd_reduce(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums),
+                                    rows, C, stream_ptr()))
+    dy = torch.empty_like(y)
+    g = torch.empty_like(y) if want_g else None
+    check(lib().vince_bn_bwd_apply(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                   _ptr(sums), rows, _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), rows, C, stream_ptr()))
+    return dy, g
+
+
+def stem_pool_fwd(y, scale, shift):
+    require_gpu(y, scale, shift)
+    N, H, W, C = y.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = torch.empty(N, Ho, Wo, C, device=y.device, dtype=y.dtype)
+    amax = torch.empty(N, Ho, Wo, C, device=y.device, dtype=torch.uint8)
+    check(lib().vince_stem_pool_fwd(dtype_code(y), _ptr(y), _ptr(scale), _ptr(shift), _ptr(out), _ptr(amax), N, H, W, C,
+                                    stream_ptr()))
+    return out, amax
+
+
+def stem_pool_bwd(dpool, amax, H, W):
+    require_gpu(dpool, amax)
+    N, _, _, C = dpool.shape
+    g = torch.empty(N, H, W, C, device=dpool.device, dtype=dpool.dtype)
+    check(lib().vince_stem_pool_bwd(dtype_code(dpool), _ptr(dpool), _ptr(amax), _ptr(g), N, H, W, C, stream_ptr()))
+    return g
+
+
+def avgpool_fwd(x):
+    require_gpu(x)
+    N, H, W, C = x.shape
+    out = torch.empty(N, C, device=x.device, dtype=torch.float32)
+    check(lib().vince_avgpool_fwd(dtype_code(x), _ptr(x), _ptr(out), N, H * W, C, stream_ptr()))
+    return out
+
+
+def avgpool_bwd(dout, H, W, dtype):
+    require_gpu(dout)
+    N, C = dout.shape
+    dx = torch.empty(N, H, W, C, device=dout.device, dtype=dtype)
+    check(lib().vince_avgpool_bwd(dtype_code(dx), _ptr(dout), _ptr(dx), N, H * W, C, stream_ptr()))
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ layouts
+def input_nchw_to_nhwc(x, dtype, perm=None):
+    require_gpu(x, perm)
+    N, C, H, W = x.shape
+    Cp = 4 if dtype == torch.float32 else 8
+    out = torch.empty(N, H, W, Cp, device=x.device, dtype=dtype)
+    check(lib().vince_input_nchw_to_nhwc(dtype_code(out), _ptr(x), _ptr(perm), _ptr(out), N, C, H, W, Cp, stream_ptr()))
+    return out
+
+
+def jigsaw_nchw_to_nhwc(x, dtype):
+    require_gpu(x)
+    N, C, H, W = x.shape
+    # vince_model.py:145-146 pads BOTH axes by 3 - (size % 3) whenever either needs it
+    if H % 3 != 0 or W % 3 != 0:
+        Hp, Wp = H + 3 - H % 3, W + 3 - W % 3
+    else:
+        Hp, Wp = H, W
+    th, tw = Hp // 3, Wp // 3
+    Cp = 4 if dtype == torch.float32 else 8
+    out = torch.empty(N * 9, th, tw, Cp, device=x.device, dtype=dtype)
+    check(lib().vince_jigsaw_nchw_to_nhwc(dtype_code(out), _ptr(x), _ptr(out), N, C, H, W, th, tw, Cp, stream_ptr()))
+    return out
+
+
+def prepare_weight(w_master, dtype, cip=None, want_transposed=True):
+    """w_master: float32 [Co][T][Ci] contiguous.  Returns (wk [Co][T][Cip], wt [Ci][T][Co] or None)."""
+    require_gpu(w_master)
+    Co, T, Ci = w_master.shape
+    cip = Ci if cip is None else cip
+    wk = torch.empty(Co, T, cip, device=w_master.device, dtype=dtype)
+    wt = torch.empty(Ci, T, Co, device=w_master.device, dtype=dtype) if want_transposed else None
+    check(lib().vince_prepare_weight(dtype_code(wk), _ptr(w_master), _ptr(wk), _ptr(wt), Co, T, Ci, cip, stream_ptr()))
+    return wk, wt
+
+
+def nhwc_to_nchw_f32(x):
+    require_gpu(x)
+    N, H, W, C = x.shape
+    out = torch.empty(N, C, H, W, device=x.device, dtype=torch.float32)
+    check(lib().vince_nhwc_to_nchw_f32(dtype_code(x), _ptr(x), _ptr(out), N, C, H, W, stream_ptr()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ InfoNCE
+class InfoNCEResult:
+    __slots__ = ("desc", "pos", "row_max", "neg_sum", "dists", "softmax_weights", "scalars")
+
+
+def infonce_fwd(q, inb, queue, temperature, frames=1, offdiag_neg=False):
+    """Fused similarity + loss + metrics.  q:[B,D] inb:[B,D] queue:[K,D] or None (all float32)."""
+    require_gpu(q, inb, queue)
+    B, D = q.shape
+    K = 0 if queue is None else queue.shape[0]
+    d = InfoNCEDesc(B=B, D=D, Bk=inb.shape[0], K=K, frames=frames, offdiag_neg=int(offdiag_neg),
+                    inv_temperature=1.0 / temperature)
+    nbytes = lib().vince_infonce_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("libvince_hip: %s" % lib().vince_last_error().decode())
+    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+    r = InfoNCEResult()
+    r.desc = d
+    r.pos = torch.empty(B, frames, device=q.device)
+    r.row_max = torch.empty(B, device=q.device)
+    r.neg_sum = torch.empty(B, device=q.device)
+    r.dists = torch.empty(B, frames, device=q.device)
+    r.softmax_weights = torch.empty(B, frames, device=q.device)
+    r.scalars = torch.empty(8, device=q.device)
+    check(lib().vince_infonce_fwd(ctypes.byref(d), _ptr(q), _ptr(inb), _ptr(queue), _ptr(r.pos), _ptr(r.row_max),
+                                  _ptr(r.neg_sum), _ptr(r.dists), _ptr(r.softmax_weights), _ptr(r.scalars), _ptr(ws),
+                                  stream_ptr()))
+    return r
+
+
+def infonce_bwd(r, q, inb, queue, grad_scale, dq, want_wmat=False):
+    require_gpu(q, inb, queue, grad_scale, dq)
+    wmat = torch.zeros(r.desc.B, r.desc.Bk, device=q.device) if want_wmat else None
+    check(lib().vince_infonce_bwd(ctypes.byref(r.desc), _ptr(q), _ptr(inb), _ptr(queue), _ptr(r.pos), _ptr(r.row_max),
+                                  _ptr(r.neg_sum), _ptr(grad_scale), _ptr(dq), _ptr(wmat), stream_ptr()))
+    return wmat
+
+
+# ------------------------------------------------------------------------------------------------ queue / EMA / SGD
+def queue_enqueue(queue, items, tail, full):
+    """Returns (new_tail, new_full).  Integer arithmetic is done in C (utils/storage_queue.py:31-49)."""
+    require_gpu(queue, items)
+    if items.dtype != queue.dtype or queue.dtype != torch.float32:
+        raise TypeError("vince_amd: queue and items must be float32")
+    t = ctypes.c_int64(tail)
+    f = ctypes.c_int32(int(full))
+    check(lib().vince_queue_enqueue(_ptr(queue), queue.shape[0], queue.shape[1], _ptr(items), items.shape[0],
+                                    ctypes.byref(t), ctypes.byref(f), stream_ptr()))
+    return t.value, bool(f.value)
+
+
+def ema_flat(key, query, momentum):
+    require_gpu(key, query)
+    check(lib().vince_ema_flat(_ptr(key), _ptr(query), key.numel(), momentum, stream_ptr()))
+
+
+def sgd_flat(param, grad, buf, lr, momentum=0.9, weight_decay=1e-4, grad_scale=1.0):
+    require_gpu(param, grad, buf)
+    check(lib().vince_sgd_flat(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), lr, momentum, weight_decay, grad_scale,
+                               stream_ptr()))
