@@ -179,6 +179,16 @@ int vince_infonce_bwd(const vince_infonce_desc* d, const float* q, const float* 
                       const float* pos, const float* row_max, const float* neg_sum, const float* grad_scale,
                       float* dq, float* wmat, void* stream);
 
+/* similarity_cross_entropy on MATERIALISED similarities [B][cols] with an arbitrary boolean mask (uint8, P positives in
+ * every row) -- utils/loss_util.py:7-62 as called by VinceModel.loss with a caller-provided tensor.  dists /
+ * softmax_weights are [B][P] in column order of the positives. */
+int vince_sce_rows_fwd(const float* sims, const uint8_t* mask, int32_t B, int32_t cols, int32_t P,
+                       float inv_temperature, float* dists, float* softmax_weights, float* row_max, float* neg_sum,
+                       void* stream);
+int vince_sce_rows_bwd(const float* sims, const uint8_t* mask, int32_t B, int32_t cols, int32_t P,
+                       float inv_temperature, const float* row_max, const float* neg_sum, const float* grad_dists,
+                       float* dsims, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Queue, momentum encoder, optimiser (K18-K21)
  */
@@ -231,9 +241,15 @@ int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void*
                         int64_t* const* bn_nbt, const float* input, const int64_t* perm, int32_t jigsaw_src_h,
                         int32_t jigsaw_src_w, void* workspace, float* pooled, int32_t train_bn, void* stream);
 const void* vince_trunk_spatial_ptr(vince_trunk_t t, const void* workspace);
-/* grads: float pointers parallel to params (accumulated into; zero them first).  dpooled: float[N][C]. */
+/* grads: float pointers parallel to params (accumulated into; zero them first).  dpooled: float[N][C].
+ * Gradient buckets for data parallelism: after the backward of residual block event_blocks[e] (blocks are numbered in
+ * forward order; backward visits them last to first) has been enqueued, hipEvent_t events[e] is recorded on `stream`;
+ * every parameter gradient of that block and of all later blocks is final at that event, so the caller can launch
+ * the RCCL all-reduce of that contiguous parameter range on a side stream while the rest of backward runs. */
 int vince_trunk_backward(vince_trunk_t t, const float* const* params, const void* wcache, void* workspace,
-                         const float* dpooled, float* const* grads, void* stream);
+                         const float* dpooled, float* const* grads, const int32_t* event_blocks, void* const* events,
+                         int32_t n_events, void* stream);
+int32_t vince_trunk_num_blocks(vince_trunk_t t);
 
 #ifdef __cplusplus
 }

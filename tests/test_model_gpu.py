@@ -1,0 +1,305 @@
+"""GPU parity of the assembled path (VinceModel / VinceQueueModel / StorageQueue / FlatSGD / VinceSolver) against the
+reference-generated golden vectors (tests/golden, G3-G6) and, teacher-forced step by step, against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vince_oracle as vo  # noqa: E402
+
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def build(arch, embed, dtype, seed, **kw):
+    from vince_amd.config import make_args
+    from vince_amd.models.vince_model import VinceModel
+    args = make_args(backbone=arch, vince_embedding_size=embed, compute_dtype=dtype, **kw)
+    model = VinceModel(args)
+    model.load_state_dict(vo.seeded_state(vo.model_spec(arch, embed, kw.get("jigsaw", False)), seed))
+    model.to(DEV)
+    return args, model
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+# ------------------------------------------------------------------------------------------ G3 / G4 trunk + head
+@pytest.mark.parametrize("arch,embed", [("ResNet18", 64), ("ResNet50", 128)])
+@pytest.mark.parametrize("hw", [64, 224])
+@pytest.mark.parametrize("train", [True, False])
+def test_g3_trunk_head_fp32(arch, embed, hw, train):
+    g = load("g3_trunk.npz")
+    p = "%s_%d_%s_" % (arch, hw, "train" if train else "eval")
+    _, model = build(arch, embed, "fp32", 11)
+    model.train(train)
+    x = vo.structured_frames(2, hw, hw, seed=500 + hw).to(DEV)
+    with torch.no_grad():
+        o = model.get_embeddings({"data": x})
+    # north_star bar: embeddings within 1e-3 relative of the fp32 reference; fp32 kernels land far inside it
+    assert rel(o["embeddings"].cpu(), g[p + "embeddings"]) < 1e-4
+    assert rel(o["prenorm_features"].cpu(), g[p + "prenorm"]) < 1e-4
+    assert rel(o["extracted_features"].cpu(), g[p + "extracted"]) < 1e-4
+    sp = o["spatial_features"].float().cpu()
+    assert list(sp.shape) == [2, vo.ARCH[arch]["out_channels"], hw // 32, hw // 32]
+    if hw == 64:
+        assert rel(sp, g[p + "spatial"]) < 1e-4
+    sd = model.state_dict()
+    for bn in ["feature_extractor.model.bn1", "feature_extractor.model.layer4.1.bn2",
+               "feature_extractor.model.layer2.0.downsample.1"]:
+        np.testing.assert_allclose(sd[bn + ".running_mean"].cpu().numpy(), g[p + bn + ".running_mean"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(sd[bn + ".running_var"].cpu().numpy(), g[p + bn + ".running_var"], rtol=1e-3, atol=1e-5)
+        assert int(sd[bn + ".num_batches_tracked"]) == int(g[p + bn + ".num_batches_tracked"])
+
+
+@pytest.mark.parametrize("arch,embed", [("ResNet18", 64), ("ResNet50", 128)])
+def test_g3_trunk_head_bf16_reported(arch, embed, record_property):
+    """bf16 trunk against the fp32 reference.  53 stacked bf16 layers cannot hold 1e-3 on raw embeddings in general
+    (SURVEY.md 7.4-4); the miss is reported as a number, and bounded."""
+    g = load("g3_trunk.npz")
+    p = "%s_224_train_" % arch
+    _, model = build(arch, embed, "bf16", 11)
+    model.train(True)
+    x = vo.structured_frames(2, 224, 224, seed=500 + 224).to(DEV)
+    with torch.no_grad():
+        o = model.get_embeddings({"data": x})
+    err = rel(o["embeddings"].cpu(), g[p + "embeddings"])
+    cos = float((o["embeddings"].cpu() * torch.from_numpy(g[p + "embeddings"])).sum(1).min())
+    record_property("bf16_embedding_rel_err", err)
+    print("bf16 %s: embedding max rel err %.3e, min cosine to reference %.6f" % (arch, err, cos))
+    assert err < 5e-2 and cos > 0.999
+
+
+# ------------------------------------------------------------------------------------------ training step, teacher forced
+def oracle_trainer(mode, lr=0.03):
+    return vo.OracleTrainer("ResNet18", 64, 512, 32, 0.07, lr, inter_batch=mode == "vince",
+                            num_frames=4 if mode == "vince" else 1, self_batch=mode == "vince", seed=5)
+
+
+def gpu_stack(mode, lr=0.03, dtype="fp32"):
+    from vince_amd.models.vince_model import VinceQueueModel
+    from vince_amd.optim import FlatSGD
+    from vince_amd.utils.storage_queue import StorageQueue
+    args, model = build("ResNet18", 64, dtype, 5, batch_size=32, vince_queue_size=512, vince_temperature=0.07,
+                        num_frames=4 if mode == "vince" else 1, inter_batch_comparison=mode == "vince",
+                        self_batch_comparison=mode == "vince", base_lr=lr)
+    model.train()
+    qm = VinceQueueModel(args, model)
+    qm.to(DEV)
+    qm.train()
+    queue = StorageQueue(512, 64, device=DEV)
+    opt = FlatSGD(model, lr=lr)
+    return args, model, qm, queue, opt
+
+
+def load_oracle_state(tr, model, qm, queue, opt):
+    """Teacher forcing: copy the oracle's complete training state into the GPU objects."""
+    model.load_state_dict({k: v.detach() for k, v in tr.q.items()})
+    qm.queue_network.load_state_dict({k: v.detach() for k, v in tr.k.items()})
+    queue.vector_queue.copy_(torch.from_numpy(tr.queue.vectors))
+    queue.current_tail, queue.full = tr.queue.current_tail, tr.queue.full
+    names = [n for n in tr.pnames if not n.startswith("feature_extractor.model.fc.")]
+    sd = dict(model.named_parameters())
+    opt.momentum_buffer.zero_()
+    for n in names:
+        if n in tr.bufs:
+            # momentum buffers live in the flat layout: write through a view shaped like the parameter
+            p = sd[n]
+            off = (p.data_ptr() - model._flat.data_ptr()) // 4
+            view = opt.momentum_buffer[off:off + p.numel()]
+            src = tr.bufs[n]
+            if p.dim() == 4:
+                src = src.permute(0, 2, 3, 1)
+            view.copy_(src.reshape(-1))
+
+
+def gpu_step(args, model, qm, queue, opt, data, qdata, mode):
+    F_ = 4 if mode == "vince" else 1
+    batch = {"data": data.to(DEV), "queue_data": qdata.to(DEV), "batch_types": ["images"], "batch_sizes": [32],
+             "data_source": ["XX"], "num_frames": [F_]}
+    qb = qm(batch, shuffle=True)
+    outs = model.get_embeddings(batch, shuffle=True)
+    ib = model.split_dict_by_type(batch["batch_types"], batch["batch_sizes"], batch)
+    output = outs[0]
+    output.update(queue.dequeue())
+    output.update(ib[0])
+    output.update(qb[0])
+    output.update(model(output))
+    ld = model.loss(output)
+    met = model.get_metrics(output)
+    total = sum(w * v for w, v in ld.values())
+    opt.zero_grad()
+    total.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    opt.step()
+    queue.enqueue(output["queue_embeddings"], None, "XX")
+    qm.vince_update(model)
+    return output, ld, met, grads
+
+
+def step_inputs(it):
+    data = vo.structured_frames(32, 64, 64, seed=1000 + it)
+    qdata = vo.structured_frames(32, 64, 64, seed=1000 + it) + 0.25 * vo.gaussian_frames(32, 64, 64, 2000 + it)
+    return data, qdata
+
+
+@pytest.mark.parametrize("mode", ["moco", "vince"])
+def test_g5_first_step_vs_reference_golden(mode):
+    """Iteration 0 of config C1 against the REFERENCE's own numbers (tests/golden/g5_step.npz)."""
+    g = load("g5_step.npz")
+    stack = gpu_stack(mode)
+    args, model, qm, queue, opt = stack
+    qi = torch.nn.functional.normalize(torch.randn(512, 64, generator=torch.Generator().manual_seed(5 + 77)), dim=-1)
+    queue.vector_queue.copy_(qi)
+    data, qdata = step_inputs(0)
+    output, ld, met, grads = gpu_step(*stack, data, qdata, mode)
+    pre = "%s_it0_" % mode
+    np.testing.assert_allclose(float(ld["nce_loss"][1]), float(g[pre + "loss_nce_loss"]), rtol=1e-3)
+    if mode == "vince":
+        np.testing.assert_allclose(float(ld["nce_loss_self"][1]), float(g[pre + "loss_nce_loss_self"]), rtol=1e-3)
+    assert rel(output["embeddings"].detach().cpu(), g[pre + "embeddings"]) < 1e-3
+    assert rel(output["queue_embeddings"].cpu(), g[pre + "queue_embeddings"]) < 1e-3
+    for kk in ["nce_accuracy_mean", "cosine_sim", "cosine_sim_neg_max"]:
+        np.testing.assert_allclose(float(met[kk]), float(g[pre + "m_" + kk]), rtol=1e-3, atol=1e-5)
+    assert queue.current_tail == int(g[pre + "tail"]) and queue.full == bool(g[pre + "full"])
+    gb = grads["feature_extractor.model.bn1.weight"].cpu().numpy()
+    assert rel(gb, g[pre + "grad_bn1w"]) < 2e-2
+    for name, key in [("feature_extractor.model.conv1.weight", "grad_conv1"), ("embedding.2.weight", "grad_emb2"),
+                      ("feature_extractor.model.layer4.1.conv2.weight", "grad_l4")]:
+        cs = vo.tensor_checksum(grads[name].cpu().contiguous())
+        np.testing.assert_allclose(cs[2], g[pre + key][2], rtol=2e-2)
+    pcs = np.array([vo.tensor_checksum(p.detach().cpu().contiguous())[2] for _, p in model.named_parameters()])
+    np.testing.assert_allclose(pcs, g[pre + "param_checksums"][:, 2], rtol=1e-4)
+    kcs = np.array([vo.tensor_checksum(p.detach().cpu().contiguous())[2] for _, p in qm.queue_network.named_parameters()])
+    np.testing.assert_allclose(kcs, g[pre + "key_checksums"][:, 2], rtol=1e-5)
+    np.testing.assert_allclose(vo.tensor_checksum(queue.vector_queue.cpu()), g[pre + "queue_checksum"], rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("mode", ["moco", "vince"])
+def test_three_steps_teacher_forced_vs_oracle(mode):
+    """Every iteration starts from the ORACLE's state (the free-running problem is chaotic, see test_oracle_golden)."""
+    tr = oracle_trainer(mode)
+    stack = gpu_stack(mode)
+    args, model, qm, queue, opt = stack
+    for it in range(3):
+        load_oracle_state(tr, model, qm, queue, opt)
+        data, qdata = step_inputs(it)
+        r = tr.step(data, qdata)
+        output, ld, met, grads = gpu_step(*stack, data, qdata, mode)
+        np.testing.assert_allclose(float(ld["nce_loss"][1]), r["nce_loss"], rtol=1e-3)
+        if mode == "vince":
+            np.testing.assert_allclose(float(ld["nce_loss_self"][1]), r["nce_loss_self"], rtol=1e-3)
+        assert rel(output["embeddings"].detach().cpu(), r["embeddings"]) < 1e-3
+        assert rel(output["queue_embeddings"].cpu(), r["queue_embeddings"]) < 1e-3
+        for kk in ["nce_accuracy_mean", "cosine_sim", "cosine_sim_neg_max"]:
+            np.testing.assert_allclose(float(met[kk]), r[kk], rtol=1e-3, atol=1e-5)
+        assert queue.current_tail == r["tail"] and queue.full == r["full"]
+        # late-layer gradients are well conditioned; stem gradients only at iteration 0
+        for name in ["embedding.2.weight", "embedding.0.bias", "feature_extractor.model.layer4.1.conv2.weight",
+                     "feature_extractor.model.layer4.1.bn2.weight"]:
+            assert rel(grads[name].cpu(), r["grads"][name]) < 5e-3, name
+        if it == 0:
+            for name in ["feature_extractor.model.conv1.weight", "feature_extractor.model.bn1.weight",
+                         "feature_extractor.model.layer2.0.downsample.0.weight"]:
+                assert rel(grads[name].cpu(), r["grads"][name]) < 2e-2, name
+        # queue contents after this step's enqueue, key encoder after EMA
+        np.testing.assert_allclose(queue.vector_queue.cpu().numpy(), tr.queue.vectors, rtol=1e-3, atol=2e-4)
+        ksd = qm.queue_network.state_dict()
+        for name in ["embedding.2.weight", "feature_extractor.model.layer4.1.conv2.weight", "feature_extractor.model.fc.weight"]:
+            assert rel(ksd[name].cpu(), tr.k[name]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ G6 jigsaw
+@pytest.mark.parametrize("hw", [66, 64])
+def test_g6_jigsaw(hw):
+    g = load("g6_jigsaw.npz")
+    p = "hw%d_" % hw
+    _, model = build("ResNet18", 64, "fp32", 21, jigsaw=True)
+    model.train()
+    x = vo.structured_frames(2, hw, hw, seed=900 + hw).to(DEV)
+    with torch.no_grad():
+        o = model.get_embeddings({"data": x, "jigsaw_orders": torch.from_numpy(g[p + "orders"])}, jigsaw=True)
+    assert rel(o["embeddings"].cpu(), g[p + "embeddings"]) < 1e-3
+    assert rel(o["extracted_features"].cpu(), g[p + "extracted"]) < 1e-3
+
+
+def test_jigsaw_backward_vs_oracle():
+    sd = vo.seeded_state(vo.model_spec("ResNet18", 64, jigsaw=True), 21)
+    pn = vo.param_names(vo.model_spec("ResNet18", 64, jigsaw=True))
+    for n in pn:
+        sd[n].requires_grad_(True)
+    x = vo.structured_frames(2, 66, 66, seed=966)
+    orders = torch.stack([torch.randperm(9, generator=torch.Generator().manual_seed(s)) for s in (1, 2)])
+    o = vo.get_embeddings(sd, x, "ResNet18", True, jigsaw=True, jigsaw_orders=orders)
+    w = torch.randn(2, 64, generator=torch.Generator().manual_seed(3))
+    (o["embeddings"] * w).sum().backward()
+    _, model = build("ResNet18", 64, "fp32", 21, jigsaw=True)
+    model.train()
+    out = model.get_embeddings({"data": x.to(DEV), "jigsaw_orders": orders}, jigsaw=True)
+    model.zero_grad()
+    (out["embeddings"] * w.to(DEV)).sum().backward()
+    named = dict(model.named_parameters())
+    for name in ["jigsaw_embedding.2.weight", "jigsaw_embedding.0.weight", "jigsaw_linear.weight",
+                 "feature_extractor.model.layer4.1.conv2.weight", "feature_extractor.model.conv1.weight"]:
+        assert rel(named[name].grad.cpu(), sd[name].grad) < 2e-2, name
+    assert model._touched["jigsaw"] and not model._touched["embedding"]
+
+
+# ------------------------------------------------------------------------------------------ API surface / solver
+def test_materialised_similarity_path_matches_fused():
+    from vince_amd.utils.loss_util import similarity_cross_entropy
+    stack = gpu_stack("vince")
+    args, model, qm, queue, opt = stack
+    data, qdata = step_inputs(0)
+    batch = {"data": data.to(DEV), "queue_data": qdata.to(DEV), "batch_types": ["images"], "batch_sizes": [32],
+             "data_source": ["XX"], "num_frames": [4]}
+    qb = qm(batch)
+    out = model.get_embeddings(batch)[0]
+    out.update(queue.dequeue()); out.update(model.split_dict_by_type(["images"], [32], batch)[0]); out.update(qb[0])
+    out.update(model(out))
+    fused = model.loss(out)["nce_loss"][1]
+    sims = out["vince_similarities"].materialize()
+    assert list(sims.shape) == [32, 32 + 512]
+    res = similarity_cross_entropy(sims, 0.07, 32, 1, out["vince_similarities_mask"])
+    np.testing.assert_allclose(float(res["dist"]), float(fused), rtol=1e-4)
+    # and its gradient agrees with the oracle's autograd
+    s_cpu = sims.cpu().clone().requires_grad_(True)
+    mask = vo.positive_mask(32, 4, 544)
+    vo.similarity_cross_entropy(s_cpu, 0.07, mask)["dist"].backward()
+    sg = sims.clone().requires_grad_(True)
+    similarity_cross_entropy(sg, 0.07, 32, 1, mask.to(DEV))["dist"].backward()
+    assert rel(sg.grad.cpu(), s_cpu.grad) < 1e-4
+
+
+def test_solver_runs_and_advances_queue():
+    from vince_amd.config import make_args
+    from vince_amd.solvers.vince_solver import VinceSolver
+    args = make_args(backbone="ResNet18", batch_size=16, vince_queue_size=64, input_size=(64, 64), compute_dtype="bf16",
+                     iterations_per_epoch=3)
+    solver = VinceSolver(args)
+    solver.reset_epoch()
+    losses = []
+    for _ in range(5):
+        ld, met = solver.run_train_iteration()
+        losses.append(float(ld["nce_loss"]))
+    assert all(np.isfinite(losses))
+    assert solver.vince_queue.current_tail == (5 * 16) % 64 and solver.vince_queue.full
+    assert solver.iteration == 5 * 16
+    assert set(met.keys()) == {"nce_accuracy_mean", "nce_softmax_weight_mean", "cosine_sim", "cosine_sim_neg_max"}
+
+
+def test_cpu_model_forward_raises():
+    from vince_amd.config import make_args
+    from vince_amd.models.vince_model import VinceModel
+    model = VinceModel(make_args())
+    with pytest.raises(RuntimeError):
+        model.get_embeddings({"data": torch.randn(2, 3, 64, 64)})

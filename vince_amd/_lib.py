@@ -60,6 +60,10 @@ PROTOTYPES = {
     "vince_infonce_workspace_bytes": (c_size_t, [P(InfoNCEDesc)]),
     "vince_infonce_fwd": (c_int, [P(InfoNCEDesc)] + [c_void_p] * 11),
     "vince_infonce_bwd": (c_int, [P(InfoNCEDesc)] + [c_void_p] * 10),
+    "vince_sce_rows_fwd": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
+    "vince_sce_rows_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
     "vince_queue_enqueue": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, P(c_int64), P(c_int32), c_void_p]),
     "vince_ema_flat": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "vince_sgd_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
@@ -77,7 +81,9 @@ PROTOTYPES = {
     "vince_trunk_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                     c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_trunk_spatial_ptr": (c_void_p, [c_void_p, c_void_p]),
-    "vince_trunk_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vince_trunk_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                     c_void_p]),
+    "vince_trunk_num_blocks": (c_int32, [c_void_p]),
 }
 
 _LIB = None

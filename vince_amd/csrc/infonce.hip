@@ -320,6 +320,87 @@ __global__ __launch_bounds__(256) void infonce_bwd_kernel(const InfoParams p) {
         }
 }
 
+
+// ---- row-wise similarity_cross_entropy on MATERIALISED similarities + arbitrary boolean mask (loss_util.py:7-62,
+// equal positives per row).  One wavefront per row; used when a caller hands VinceModel.loss a real tensor.
+__device__ inline int lanes_below(unsigned long long ballot, int lane) {
+    return __popcll(ballot & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(256) void sce_rows_fwd_kernel(const float* __restrict__ sims, const uint8_t* __restrict__ mask,
+                                                           int B, int cols, int P, float invT, float* dists, float* sw,
+                                                           float* row_max, float* neg_sum) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* s = sims + (size_t)row * cols;
+    const uint8_t* m = mask + (size_t)row * cols;
+    float M = NEG_BIG;
+    for (int j = lane; j < cols; j += 64) M = fmaxf(M, s[j] * invT);
+    M = wave_max(M);
+    float S = 0.f;
+    for (int j = lane; j < cols; j += 64) S += m[j] ? 0.f : expf(s[j] * invT - M);
+    S = wave_sum(S);
+    int base = 0;
+    for (int j0 = 0; j0 < cols; j0 += 64) {
+        const int j = j0 + lane;
+        const bool isp = j < cols && m[j];
+        const unsigned long long b = __ballot(isp);
+        if (isp) {
+            const int pi = base + lanes_below(b, lane);
+            if (pi < P) {
+                const float sp = s[j] * invT - M;
+                const float ls = sp - logf(expf(sp) + S);
+                dists[(size_t)row * P + pi] = -ls;
+                sw[(size_t)row * P + pi] = expf(ls);
+            }
+        }
+        base += __popcll(b);
+    }
+    if (lane == 0) { row_max[row] = M; neg_sum[row] = S; }
+}
+
+__global__ __launch_bounds__(256) void sce_rows_bwd_kernel(const float* __restrict__ sims, const uint8_t* __restrict__ mask,
+                                                           int B, int cols, int P, float invT,
+                                                           const float* __restrict__ row_max,
+                                                           const float* __restrict__ neg_sum,
+                                                           const float* __restrict__ gd, float* __restrict__ dsims) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* s = sims + (size_t)row * cols;
+    const uint8_t* m = mask + (size_t)row * cols;
+    const float M = row_max[row], S = neg_sum[row];
+    float c = 0.f;
+    int base = 0;
+    for (int j0 = 0; j0 < cols; j0 += 64) {
+        const int j = j0 + lane;
+        const bool isp = j < cols && m[j];
+        const unsigned long long b = __ballot(isp);
+        if (isp) {
+            const int pi = base + lanes_below(b, lane);
+            if (pi < P) c += gd[(size_t)row * P + pi] / (expf(s[j] * invT - M) + S);
+        }
+        base += __popcll(b);
+    }
+    c = wave_sum(c);
+    base = 0;
+    for (int j0 = 0; j0 < cols; j0 += 64) {
+        const int j = j0 + lane;
+        const bool isp = j < cols && m[j];
+        const unsigned long long b = __ballot(isp);
+        if (j < cols) {
+            float g;
+            if (isp) {
+                const int pi = base + lanes_below(b, lane);
+                g = pi < P ? -gd[(size_t)row * P + pi] * S / (expf(s[j] * invT - M) + S) : 0.f;
+            } else {
+                g = expf(s[j] * invT - M) * c;
+            }
+            dsims[(size_t)row * cols + j] = g * invT;
+        }
+        base += __popcll(b);
+    }
+}
+
 int fill_params(const vince_infonce_desc* d, InfoParams& p) {
     VINCE_CHECK_ARG(d, VINCE_E_ARG, "vince_infonce: null descriptor");
     VINCE_CHECK_ARG(d->B > 0 && d->Bk >= 0 && d->K >= 0 && (d->Bk + d->K) > 0, VINCE_E_SHAPE, "vince_infonce: bad sizes");
@@ -385,6 +466,28 @@ extern "C" int vince_infonce_bwd(const vince_infonce_desc* d, const float* q, co
     dim3 grid((d->B + RT - 1) / RT, P);
     if (d->D == 64) hipLaunchKernelGGL(infonce_bwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(infonce_bwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_sce_rows_fwd(const float* sims, const uint8_t* mask, int32_t B, int32_t cols, int32_t P,
+                                  float inv_temperature, float* dists, float* softmax_weights, float* row_max,
+                                  float* neg_sum, void* stream) {
+    VINCE_CHECK_ARG(sims && mask && dists && softmax_weights && row_max && neg_sum && B > 0 && cols > 0 && P > 0, VINCE_E_ARG,
+                    "vince_sce_rows_fwd: bad arguments");
+    hipLaunchKernelGGL(sce_rows_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, sims, mask, B, cols, P,
+                       inv_temperature, dists, softmax_weights, row_max, neg_sum);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_sce_rows_bwd(const float* sims, const uint8_t* mask, int32_t B, int32_t cols, int32_t P,
+                                  float inv_temperature, const float* row_max, const float* neg_sum,
+                                  const float* grad_dists, float* dsims, void* stream) {
+    VINCE_CHECK_ARG(sims && mask && row_max && neg_sum && grad_dists && dsims && B > 0 && cols > 0 && P > 0, VINCE_E_ARG,
+                    "vince_sce_rows_bwd: bad arguments");
+    hipLaunchKernelGGL(sce_rows_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, sims, mask, B, cols, P,
+                       inv_temperature, row_max, neg_sum, grad_dists, dsims);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

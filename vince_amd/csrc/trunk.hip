@@ -252,6 +252,7 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
 extern "C" void vince_trunk_destroy(vince_trunk_t t) { delete t; }
 extern "C" int32_t vince_trunk_num_params(vince_trunk_t t) { return t ? t->nparams : 0; }
 extern "C" int32_t vince_trunk_num_bn(vince_trunk_t t) { return t ? t->nbn : 0; }
+extern "C" int32_t vince_trunk_num_blocks(vince_trunk_t t) { return t ? (int32_t)t->blocks.size() : 0; }
 extern "C" int32_t vince_trunk_out_channels(vince_trunk_t t) { return t ? t->outC : 0; }
 extern "C" int32_t vince_trunk_out_hw(vince_trunk_t t, int32_t* h, int32_t* w) {
     if (!t) return VINCE_E_ARG;
@@ -407,7 +408,8 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
 }
 
 extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params, const void* wcache, void* workspace,
-                                    const float* dpooled, float* const* grads, void* stream) {
+                                    const float* dpooled, float* const* grads, const int32_t* event_blocks,
+                                    void* const* events, int32_t n_events, void* stream) {
     VINCE_CHECK_ARG(t && params && wcache && workspace && dpooled && grads, VINCE_E_ARG, "vince_trunk_backward: null pointer");
     Ctx c{t, params, wcache, workspace, stream, t->cfg.dtype};
     const int N = t->cfg.N;
@@ -445,6 +447,9 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             }
         }
         std::swap(Z, DX);
+        // gradient buckets: every parameter of blocks >= bi is final here -- let the caller start its all-reduce
+        for (int e = 0; e < n_events; ++e)
+            if (event_blocks[e] == bi) VINCE_CHECK_HIP(hipEventRecord((hipEvent_t)events[e], (hipStream_t)stream));
     }
     // stem: Z = gradient wrt the pooled stem output
     RC(vince_stem_pool_bwd(c.dtype, Z, (const uint8_t*)at(workspace, t->off_amax), DA, N, t->sH, t->sW, 64, stream));

@@ -1,0 +1,138 @@
+"""Data-parallel glue: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
+
+The reference's only multi-GPU mechanism is nn.DataParallel around the trunk (models/vince_model.py:35): per-chunk BN
+statistics, gradients reduced to device 0, heads / loss / queue on one GPU.  The MI355X-native equivalent
+ keeps the same per-sample semantics with explicit collectives:
+
+  * gradients: SUM all-reduce of the flat fp32 gradient buffer, in stage-sized buckets launched on a side stream as
+    soon as the engine's bucket events fire (layer4 + heads first), 1/world folded into the SGD kernel;
+  * keys: all-gather of each rank's B x D keys -> every rank enqueues the same world*B block in rank order at the same
+    tail, so the replicated queues stay bit-identical;
+  * shuffle-BN: optional cross-rank permutation of the key images before encoding (all_to_all) and inverse
+    permutation of the gathered keys;
+  * BN statistics stay per rank (the reference's per-chunk statistics); EMA and SGD are replicated.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def is_distributed():
+    return world()[0] > 1
+
+
+# ------------------------------------------------------------------------------------------------ gradient buckets
+def bucket_plan(model, arch_layers):
+    """Contiguous flat-gradient ranges in the order their gradients become final during backward, with the index of
+    the residual block after whose backward the range is complete.  Returns [(block_index or None, start, end)].
+    The last bucket (stem + layer1, finished at the very end of backward) has block index None."""
+    n_train = model._n_train
+    so = model._stage_offsets
+    first_block = {}
+    acc = 0
+    for li, n in enumerate(arch_layers):
+        first_block["layer%d" % (li + 1)] = acc
+        acc += n
+    # heads sit after the trunk in the flat buffer; their gradients are final before the trunk backward starts
+    plan = [(first_block["layer4"], so["layer4"], n_train),
+            (first_block["layer3"], so["layer3"], so["layer4"]),
+            (first_block["layer2"], so["layer2"], so["layer3"]),
+            (None, 0, so["layer2"])]
+    return plan
+
+
+class GradientReducer:
+    """Bucketed all-reduce of VinceModel's flat gradient buffer, overlapped with the rest of backward."""
+
+    def __init__(self, model, arch_layers):
+        self.model = model
+        self.plan = bucket_plan(model, arch_layers)
+        self.on_gpu = model._flat.is_cuda
+        if self.on_gpu:
+            self.comm_stream = torch.cuda.Stream()
+            self.events = [torch.cuda.Event() for _ in self.plan]
+            self.done = torch.cuda.Event()
+            model._bucket_events = [(blk, ev) for (blk, _, _), ev in zip(self.plan, self.events) if blk is not None]
+
+    def reduce_after_backward(self):
+        """Call right after loss.backward(): enqueues the bucket all-reduces (each waits for its own event) and makes
+        the compute stream wait for all of them."""
+        grad = self.model._flat_grad
+        if not self.on_gpu:
+            for _, a, b in self.plan:
+                dist.all_reduce(grad[a:b], op=dist.ReduceOp.SUM)
+            return
+        cur = torch.cuda.current_stream()
+        tail_event = torch.cuda.Event()
+        tail_event.record(cur)
+        with torch.cuda.stream(self.comm_stream):
+            for (blk, a, b), ev in zip(self.plan, self.events):
+                self.comm_stream.wait_event(ev if blk is not None else tail_event)
+                dist.all_reduce(grad[a:b], op=dist.ReduceOp.SUM)
+            self.done.record(self.comm_stream)
+        cur.wait_event(self.done)
+
+
+# ------------------------------------------------------------------------------------------------ keys
+def gather_keys(keys):
+    """[B, D] per rank -> [world*B, D], rank order (rank r's rows at [r*B, (r+1)*B))."""
+    w, _ = world()
+    if w == 1:
+        return keys
+    out = torch.empty(w * keys.shape[0], keys.shape[1], dtype=keys.dtype, device=keys.device)
+    dist.all_gather_into_tensor(out, keys.contiguous())
+    return out
+
+
+def global_permutation(n_global, step, seed=0):
+    """The same permutation on every rank (seeded by step) -- which rank encodes which key image (shuffle-BN)."""
+    g = torch.Generator().manual_seed(seed * 1000003 + step)
+    return torch.randperm(n_global, generator=g)
+
+
+def exchange_rows(local, perm):
+    """Cross-rank gather: returns rows perm[r*B:(r+1)*B] of the GLOBAL tensor whose rank-s slice is `local` on rank s.
+    all_to_all_single with uneven splits; row order inside each received block follows the sender's index order, so a
+    local re-ordering restores the requested order."""
+    w, r = world()
+    B = local.shape[0]
+    if w == 1:
+        return local[perm.to(local.device)]
+    want = perm[r * B:(r + 1) * B]                       # global indices this rank must end up with
+    # what every rank d wants from me: indices in perm[d*B:(d+1)*B] that fall in my slice
+    send_idx, send_counts = [], []
+    for d in range(w):
+        wd = perm[d * B:(d + 1) * B]
+        mine = wd[(wd >= r * B) & (wd < (r + 1) * B)] - r * B
+        send_idx.append(mine)
+        send_counts.append(int(mine.numel()))
+    recv_counts = [int(((want >= s * B) & (want < (s + 1) * B)).sum()) for s in range(w)]
+    send = local[torch.cat(send_idx).to(local.device)].contiguous()
+    recv = torch.empty((sum(recv_counts),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts)
+    # recv holds, source rank by source rank, the wanted rows in the order they appear in `want`
+    order = torch.cat([torch.nonzero((want >= s * B) & (want < (s + 1) * B)).flatten() for s in range(w)])
+    out = torch.empty_like(recv)
+    out[order.to(local.device)] = recv
+    return out
+
+
+def unpermute_gathered(gathered, perm):
+    """gathered[j] is the key of global sample perm[j]; returns keys in natural global order."""
+    out = torch.empty_like(gathered)
+    out[perm.to(gathered.device)] = gathered
+    return out
+
+
+def all_reduce_mean_scalars(t):
+    w, _ = world()
+    if w == 1:
+        return t
+    t = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t / w

@@ -1,0 +1,115 @@
+"""Python handle on the C++ trunk engine (csrc/trunk.hip): owns the engine handle and the ctypes pointer tables."""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import TrunkCfg, VINCE_BF16, VINCE_F32, check, lib
+
+ARCH_CODE = {"ResNet18": 18, "ResNet50": 50}
+
+# scratch workspace shared by every no-grad forward on a device (key encoder, validation): nothing in it outlives
+# the call, so one buffer of the largest size seen is enough.
+_NOGRAD_WS = {}
+
+
+def nograd_workspace(device, nbytes):
+    cur = _NOGRAD_WS.get(device)
+    if cur is None or cur.numel() < nbytes:
+        cur = None
+        _NOGRAD_WS[device] = None
+        cur = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _NOGRAD_WS[device] = cur
+    return cur
+
+
+class TrunkPlan:
+    """Static description of the trunk's parameters / BN layers, queried from the engine (reference state-dict order)."""
+
+    def __init__(self, arch):
+        L = lib()
+        h = ctypes.c_void_p()
+        check(L.vince_trunk_create(ctypes.byref(TrunkCfg(arch=ARCH_CODE[arch], N=1, H=64, W=64, dtype=VINCE_F32)),
+                                   ctypes.byref(h)))
+        self.params = []   # (name, kind, shape, bn_index)
+        for i in range(L.vince_trunk_num_params(h)):
+            buf = ctypes.create_string_buffer(128)
+            kind, shape, bn = ctypes.c_int32(), (ctypes.c_int32 * 4)(), ctypes.c_int32()
+            check(L.vince_trunk_param_info(h, i, buf, 128, ctypes.byref(kind), ctypes.byref(shape), ctypes.byref(bn)))
+            shp = tuple(shape) if kind.value == 0 else (shape[0],)
+            self.params.append((buf.value.decode(), kind.value, shp, bn.value))
+        self.bns = []      # (name, channels)
+        for i in range(L.vince_trunk_num_bn(h)):
+            buf = ctypes.create_string_buffer(128)
+            c = ctypes.c_int32()
+            check(L.vince_trunk_bn_info(h, i, buf, 128, ctypes.byref(c)))
+            self.bns.append((buf.value.decode(), c.value))
+        self.out_channels = L.vince_trunk_out_channels(h)
+        L.vince_trunk_destroy(h)
+
+
+class Trunk:
+    """One engine instance for a fixed (arch, N, H, W, dtype)."""
+
+    def __init__(self, arch, N, H, W, dtype):
+        L = lib()
+        self.arch, self.N, self.H, self.W, self.dtype = arch, N, H, W, dtype
+        self._h = ctypes.c_void_p()
+        code = VINCE_F32 if dtype == torch.float32 else VINCE_BF16
+        check(L.vince_trunk_create(ctypes.byref(TrunkCfg(arch=ARCH_CODE[arch], N=N, H=H, W=W, dtype=code)),
+                                   ctypes.byref(self._h)))
+        self.ws_bytes = L.vince_trunk_workspace_bytes(self._h)
+        self.wc_bytes = L.vince_trunk_weight_cache_bytes(self._h)
+        self.out_channels = L.vince_trunk_out_channels(self._h)
+        oh, ow = ctypes.c_int32(), ctypes.c_int32()
+        L.vince_trunk_out_hw(self._h, ctypes.byref(oh), ctypes.byref(ow))
+        self.out_h, self.out_w = oh.value, ow.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().vince_trunk_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def prepare_weights(self, param_ptrs, wcache):
+        check(lib().vince_trunk_prepare_weights(self._h, param_ptrs, ctypes.c_void_p(wcache.data_ptr()), ops.stream_ptr()))
+
+    def forward(self, param_ptrs, wcache, bn_running_ptrs, bn_nbt_ptrs, data, workspace, pooled, train_bn, perm=None,
+                jigsaw_src=None):
+        jh, jw = (0, 0) if jigsaw_src is None else jigsaw_src
+        check(lib().vince_trunk_forward(
+            self._h, param_ptrs, ctypes.c_void_p(wcache.data_ptr()), bn_running_ptrs, bn_nbt_ptrs,
+            ctypes.c_void_p(data.data_ptr()), None if perm is None else ctypes.c_void_p(perm.data_ptr()), jh, jw,
+            ctypes.c_void_p(workspace.data_ptr()), ctypes.c_void_p(pooled.data_ptr()), int(train_bn), ops.stream_ptr()))
+
+    def backward(self, param_ptrs, wcache, workspace, dpooled, grad_ptrs, bucket_events=None):
+        """bucket_events: optional [(block_index, torch.cuda.Event)] recorded as soon as that block's (and every later
+        block's) parameter gradients are final."""
+        n = 0 if not bucket_events else len(bucket_events)
+        blocks = (ctypes.c_int32 * max(n, 1))()
+        events = (ctypes.c_void_p * max(n, 1))()
+        for i in range(n):
+            blocks[i] = bucket_events[i][0]
+            events[i] = bucket_events[i][1].cuda_event
+        check(lib().vince_trunk_backward(self._h, param_ptrs, ctypes.c_void_p(wcache.data_ptr()),
+                                         ctypes.c_void_p(workspace.data_ptr()), ctypes.c_void_p(dpooled.data_ptr()),
+                                         grad_ptrs, blocks, events, n, ops.stream_ptr()))
+
+    def spatial_view(self, workspace):
+        """The trunk output inside `workspace` as an [N, C, h, w] tensor with channels_last strides (zero copy)."""
+        ptr = lib().vince_trunk_spatial_ptr(self._h, ctypes.c_void_p(workspace.data_ptr()))
+        off = ptr - workspace.data_ptr()
+        esize = 4 if self.dtype == torch.float32 else 2
+        n = self.N * self.out_h * self.out_w * self.out_channels
+        flat = workspace[off: off + n * esize].view(self.dtype)
+        return flat.view(self.N, self.out_h, self.out_w, self.out_channels).permute(0, 3, 1, 2)
+
+
+def pointer_table(tensors):
+    """ctypes array of device pointers (None -> NULL)."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr

@@ -1,0 +1,621 @@
+"""VinceModel / VinceQueueModel -- the reference's class API (models/vince_model.py:19-613) on the HIP kernels.
+
+What is different underneath
+  * All trainable tensors of the path (trunk, projection MLP, jigsaw head) live in ONE flat fp32 device buffer with
+    a parallel flat gradient buffer; the ``nn.Parameter`` objects the reference's callers see are views into it
+    (conv weights as channels_last views, whose memory is the kernels' [Co][kh][kw][Ci] layout).  SGD, the momentum
+    (EMA) update and the data-parallel gradient all-reduce are single passes over that buffer.
+  * The trunk runs in the C++ engine (csrc/trunk.hip) in ``args.compute_dtype`` (bf16 or fp32, NHWC); the head
+    (avg-pool output, MLP, L2 normalise) and the similarity / InfoNCE stage are always exact fp32 on the f32 MFMA.
+  * ``forward`` never materialises the B x (K+1) logits: ``vince_similarities`` is a lazy handle, ``loss`` and
+    ``get_metrics`` read the fused kernel's per-row results.
+  * Autograd: two coarse ``torch.autograd.Function`` nodes (encoder, InfoNCE) so ``loss.backward()`` works as in
+    vince_solver.py:463-468; parameter gradients are written straight into the flat gradient buffer.
+There is no CPU path: tensors must be on the GPU.
+"""
+import copy
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import constants, ops
+from ..engine import Trunk, nograd_workspace, pointer_table
+from ..utils import loss_util
+from .base_model import BaseModel
+
+_ALIGN = 64  # floats; every tensor in the flat buffers starts on a 256-byte boundary
+
+
+def _compute_dtype(args):
+    name = str(getattr(args, "compute_dtype", "fp32")).lower()
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if name in ("fp32", "float32", "f32"):
+        return torch.float32
+    raise ValueError("compute_dtype must be bf16 or fp32, got %r" % name)
+
+
+class LazySimilarities:
+    """Stand-in for the reference's ``vince_similarities`` tensor: shape is known, values are produced on demand."""
+
+    def __init__(self, q, inb, queue, moco_mode, include_inb=True):
+        self._q, self._inb, self._queue, self._moco, self._include_inb = q, inb, queue, moco_mode, include_inb
+        ncols = ((1 if moco_mode else inb.shape[0]) if include_inb else 0) + (0 if queue is None else queue.shape[0])
+        self.shape = torch.Size((q.shape[0], ncols))
+        self._value = None
+
+    def materialize(self):
+        if self._value is None:
+            q = self._q.detach().contiguous()
+            parts = []
+            if not self._include_inb:
+                pass
+            elif self._moco:
+                parts.append((q * self._inb).sum(1, keepdim=True))          # vince_model.py:227
+            else:
+                parts.append(ops.linear_fwd(q, self._inb.contiguous(), None))  # q @ k.T
+            if self._queue is not None:
+                parts.append(ops.linear_fwd(q, self._queue.contiguous(), None))
+            self._value = torch.cat(parts, dim=1)
+        return self._value
+
+    def __array__(self, dtype=None):
+        return self.materialize().cpu().numpy()
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    """Fused (B x D) . (D x (Bk+K)) similarity + InfoNCE.  Gradient flows to the query operand only (keys and the
+    queue are detached, vince_model.py:610, storage_queue.py:53); for the self-similarity term both operands are q."""
+
+    @staticmethod
+    def forward(ctx, q, inb, queue, temperature, frames, offdiag_neg, self_sim):
+        ctx.set_materialize_grads(False)
+        qc = q.detach().contiguous()
+        inbc = qc if self_sim else inb.detach().contiguous()
+        r = ops.infonce_fwd(qc, inbc, queue, temperature, frames=frames, offdiag_neg=offdiag_neg)
+        ctx.r, ctx.qc, ctx.inbc, ctx.queue, ctx.self_sim = r, qc, inbc, queue, self_sim
+        ctx.mark_non_differentiable(r.scalars, r.dists, r.softmax_weights, r.pos)
+        return r.scalars[0].clone(), r.scalars, r.dists, r.softmax_weights, r.pos
+
+    @staticmethod
+    def backward(ctx, g_loss, *unused):
+        r = ctx.r
+        if g_loss is None:
+            return None, None, None, None, None, None, None
+        dq = torch.zeros_like(ctx.qc)
+        gs = g_loss.detach().reshape(1).contiguous().float()
+        wmat = ops.infonce_bwd(r, ctx.qc, ctx.inbc, ctx.queue, gs, dq, want_wmat=ctx.self_sim)
+        if ctx.self_sim:   # column side of q.q^T: dq_j += sum_i w_ij q_i
+            B, D = ctx.qc.shape
+            ops.conv_wgrad(ops.linear_desc(B, D, B), ctx.qc, wmat, dq)
+        return dq, None, None, None, None, None, None
+
+
+class _EncodeFn(torch.autograd.Function):
+    """trunk -> avg-pool -> head -> L2 normalise as one autograd node.  ``anchor`` is a dummy requires-grad scalar that
+    makes autograd call backward; parameter gradients are accumulated into the model's flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, anchor, data, model, jigsaw, orders, with_head):
+        ctx.set_materialize_grads(False)
+        out = model._encode(data, jigsaw, orders, with_head, save=True)
+        ctx.model, ctx.generation = model, model._fwd_generation
+        ctx.mark_non_differentiable(out[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_spatial, d_pooled, d_pre, d_emb):
+        model = ctx.model
+        if ctx.generation != model._fwd_generation:
+            raise RuntimeError("VinceModel: backward of a stale forward -- the saved activations were overwritten by a "
+                               "later grad-enabled forward of the same model")
+        model._encode_backward(d_pooled, d_pre, d_emb)
+        return torch.zeros_like(model._anchor), None, None, None, None, None
+
+
+class VinceModel(BaseModel):
+    def __init__(self, args):
+        super(VinceModel, self).__init__(args)
+        self.args = args
+        self.num_frames = self.args.num_frames
+        self.compute_dtype = _compute_dtype(args)
+
+        # Network stuff (vince_model.py:25-49)
+        self.feature_extractor = self.args.backbone(self.args, -2)
+        self.feature_extractor.bind_owner(self)
+        resnet_output_channels = self.feature_extractor.output_channels
+        self.output_channels = resnet_output_channels
+        if getattr(self.args, "use_attention", False):
+            raise NotImplementedError("--use-attention (dg_util AttentionPool2D) is not part of the HIP path")
+        self.embedding = nn.Sequential(
+            nn.Linear(self.output_channels, self.output_channels),
+            constants.NONLINEARITY(),
+            nn.Linear(self.output_channels, self.args.vince_embedding_size),
+        )
+        if self.args.jigsaw:
+            self.jigsaw_linear = nn.Linear(self.output_channels, self.output_channels)
+            self.jigsaw_embedding = nn.Sequential(
+                nn.Linear(self.output_channels * 9, self.output_channels),
+                constants.NONLINEARITY(),
+                nn.Linear(self.output_channels, self.args.vince_embedding_size),
+            )
+        if getattr(self.args, "use_imagenet", False):   # vince_model.py:79-90: plain torch side heads on detached features
+            self.imagenet_decoders = nn.ModuleList([
+                nn.Linear(self.output_channels, 1000),
+                nn.Sequential(nn.Linear(self.output_channels, self.output_channels), constants.NONLINEARITY(),
+                              nn.Linear(self.output_channels, 1000)),
+            ])
+            self.num_imagenet_decoders = len(self.imagenet_decoders)
+
+        self._anchor = torch.zeros((), requires_grad=True)
+        self._trunks = {}
+        self._saved_ws = None
+        self._wcache = None
+        self._saved = None
+        self._fwd_generation = 0
+        self._param_version, self._wcache_version = 1, 0
+        self._grad_zero_pending = True
+        self._flat = self._flat_grad = None
+        self._build_flat()
+
+    # ------------------------------------------------------------------------------------------ flat storage
+    def _flat_entries(self):
+        """(parameter, is_conv) in flat order: trunk (engine order), heads, then the EMA-only tail (fc)."""
+        res = self.feature_extractor.model
+        entries = [(p, p.dim() == 4) for p in res.trunk_params]
+        heads = [self.embedding[0].weight, self.embedding[0].bias, self.embedding[2].weight, self.embedding[2].bias]
+        if self.args.jigsaw:
+            heads += [self.jigsaw_linear.weight, self.jigsaw_linear.bias, self.jigsaw_embedding[0].weight,
+                      self.jigsaw_embedding[0].bias, self.jigsaw_embedding[2].weight, self.jigsaw_embedding[2].bias]
+        entries += [(p, False) for p in heads]
+        tail = [(res.fc.weight, False), (res.fc.bias, False)]
+        return entries, tail
+
+    def _build_flat(self):
+        entries, tail = self._flat_entries()
+        device = entries[0][0].device
+        offs, total = [], 0
+        for p, _ in entries + tail:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        n_train = offs[len(entries)] if tail else total
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        grad = torch.zeros(n_train, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for i, (p, is_conv) in enumerate(entries + tail):
+                n, off = p.numel(), offs[i]
+
+                def view_of(buf):
+                    if is_conv:
+                        co, ci, kh, kw = p.shape
+                        return buf[off:off + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+                    return buf[off:off + n].view(p.shape)
+
+                v = view_of(flat)
+                v.copy_(p.data)
+                p.data = v
+                p.grad = view_of(grad) if (i < len(entries) and p.requires_grad) else None
+        self._flat, self._flat_grad = flat, grad
+        self._n_train, self._n_ema = n_train, total
+        self._offs = offs
+        self._anchor = torch.zeros((), requires_grad=True, device=device)
+        res = self.feature_extractor.model
+        ntrunk = len(res.trunk_params)
+        self._head_params = [p for p, _ in entries[ntrunk:]]
+        # contiguous flat ranges by role: SGD skips a head whose parameters received no gradient this step, exactly as
+        # torch.optim.SGD skips parameters whose .grad is None (the standard head idles when the query side is jigsawed)
+        emb_end = offs[ntrunk + 4] if len(entries) > ntrunk + 4 else n_train
+        self._segments = {"trunk": (0, offs[ntrunk]), "embedding": (offs[ntrunk], emb_end), "jigsaw": (emb_end, n_train)}
+        self._touched = {"trunk": False, "embedding": False, "jigsaw": False}
+        self._bucket_events = None
+        # first trunk-parameter offset of every ResNet stage (gradient buckets for data parallelism)
+        self._stage_offsets = {}
+        for i, (name, _, _, _) in enumerate(res.plan.params):
+            stage = name.split(".")[0]
+            if stage.startswith("layer") and stage not in self._stage_offsets:
+                self._stage_offsets[stage] = offs[i]
+        if device.type == "cuda":
+            self._param_ptrs = pointer_table([p.data for p in res.trunk_params])
+            self._grad_ptrs = pointer_table([flat_grad_view(grad, offs[i], res.trunk_params[i]) for i in range(ntrunk)])
+            self._head_grads = [flat_grad_view(grad, offs[ntrunk + j], hp) for j, hp in enumerate(self._head_params)]
+            run, nbt = [], []
+            for node in res.bn_nodes():
+                run += [node.running_mean, node.running_var]
+                nbt.append(node.num_batches_tracked)
+            self._bn_running_ptrs, self._bn_nbt_ptrs = pointer_table(run), pointer_table(nbt)
+        self._trunks, self._saved_ws, self._wcache, self._saved = {}, None, None, None
+        self._touch()
+
+    def _apply(self, fn, *a, **k):
+        super(VinceModel, self)._apply(fn, *a, **k)
+        if getattr(self, "_flat", None) is not None:
+            self._build_flat()
+        return self
+
+    def to(self, device):
+        super(VinceModel, self).to(device)   # the reference's VinceModel.to returns None (vince_model.py:92-94); we return self
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # accept DataParallel-era keys (feature_extractor.module.model.*)
+        fixed = {k.replace("feature_extractor.module.", "feature_extractor."): v for k, v in state_dict.items()}
+        out = super(VinceModel, self).load_state_dict(fixed, strict=strict, **kw)
+        self._touch()
+        return out
+
+    def _touch(self):
+        """Parameters changed: the compute-dtype weight copies must be rebuilt before the next forward."""
+        self._param_version += 1
+
+    def zero_grad(self, set_to_none=True):
+        self._grad_zero_pending = True
+        self._touched = {"trunk": False, "embedding": False, "jigsaw": False}
+        if hasattr(self, "imagenet_decoders"):
+            for p in self.imagenet_decoders.parameters():
+                p.grad = None
+
+    def flat_parameters(self):
+        """(flat params, flat grads, trainable length, ema length) for the fused optimiser / EMA / all-reduce."""
+        return self._flat, self._flat_grad, self._n_train, self._n_ema
+
+    def vince_parameters(self):
+        # vince_model.py:96-104 (average_layers has no parameters without attention)
+        params = list(self.feature_extractor.parameters()) + list(self.embedding.parameters())
+        if self.args.jigsaw:
+            params += list(self.jigsaw_linear.parameters()) + list(self.jigsaw_embedding.parameters())
+        return params
+
+    # ------------------------------------------------------------------------------------------ engine plumbing
+    def _require_gpu(self):
+        if self._flat.device.type != "cuda":
+            raise RuntimeError("VinceModel: parameters are on %s -- the HIP path needs the GPU (model.to('cuda:0')); "
+                               "there is no CPU fallback" % self._flat.device)
+
+    def _trunk(self, n, h, w):
+        key = (n, h, w)
+        t = self._trunks.get(key)
+        if t is None:
+            t = Trunk(self.feature_extractor.arch, n, h, w, self.compute_dtype)
+            self._trunks[key] = t
+        return t
+
+    def _ensure_weights(self, trunk):
+        if self._wcache is None:
+            self._wcache = torch.empty(trunk.wc_bytes, dtype=torch.uint8, device=self._flat.device)
+        if self._wcache_version != self._param_version:
+            trunk.prepare_weights(self._param_ptrs, self._wcache)
+            self._head_t = {}
+            for p in self._head_params:
+                if p.dim() == 2:
+                    self._head_t[id(p)] = ops.prepare_weight(p.data.view(p.shape[0], 1, p.shape[1]), torch.float32)[1].view(
+                        p.shape[1], p.shape[0])
+            self._wcache_version = self._param_version
+
+    def _encode(self, data, jigsaw, orders, with_head, save):
+        """Returns (spatial, pooled, prenorm, embeddings).  data: float32 NCHW on the GPU."""
+        self._require_gpu()
+        if data.dtype != torch.float32 or data.dim() != 4 or data.shape[1] != 3:
+            raise ValueError("VinceModel: expected float32 N x 3 x H x W frames, got %s %s" % (data.dtype, tuple(data.shape)))
+        data = data.to(self._flat.device).contiguous()
+        n, _, h, w = data.shape
+        if jigsaw:
+            hp, wp = (h + 3 - h % 3, w + 3 - w % 3) if (h % 3 or w % 3) else (h, w)   # vince_model.py:145-146
+            trunk = self._trunk(n * 9, hp // 3, wp // 3)
+        else:
+            trunk = self._trunk(n, h, w)
+        self._ensure_weights(trunk)
+        if save:
+            if self._saved_ws is None or self._saved_ws.numel() < trunk.ws_bytes:
+                self._saved_ws = None
+                self._saved_ws = torch.empty(trunk.ws_bytes, dtype=torch.uint8, device=self._flat.device)
+            ws = self._saved_ws
+            self._fwd_generation += 1
+        else:
+            ws = nograd_workspace(self._flat.device, trunk.ws_bytes)
+        nt = trunk.N
+        pooled = torch.empty(nt, self.output_channels, device=self._flat.device, dtype=torch.float32)
+        trunk.forward(self._param_ptrs, self._wcache, self._bn_running_ptrs, self._bn_nbt_ptrs, data, ws, pooled,
+                      train_bn=self.training, jigsaw_src=(h, w) if jigsaw else None)
+        spatial = trunk.spatial_view(ws).clone()
+        pre = emb = None
+        saved = dict(trunk=trunk, pooled=pooled, jigsaw=jigsaw)
+        if with_head:
+            if jigsaw:   # vince_model.py:161-171
+                f = ops.linear_fwd(pooled, self.jigsaw_linear.weight.data, self.jigsaw_linear.bias.data)
+                c = f.shape[1]
+                idx = orders.to(f.device).unsqueeze(-1).expand(n, 9, c)
+                g = torch.gather(f.view(n, 9, c), 1, idx).reshape(n, 9 * c).contiguous()
+                hid = ops.linear_fwd(g, self.jigsaw_embedding[0].weight.data, self.jigsaw_embedding[0].bias.data, relu=True)
+                pre = ops.linear_fwd(hid, self.jigsaw_embedding[2].weight.data, self.jigsaw_embedding[2].bias.data)
+                saved.update(g=g, hid=hid, orders=orders.to(f.device))
+            else:        # vince_model.py:175-177
+                hid = ops.linear_fwd(pooled, self.embedding[0].weight.data, self.embedding[0].bias.data, relu=True)
+                pre = ops.linear_fwd(hid, self.embedding[2].weight.data, self.embedding[2].bias.data)
+                saved.update(hid=hid)
+            emb, norms = ops.l2norm_fwd(pre)   # F.normalize(dim=1), vince_model.py:180
+            saved.update(pre=pre, norms=norms)
+        if save:
+            self._saved = saved
+        return spatial, pooled, pre, emb
+
+    def _encode_backward(self, d_pooled, d_pre, d_emb):
+        s = self._saved
+        if self._grad_zero_pending:
+            self._flat_grad.zero_()
+            self._grad_zero_pending = False
+        hg = {id(p): g for p, g in zip(self._head_params, self._head_grads)}
+        ht = self._head_t
+        dpool_total = d_pooled.contiguous().float() if d_pooled is not None else None
+        if "pre" in s and (d_pre is not None or d_emb is not None):
+            dpre = None
+            if d_emb is not None:
+                dpre = ops.l2norm_bwd(s["pre"], s["norms"], d_emb.contiguous().float())
+            if d_pre is not None:
+                dpre = d_pre.contiguous().float() if dpre is None else dpre + d_pre
+            self._touched["jigsaw" if s["jigsaw"] else "embedding"] = True
+            if s["jigsaw"]:
+                l0, l2, lj = self.jigsaw_embedding[0], self.jigsaw_embedding[2], self.jigsaw_linear
+                dh = ops.linear_bwd(s["hid"], ht[id(l2.weight)], dpre, hg[id(l2.weight)], hg[id(l2.bias)])
+                dh = ops.relu_bwd(dh, s["hid"])
+                dg = ops.linear_bwd(s["g"], ht[id(l0.weight)], dh, hg[id(l0.weight)], hg[id(l0.bias)])
+                n, c = dg.shape[0], dg.shape[1] // 9
+                df = torch.zeros(n, 9, c, device=dg.device)
+                df.scatter_(1, s["orders"].unsqueeze(-1).expand(n, 9, c), dg.view(n, 9, c))
+                df = df.view(n * 9, c).contiguous()
+                dp = ops.linear_bwd(s["pooled"], ht[id(lj.weight)], df, hg[id(lj.weight)], hg[id(lj.bias)])
+            else:
+                l0, l2 = self.embedding[0], self.embedding[2]
+                dh = ops.linear_bwd(s["hid"], ht[id(l2.weight)], dpre, hg[id(l2.weight)], hg[id(l2.bias)])
+                dh = ops.relu_bwd(dh, s["hid"])
+                dp = ops.linear_bwd(s["pooled"], ht[id(l0.weight)], dh, hg[id(l0.weight)], hg[id(l0.bias)])
+            dpool_total = dp if dpool_total is None else dpool_total + dp
+        if dpool_total is None:
+            return
+        self._touched["trunk"] = True
+        s["trunk"].backward(self._param_ptrs, self._wcache, self._saved_ws, dpool_total.contiguous(), self._grad_ptrs,
+                            bucket_events=self._bucket_events)
+
+    def _run_encoder(self, data, jigsaw=False, orders=None, with_head=True):
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.feature_extractor.model.trunk_params)
+        if needs_grad:
+            return _EncodeFn.apply(self._anchor, data, self, jigsaw, orders, with_head)
+        return self._encode(data, jigsaw, orders, with_head, save=False)
+
+    # ------------------------------------------------------------------------------------------ reference API
+    @staticmethod
+    def split_dict_by_type(batch_types, batch_sizes, dict_to_split):
+        # vince_model.py:106-121
+        num_total = 0
+        mini_batch_list = []
+        assert "queue_vectors" not in dict_to_split
+        for ind, (batch_type, batch_size) in enumerate(zip(batch_types, batch_sizes)):
+            mini_batch = {
+                key: (val[ind] if len(val) == len(batch_types) else val[num_total: num_total + batch_size])
+                for key, val in dict_to_split.items()
+            }
+            mini_batch["batch_type"] = batch_type
+            mini_batch.pop("batch_types", None)
+            mini_batch_list.append(mini_batch)
+            num_total += batch_size
+        return mini_batch_list
+
+    def extract_features(self, inputs, run_average_layer=True):
+        # vince_model.py:123-133
+        spatial, pooled, _, _ = self._run_encoder(inputs, with_head=False)
+        return_val = {"spatial_features": spatial}
+        if run_average_layer:
+            return_val["extracted_features"] = pooled
+        return return_val
+
+    def get_embeddings(self, inputs, jigsaw=False, shuffle=False):
+        # vince_model.py:135-196
+        data = inputs["data"]
+        if shuffle:
+            # The reference permutes the batch before the DataParallel scatter and un-permutes every output
+            # (vince_model.py:137-142,184-192).  On one device that is the identity on every returned tensor, so only
+            # the RNG draw is kept; across ranks the key shuffle is done by the data-parallel glue (vince_amd/dp.py).
+            torch.randperm(data.shape[0], device=data.device)
+        orders = None
+        if jigsaw:
+            orders = inputs.get("jigsaw_orders")
+            if orders is None:   # vince_model.py:166: an independent random tile order per sample
+                orders = torch.rand(data.shape[0], 9, device=data.device).argsort(dim=1)
+        spatial, pooled, pre, emb = self._run_encoder(data, jigsaw, orders)
+        return_val = {
+            "spatial_features": spatial,
+            "extracted_features": pre if jigsaw else pooled,   # vince_model.py:171-172 overwrites it in jigsaw mode
+            "prenorm_features": pre,
+            "embeddings": emb,
+        }
+        if "batch_types" in inputs:
+            return_val = self.split_dict_by_type(inputs["batch_types"], inputs["batch_sizes"], return_val)
+        return return_val
+
+    def forward(self, inputs: Dict[str, torch.Tensor]):
+        # vince_model.py:198-250
+        return_val = copy.copy(inputs)
+        features = return_val["extracted_features"]
+        if inputs["data_source"] == "IN":
+            imagenet_features = features.clone().detach()
+
+        output = return_val["embeddings"]
+        if "queue_embeddings" in inputs and "vince_similarities" not in inputs:
+            queue_embeddings = inputs["queue_embeddings"]
+            queue_vectors = inputs["queue_vectors"]
+            B = output.shape[0]
+            if self.args.inter_batch_comparison:
+                if B != self.args.batch_size:
+                    raise ValueError("inter-batch comparison needs full batches (%d != %d): the reference's mask slice "
+                                     "would misalign the [B | K] blocks (vince_model.py:240)" % (B, self.args.batch_size))
+                frames = inputs["num_frames"] if inputs["num_frames"] > 1 else 1
+                if self.args.self_batch_comparison:
+                    loss_s, scal_s, dists_s, sw_s, _ = _InfoNCEFn.apply(
+                        output, None, None, self.args.vince_self_temperature, frames, True, True)
+                    return_val.update(dict(
+                        vince_self_similarities=LazySimilarities(output, output.detach(), None, False),
+                        vince_self_similarities_mask=("block_diag", frames, B, 0),
+                        _vince_nce_self=dict(loss=loss_s, scalars=scal_s, dists=dists_s, softmax_weights=sw_s),
+                    ))
+                loss, scal, dists, sw, pos = _InfoNCEFn.apply(output, queue_embeddings, queue_vectors,
+                                                              self.args.vince_temperature, frames, True, False)
+                sims = LazySimilarities(output, queue_embeddings.detach(), queue_vectors, False)
+                mask = ("block_diag", frames, B, queue_vectors.shape[0])
+                return_val["vince_l_neg"] = sims
+            else:
+                loss, scal, dists, sw, pos = _InfoNCEFn.apply(output, queue_embeddings, queue_vectors,
+                                                              self.args.vince_temperature, 1, False, False)
+                sims = LazySimilarities(output, queue_embeddings.detach(), queue_vectors, True)
+                mask = ("first_column", 1, B, queue_vectors.shape[0])
+                return_val["vince_l_pos"] = pos
+                return_val["vince_l_neg"] = LazySimilarities(output, queue_embeddings.detach(), queue_vectors, False,
+                                                             include_inb=False)
+            return_val.update(dict(
+                vince_similarities=sims,
+                vince_similarities_mask=mask,
+                _vince_nce=dict(loss=loss, scalars=scal, dists=dists, softmax_weights=sw),
+            ))
+
+        if inputs["data_source"] == "IN":
+            imagenet_features = imagenet_features[: inputs["imagenet_labels"].shape[0]]
+            for ii, imagenet_decoder in enumerate(self.imagenet_decoders):
+                return_val["imagenet_decoder_%d" % ii] = imagenet_decoder(imagenet_features)
+        return return_val
+
+    def loss(self, network_outputs: Optional[Dict]) -> Dict[str, Optional[Tuple[float, torch.Tensor]]]:
+        # vince_model.py:252-290
+        if network_outputs is None:
+            losses = {"nce_loss": None}
+            if self.args.self_batch_comparison:
+                losses["nce_loss_self"] = None
+            if hasattr(self, "num_imagenet_decoders"):
+                for ii in range(self.num_imagenet_decoders):
+                    losses["imagenet_loss_%d" % ii] = None
+            return losses
+
+        losses = {}
+        for key, lkey in (("", "nce_loss"), ("self_", "nce_loss_self")):
+            fused = network_outputs.get("_vince_nce" if key == "" else "_vince_nce_self")
+            if fused is not None:
+                b = fused["dists"].shape[0]
+                res = dict(dists=fused["dists"].view(b, 1, -1), dist=fused["loss"],
+                           softmax_weights=fused["softmax_weights"].view(b, 1, -1), softmax_weight=fused["scalars"][1])
+            elif ("vince_" + key + "similarities") in network_outputs and (key == "" or self.args.self_batch_comparison):
+                # a caller handed us materialised similarities + a boolean mask: the row-wise kernel of loss_util
+                sims = network_outputs["vince_" + key + "similarities"]
+                mask = network_outputs["vince_" + key + "similarities_mask"]
+                if isinstance(sims, LazySimilarities):
+                    sims = sims.materialize()
+                temperature = self.args.vince_temperature if key == "" else self.args.vince_self_temperature
+                res = loss_util.similarity_cross_entropy(sims, temperature, sims.shape[0], 1, mask)
+            else:
+                continue
+            network_outputs.update({"vince_loss_" + key + k: v for k, v in res.items()})
+            losses[lkey] = (1.0, res["dist"])
+
+        if network_outputs["data_source"] == "IN":
+            for ii in range(self.num_imagenet_decoders):
+                losses["imagenet_loss_%d" % ii] = (1.0, F.cross_entropy(network_outputs["imagenet_decoder_%d" % ii],
+                                                                        network_outputs["imagenet_labels"]))
+        return losses
+
+    def get_metrics(self, network_outputs: Optional[Dict]) -> Dict[str, Optional[float]]:
+        # vince_model.py:292-349
+        with torch.no_grad():
+            metrics = {}
+            if network_outputs is None:
+                metrics.update({"nce_accuracy_mean": None, "nce_softmax_weight_mean": None, "cosine_sim": None,
+                                "cosine_sim_neg_max": None})
+                if self.args.self_batch_comparison:
+                    metrics.update({"nce_accuracy_self_mean": None, "nce_softmax_weight_self_mean": None,
+                                    "cosine_self_sim": None})
+                if hasattr(self, "num_imagenet_decoders"):
+                    for ii in range(self.num_imagenet_decoders):
+                        metrics["imagenet_accuracy_%d" % ii] = None
+                return metrics
+
+            for key in ["", "self_"]:
+                fused = network_outputs.get("_vince_nce" if key == "" else "_vince_nce_self")
+                if fused is None:
+                    continue
+                sc = fused["scalars"]
+                metrics.update({
+                    "nce_accuracy_" + key + "mean": sc[2],
+                    "nce_softmax_weight_" + key + "mean": sc[1],
+                    "cosine_" + key + "sim": sc[3],
+                })
+                if key == "":
+                    metrics["cosine_sim_neg_max"] = sc[4]
+
+            if network_outputs["data_source"] == "IN":
+                for ii in range(self.num_imagenet_decoders):
+                    predictions = torch.argmax(network_outputs["imagenet_decoder_%d" % ii], dim=1)
+                    metrics["imagenet_accuracy_%d" % ii] = (predictions == network_outputs["imagenet_labels"]).float().mean()
+            return metrics
+
+    def get_image_output(self, network_outputs):
+        # vince_model.py:351-570 draws TensorBoard sheets with dg_util.drawing / cv2: off the timed path, out of scope.
+        return {}
+
+
+def flat_grad_view(grad, off, p):
+    n = p.numel()
+    if p.dim() == 4:
+        co, ci, kh, kw = p.shape
+        return grad[off:off + n].view(co, kh, kw, ci)
+    return grad[off:off + n].view(p.shape)
+
+
+class VinceQueueModel(BaseModel):
+    """Momentum (key) encoder, vince_model.py:573-613."""
+
+    def __init__(self, args, encoder: VinceModel):
+        super(VinceQueueModel, self).__init__(args)
+        # the reference deep-copies the encoder (:576); here a fresh model is built and the state copied, which is the
+        # same thing without cloning engine handles / workspaces
+        self.queue_network = VinceModel(args)
+        self.queue_network.load_state_dict(encoder.state_dict())
+        if encoder._flat.device.type == "cuda":
+            self.queue_network.to(encoder._flat.device)
+        self.vince_momentum = self.args.vince_momentum
+        for param in self.queue_network.parameters():
+            param.requires_grad = False
+        self.queue_network._build_flat()   # drop the gradient views of the frozen copy
+
+    def to(self, device):
+        super(VinceQueueModel, self).to(device)
+        self._device = device
+        return self
+
+    def param_update(self, encoder_model: VinceModel, momentum: float):
+        # vince_model.py:587-592: theta_k <- theta_k * m + (1 - m) * theta_q over vince_parameters() -- one pass over the
+        # flat buffer (trunk + heads + the unused fc); BatchNorm buffers are NOT touched.
+        with torch.no_grad():
+            kflat, _, _, n_ema = self.queue_network.flat_parameters()
+            qflat, _, _, _ = encoder_model.flat_parameters()
+            ops.ema_flat(kflat[:n_ema], qflat[:n_ema], float(momentum))
+        self.queue_network._touch()
+
+    def vince_update(self, encoder_model):
+        self.param_update(encoder_model, self.vince_momentum)
+
+    def forward(self, inputs, jigsaw=False, shuffle=True):
+        # vince_model.py:597-613
+        with torch.no_grad():
+            queue_data = inputs["queue_data"]
+            sub = {"data": queue_data, "batch_types": inputs["batch_types"], "batch_sizes": inputs["batch_sizes"]}
+            if "queue_jigsaw_orders" in inputs:
+                sub["jigsaw_orders"] = inputs["queue_jigsaw_orders"]
+            output_mini_batches = self.queue_network.get_embeddings(sub, jigsaw=jigsaw, shuffle=shuffle)
+            return_vals = []
+            for outputs in output_mini_batches:
+                return_val = {}
+                for key, val in outputs.items():
+                    if isinstance(val, torch.Tensor):
+                        val = val.detach()
+                    return_val["queue_" + key] = val
+                return_vals.append(return_val)
+            return return_vals

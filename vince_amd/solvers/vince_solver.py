@@ -1,0 +1,324 @@
+"""VinceSolver -- training / validation driver of the hot path (reference solvers/vince_solver.py:33-706).
+
+The step order that parity depends on is the reference's (vince_solver.py:386-518):
+key forward -> query forward -> dequeue -> similarities -> loss -> metrics -> backward -> SGD -> ENQUEUE -> EMA,
+i.e. the queue is read before this step's keys are written, and ``iteration += batch_size``.
+
+Differences that are deliberate:
+  * batches come from ``args.batch_source`` (a callable returning the reference's batch dict) or, by default, from
+    on-device synthetic frames -- the dataset / augmentation stack is upstream of the path and out of scope;
+  * one process per GPU: with torch.distributed initialised, gradients are all-reduced in buckets overlapped with
+    backward and keys are all-gathered into a replicated queue (vince_amd/dp.py);
+  * no TensorBoard image dumps, no CIFAR kNN in run_val (eval / visualisation only).
+"""
+import copy
+import os
+import random
+import time
+from queue import Queue
+from threading import Thread
+
+import torch
+
+from .. import constants, dp
+from ..data_source import SyntheticFrames
+from ..models.vince_model import VinceModel, VinceQueueModel
+from ..optim import FlatSGD
+from ..utils.storage_queue import StorageQueue
+from .base_solver import BaseSolver
+from .meters import AverageMeter
+
+ARCH_LAYERS = {"ResNet18": (2, 2, 2, 2), "ResNet50": (3, 4, 6, 3)}
+
+
+def stack_dicts_in_list(dicts, concat=False):
+    """pt_util.stack_dicts_in_list (App. B): dict of stacked / concatenated tensors; other values collected in lists."""
+    out = {}
+    for key in dicts[0]:
+        vals = [d[key] for d in dicts]
+        if isinstance(vals[0], torch.Tensor):
+            out[key] = torch.cat(vals, 0) if concat else torch.stack(vals, 0)
+        else:
+            out[key] = vals
+    return out
+
+
+class VinceSolver(BaseSolver):
+    def __init__(self, args, train_logger=None, val_logger=None):
+        self.num_frames = args.num_frames
+        self.train_batch_fns = []
+        self.val_batch_fns = []
+        self.vince_queue: StorageQueue = None
+        self.queue_model: VinceQueueModel = None
+        self.batch_count = 0
+        self.batch_queue = Queue(2)
+        self.prefetch_thread = None
+        self.kill_thread = False
+        self.drawn_this_epoch = False
+        self.reducer = None
+        super(VinceSolver, self).__init__(args, train_logger, val_logger)
+
+    # ------------------------------------------------------------------------------------------ setup
+    def _torch_device(self):
+        dev = self.args.pytorch_gpu_ids[0]
+        return torch.device(dev) if isinstance(dev, str) else torch.device("cuda:%d" % dev)   # vince_solver.py:269
+
+    def setup_dataloader(self):
+        src = getattr(self.args, "batch_source", None)
+        if src is None:
+            w, r = dp.world()
+            h, wd = self.args.input_size
+            src = SyntheticFrames(self.args.batch_size, h, wd, self.args.num_frames, device=self._torch_device(),
+                                  rank=r, world=w)
+        self.train_batch_fns = src if isinstance(src, (list, tuple)) else [src]
+        self.val_batch_fns = list(getattr(self.args, "val_batch_source", None) or [])
+
+    @property
+    def iterations_per_epoch(self):
+        return self.args.iterations_per_epoch
+
+    def setup_other(self):
+        pass   # CIFAR kNN data (vince_solver.py:236-250) is an eval-only extra
+
+    def setup_optimizer(self):
+        # vince_solver.py:252-265: SGD(lr=base_lr, weight_decay=1e-4, momentum=0.9) on model.parameters()
+        self.optimizer = FlatSGD(self.model, lr=self.args.base_lr, momentum=0.9, weight_decay=0.0001)
+        w, _ = dp.world()
+        if w > 1:
+            self.reducer = dp.GradientReducer(self.model, ARCH_LAYERS[self.model.feature_extractor.arch])
+            self.optimizer.grad_scale = 1.0 / w
+        self.print_optimizer()
+
+    def setup_model(self):
+        device = self._torch_device()
+        args = copy.copy(self.args)
+        args.title = os.path.join(getattr(args, "title", "vince"), "VinceModel")
+        if getattr(args, "checkpoint_dir", None):
+            base = getattr(args, "base_logdir", constants.BASE_LOG_DIR)
+            args.checkpoint_dir = os.path.join(base, args.title, *(args.checkpoint_dir.split(os.sep)[2:]))
+            if getattr(args, "long_save_checkpoint_dir", None):
+                args.long_save_checkpoint_dir = os.path.join(
+                    base, args.title, *(args.long_save_checkpoint_dir.split(os.sep)[2:-1]), constants.TIME_STR)
+        self.model = VinceModel(args)
+        self.iteration = self.model.restore()
+        self.model.to(device)
+        w, _ = dp.world()
+        if w > 1:   # replicas must start identical (the reference re-broadcasts parameters every forward)
+            torch.distributed.broadcast(self.model._flat, src=0)
+            self.model._touch()
+        self.queue_model = VinceQueueModel(args, self.model)
+        self.queue_model.to(device)
+        self.vince_queue = StorageQueue(args.vince_queue_size, args.vince_embedding_size, device=device,
+                                        keep_images=getattr(args, "keep_queue_images", False))
+        if w > 1:
+            torch.distributed.broadcast(self.vince_queue.vector_queue, src=0)
+        self.epoch = self.iteration // (self.args.iterations_per_epoch * self.args.batch_size)
+        if self.iteration > 0:
+            print("Resuming epoch", self.epoch)
+        if getattr(self.args, "prefetch_thread", False):
+            self.start_prefetch()
+        self.fill_queue_repeat()
+
+    # ------------------------------------------------------------------------------------------ queue fill
+    def fill_queue_repeat(self):
+        # vince_solver.py:315-333: hard-copy the parameters, encode ONE batch, enqueue it repeatedly up to K, then reset
+        # tail = 0 / full = False so the first real enqueue overwrites row 0 (App. D item 6).
+        self.queue_model.param_update(self.model, 0)
+        num_added = 0
+        self.vince_queue.clear()
+        with torch.no_grad():
+            batches_concat, batches = self.get_batch()
+            outputs = self.queue_model(batches_concat)
+            while num_added < self.vince_queue.maxsize:
+                for batch, output in zip(batches, outputs):
+                    keys = dp.gather_keys(output["queue_embeddings"])
+                    self.vince_queue.enqueue(keys, None, batch["data_source"])
+                    num_added += keys.shape[0]
+                    if num_added >= self.vince_queue.maxsize:
+                        break
+        self.vince_queue.current_tail = 0
+        self.vince_queue.full = False
+        print("Queue filled with repeats")
+
+    def reset_epoch(self):
+        super(VinceSolver, self).reset_epoch()
+        self.queue_model.train()   # the key encoder never leaves train mode (vince_solver.py:337)
+        self.drawn_this_epoch = False
+
+    # ------------------------------------------------------------------------------------------ batches
+    def _next_batches(self):
+        batches = []
+        for _ in range(len(self.train_batch_fns)):
+            loader_id = self.batch_count % len(self.train_batch_fns)
+            batch = self.train_batch_fns[loader_id](loader_id)
+            if batch is None:
+                return None
+            self.batch_count += 1
+            device = self.model.device
+            batch = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+            batch.setdefault("queue_data_cpu", None)
+            batches.append(batch)
+        if len(batches) == 1:
+            concat = {k: v if isinstance(v, torch.Tensor) else [v] for k, v in batches[0].items()}
+        else:
+            concat = stack_dicts_in_list(batches, concat=True)
+        concat["batch_types"] = concat.pop("batch_type")
+        concat["batch_sizes"] = concat.pop("batch_size")
+        return concat, batches
+
+    def prefetch_batches(self):
+        while not self.kill_thread:
+            self.batch_queue.put(self._next_batches())
+
+    def start_prefetch(self):
+        self.prefetch_thread = Thread(target=self.prefetch_batches, daemon=True)
+        self.prefetch_thread.start()
+
+    def end(self):
+        self.kill_thread = True
+
+    def get_batch(self):
+        if self.prefetch_thread is not None:
+            batches = self.batch_queue.get()
+            while batches is None:
+                self.fill_queue_repeat()
+                batches = self.batch_queue.get()
+            return batches
+        batches = self._next_batches()
+        while batches is None:   # loader epoch ended: refill the queue with repeats (vince_solver.py:379-384)
+            self.fill_queue_repeat()
+            batches = self._next_batches()
+        return batches
+
+    # ------------------------------------------------------------------------------------------ the hot loop
+    def run_train_iteration(self):
+        total_t_start = time.time()
+        t_start = time.time()
+        image_batch_concat, image_batches = self.get_batch()
+        t_end = time.time()
+        self.time_meters["data_cache_time"].update(t_end - t_start)
+        t_start = time.time()
+
+        # key encoder (no grad) then query encoder (vince_solver.py:397-406)
+        if self.args.jigsaw:
+            if random.random() < 0.5:
+                queue_batches = self.queue_model(image_batch_concat, jigsaw=True, shuffle=True)
+                outputs = self.model.get_embeddings(image_batch_concat, jigsaw=False, shuffle=True)
+            else:
+                queue_batches = self.queue_model(image_batch_concat, jigsaw=False, shuffle=True)
+                outputs = self.model.get_embeddings(image_batch_concat, jigsaw=True, shuffle=True)
+        else:
+            queue_batches = self.queue_model(image_batch_concat, shuffle=True)
+            outputs = self.model.get_embeddings(image_batch_concat, shuffle=True)
+
+        t_end = time.time()
+        self.time_meters["forward_time"].update(t_end - t_start)
+        t_start = time.time()
+
+        loss_list, metrics_list = [], []
+        image_batches = self.model.split_dict_by_type(image_batch_concat["batch_types"], image_batch_concat["batch_sizes"],
+                                                      image_batch_concat)
+        for image_batch, queue_batch, output in zip(image_batches, queue_batches, outputs):
+            output.update(self.vince_queue.dequeue())
+            output.update(image_batch)
+            output.update(queue_batch)
+            output.update(self.model(output))
+            loss_dict = self.model.loss(output)
+            metrics = self.model.get_metrics(output)
+            loss_list.append({key: val[0] * val[1] for key, val in loss_dict.items()})
+            metrics_list.append(metrics)
+
+        loss_dict = {k: v.mean() for k, v in stack_dicts_in_list(loss_list).items()}
+        metrics = {k: v.mean() for k, v in stack_dicts_in_list(metrics_list).items()}
+
+        updated_loss_meters = set()
+        total_loss = 0
+        for key, weighted_loss in loss_dict.items():
+            total_loss = total_loss + weighted_loss
+            updated_loss_meters.add(key)
+        loss = total_loss
+
+        t_end = time.time()
+        self.time_meters["metrics_time"].update(t_end - t_start)
+        t_start = time.time()
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.reduce_after_backward()
+        self.optimizer.step()
+        t_end = time.time()
+        self.time_meters["backward_time"].update(t_end - t_start)
+
+        for image_batch, output in zip(image_batches, outputs):
+            # update queue (after the optimizer step, before the EMA, vince_solver.py:497-499); with several ranks
+            # every rank enqueues the same world*B block in rank order
+            keys = dp.gather_keys(output["queue_embeddings"])
+            self.vince_queue.enqueue(keys, image_batch.get("queue_data_cpu"), image_batch["data_source"])
+        self.queue_model.vince_update(self.model)
+
+        if self.logger_iteration % self.args.save_frequency == 0:
+            self.model.save(self.iteration, 5)
+
+        if self.logger_iteration % self.args.log_frequency == 0:
+            # the only host synchronisation of the step: scalar read-back for the meters (the reference's
+            # assert torch.isfinite(loss), vince_solver.py:446, synchronises every step)
+            vals = {k: float(v) for k, v in loss_dict.items()}
+            total = sum(vals.values())
+            if not (total == total and abs(total) != float("inf")):
+                raise AssertionError("non-finite loss %r" % vals)
+            for key, v in vals.items():
+                self.loss_meters[key].update(v)
+            if "total_loss" in self.loss_meters:
+                self.loss_meters["total_loss"].update(total)
+                updated_loss_meters.add("total_loss")
+            for key, val in metrics.items():
+                self.metric_meters[key].update(float(val))
+            if self.train_logger is not None:
+                log_dict = {"times/%s/%s" % (self.full_name, k): v.val for k, v in self.time_meters.items()}
+                log_dict.update({"losses/%s/%s" % (self.full_name, k): self.loss_meters[k].val for k in updated_loss_meters})
+                log_dict.update({"metrics/%s/%s" % (self.full_name, k): self.metric_meters[k].val for k in metrics})
+                self.train_logger.dict_log(log_dict, self.iteration)
+
+        self.iteration += self.args.batch_size
+        self.time_meters["total_time"].update(time.time() - total_t_start)
+        self.logger_iteration += 1
+        return loss_dict, metrics
+
+    # ------------------------------------------------------------------------------------------ validation
+    def run_val(self):
+        """vince_solver.py:520-649 without the CIFAR kNN / image dumps: the QUERY encoder in eval mode (running BN
+        statistics), the key encoder still in train mode, no backward, no enqueue, no EMA."""
+        if not self.val_batch_fns:
+            return {}
+        self.model.eval()
+        loss_meters = {k: AverageMeter() for k in self.model.loss(None).keys()}
+        metric_meters = {k: AverageMeter() for k in self.model.get_metrics(None).keys()}
+        with torch.no_grad():
+            for fn in self.val_batch_fns:
+                while True:
+                    batch = fn(0)
+                    if batch is None:
+                        break
+                    device = self.model.device
+                    batch = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+                    concat = {k: v if isinstance(v, torch.Tensor) else [v] for k, v in batch.items()}
+                    concat["batch_types"] = concat.pop("batch_type")
+                    concat["batch_sizes"] = concat.pop("batch_size")
+                    queue_batches = self.queue_model(concat, shuffle=False)
+                    outputs = self.model.get_embeddings(concat)
+                    image_batches = self.model.split_dict_by_type(concat["batch_types"], concat["batch_sizes"], concat)
+                    for image_batch, queue_batch, output in zip(image_batches, queue_batches, outputs):
+                        output.update(self.vince_queue.dequeue())
+                        output.update(image_batch)
+                        output.update(queue_batch)
+                        output.update(self.model(output))
+                        for k, v in self.model.loss(output).items():
+                            loss_meters[k].update(float(v[0] * v[1]), batch["batch_size"])
+                        for k, v in self.model.get_metrics(output).items():
+                            metric_meters[k].update(float(v), batch["batch_size"])
+        self.model.train()
+        out = {k: m.avg for k, m in loss_meters.items()}
+        out.update({k: m.avg for k, m in metric_meters.items()})
+        if self.val_logger is not None:
+            self.val_logger.dict_log({"losses/%s/%s" % (self.full_name, k): v for k, v in out.items()}, self.iteration)
+        return out
