@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py -- encoded frames/s of the VINCE encoder + contrastive training step on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 20 --warmup 5
+
+One "step" = one full VinceSolver.run_train_iteration on one synthetic batch already resident in HBM: key-encoder
+forward + query-encoder forward + fused similarity/InfoNCE + metrics + backward + SGD + queue enqueue + EMA
+(reference solvers/vince_solver.py:386-518).  Every step encodes 2*B frames per GPU (B keys + B queries), so
+value = 2 * B * n_gpus * steps / seconds ("encoded frames/sec/node", BASELINE.json).  Workload = BASELINE config 3:
+ResNet-50, 224x224, B=256 per GPU, K=65536, D=128, T=0.2, bf16 trunk / fp32 head+loss, random-init weights,
+synthetic N(0,1) frames.  Weak scaling: per-GPU batch fixed.
+
+Extra legs (rank 0, N=1 only unless --no-extras):
+  roofline      per-kernel hipEvent timing of the dominant kernel (bf16 implicit-GEMM conv, 128-channel tile) over
+                instrumented steps: algorithmic FLOPs of its launches / their summed duration vs the 2.5 PFLOP/s dense
+                bf16 MFMA peak; plus the whole-step MFMA fraction.
+  cpu_baseline  the CPU oracle (oracle/vince_oracle.py, a torch-CPU restatement pinned to the reference) timed on the
+                host cores at B=16 for a few steps.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# algorithmic work per unit (hook-counted on the reference's resnet.py)
+STEP_GFLOP_PER_SAMPLE = {"ResNet50": 32.766, "ResNet18": 14.512}     # key fwd + query fwd + query bwd + similarity
+FWD_GFLOP_PER_FRAME = {"ResNet50": 8.2000, "ResNet18": 3.6282}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}                          # MI355X_MICROARCH.md dense MFMA peaks
+KERNEL_TAGS = ["conv_igemm<f32,64>", "conv_igemm<f32,128>", "conv_igemm<bf16,64>", "conv_igemm<bf16,128>",
+               "conv_wgrad<f32>", "conv_wgrad<bf16>"]
+
+
+class PooledFrames:
+    """Cycles through a small pool of pre-generated on-device batches (inputs resident in HBM before timing)."""
+
+    def __init__(self, batch, h, w, frames, device, pool, rank, world):
+        self.items = []
+        g = torch.Generator(device=device)
+        for i in range(pool):
+            g.manual_seed(1000 + i * world + rank)
+            data = torch.randn(batch, 3, h, w, generator=g, device=device)
+            qdata = data + 0.25 * torch.randn(batch, 3, h, w, generator=g, device=device)
+            self.items.append({"data": data, "queue_data": qdata, "batch_type": "images", "batch_size": batch,
+                               "data_source": "SYN", "num_frames": frames})
+        self.i = 0
+
+    def __call__(self, loader_id=0):
+        item = self.items[self.i % len(self.items)]
+        self.i += 1
+        return dict(item)
+
+
+def cpu_baseline(arch, embed, K, T, hw, batch, steps):
+    """Times the CPU oracle's full training step on the host cores (baseline, not a target)."""
+    from oracle import vince_oracle as vo
+    tr = vo.OracleTrainer(arch, embed, K, batch, T, 0.03, seed=0)
+    data = vo.gaussian_frames(batch, hw, hw, 1000)
+    qdata = data + 0.25 * vo.gaussian_frames(batch, hw, hw, 2000)
+    tr.step(data, qdata)   # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        tr.step(data, qdata)
+    dt = time.time() - t0
+    return 2.0 * batch * steps / dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--backbone", default="ResNet50")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--queue", type=int, default=65536)
+    ap.add_argument("--embed", type=int, default=128)
+    ap.add_argument("--temperature", type=float, default=0.2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline and cpu_baseline legs")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    opt = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+    assert world == opt.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (opt.gpus, world)
+    device = torch.device("cuda", local)
+
+    from vince_amd.config import make_args
+    from vince_amd.solvers.vince_solver import VinceSolver
+    from vince_amd._lib import lib
+
+    pool = PooledFrames(opt.batch, opt.size, opt.size, 1, device, pool=4, rank=rank, world=world)
+    args = make_args(backbone=opt.backbone, batch_size=opt.batch, vince_queue_size=opt.queue,
+                     vince_embedding_size=opt.embed, vince_temperature=opt.temperature, compute_dtype=opt.dtype,
+                     input_size=(opt.size, opt.size), base_lr=0.03, pytorch_gpu_ids=[local],
+                     feature_extractor_gpu_ids=[local], batch_source=pool, log_frequency=10 ** 9,
+                     iterations_per_epoch=10 ** 9)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO() if rank != 0 else sys.stderr):
+        solver = VinceSolver(args)
+        solver.reset_epoch()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(opt.warmup):
+        solver.run_train_iteration()
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(opt.steps):
+        last = solver.run_train_iteration()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(last[0]["nce_loss"])
+    frames_per_s = 2.0 * opt.batch * world * opt.steps / dt
+    ms_per_step = 1000.0 * dt / opt.steps
+    step_tflop = STEP_GFLOP_PER_SAMPLE.get(opt.backbone, 0.0) * opt.batch / 1000.0
+    whole_step_tflops = step_tflop / (ms_per_step / 1000.0)
+
+    out = {
+        "metric": "encoded frames/sec/node (full VINCE training step: key fwd + query fwd + InfoNCE + bwd + SGD + enqueue + EMA)",
+        "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": opt.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: %s %dx%d, B=%d per GPU, K=%d, D=%d, T=%g (MoCo-v2 mode), random init"
+                               % (opt.backbone, opt.size, opt.size, opt.batch, opt.queue, opt.embed, opt.temperature),
+                   "global_batch": opt.batch * world, "frames_per_step": 2 * opt.batch * world,
+                   "parallelism": "dp%d" % world, "final_loss": round(loss, 5)},
+        "step_mfma_frac": round(whole_step_tflops / PEAK_TFLOPS[opt.dtype], 4),
+        "step_tflops_per_gpu": round(whole_step_tflops, 2),
+    }
+
+    if rank == 0 and world == 1 and not opt.no_extras:
+        # ---- roofline leg: hipEvent pairs around every conv launch for a few extra steps -------------------------
+        L = lib()
+        L.vince_profile_enable(1)
+        for _ in range(opt.profile_steps):
+            solver.run_train_iteration()
+        torch.cuda.synchronize()
+        L.vince_profile_enable(0)
+        n = len(KERNEL_TAGS)
+        ms, fl, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_int64 * n)()
+        L.vince_profile_collect(n, ms, fl, cnt)
+        kernels = {}
+        for i, name in enumerate(KERNEL_TAGS):
+            if cnt[i]:
+                kernels[name] = {"launches_per_step": cnt[i] // opt.profile_steps, "avg_us": round(1000.0 * ms[i] / cnt[i], 2),
+                                 "ms_per_step": round(ms[i] / opt.profile_steps, 3),
+                                 "tflops": round(fl[i] / (ms[i] * 1e-3) / 1e12, 1)}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
+        dom_conv = "conv_igemm<%s,128>" % ("bf16" if opt.dtype == "bf16" else "f32")
+        if dom_conv in kernels:
+            k = kernels[dom_conv]
+            out["roofline"] = {"bound": "mfma", "kernel": dom_conv, "achieved": k["tflops"], "peak": PEAK_TFLOPS[opt.dtype],
+                               "unit": "TFLOP/s", "frac": round(k["tflops"] / PEAK_TFLOPS[opt.dtype], 4), "traffic": None,
+                               "avg_us": k["avg_us"], "launches_per_step": k["launches_per_step"],
+                               "ms_per_step": k["ms_per_step"], "longest_kernel_family": dom}
+        out["kernels"] = kernels
+        # ---- cpu_baseline leg ----------------------------------------------------------------------------------------
+        try:
+            cores = torch.get_num_threads()
+            cb, csteps = 16, opt.cpu_steps
+            v = cpu_baseline(opt.backbone, opt.embed, opt.queue, opt.temperature, opt.size, cb, csteps)
+            out["cpu_baseline"] = {"value": round(v, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+                                   "sample": "CPU oracle (torch-CPU restatement pinned to the reference), %s %dx%d, "
+                                             "B=%d, K=%d, %d full training steps after 1 warm-up"
+                                             % (opt.backbone, opt.size, opt.size, cb, opt.queue, csteps)}
+        except Exception as e:   # the baseline leg must never take the measurement down
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

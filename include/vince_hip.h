@@ -40,6 +40,13 @@ extern "C" {
 const char* vince_last_error(void);
 int vince_abi_version(void);
 
+/* Measurement aid (bench.py): while enabled, every conv_igemm / conv_wgrad launch is bracketed by a hipEvent pair on
+ * its stream.  Tags: 0..3 = conv_igemm {f32 CT64, f32 CT128, bf16 CT64, bf16 CT128}, 4 = conv_wgrad f32,
+ * 5 = conv_wgrad bf16.  collect() synchronises, returns per-tag total milliseconds / algorithmic FLOPs / launches and
+ * clears the log.  Not for production runs (one event pair per launch). */
+int vince_profile_enable(int on);
+int vince_profile_collect(int32_t ntags, double* ms, double* flops, int64_t* count);
+
 /* ---------------------------------------------------------------------------------------------
  * Generalised tap convolution as implicit GEMM on MFMA (K1-K3, K8 forward; dgrad of the same).
  *

@@ -32,6 +32,8 @@ P = ctypes.POINTER
 PROTOTYPES = {
     "vince_last_error": (ctypes.c_char_p, []),
     "vince_abi_version": (c_int, []),
+    "vince_profile_enable": (c_int, [c_int]),
+    "vince_profile_collect": (c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
     "vince_conv_igemm": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vince_conv_wgrad": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_void_p]),
     "vince_bn_finalize": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,

@@ -20,6 +20,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // error plumbing: every export returns int, never throws; message kept thread-local
 // ---------------------------------------------------------------------------------------------
 void vince_set_error(const char* fmt, ...);
+bool vince_profile_enabled();
+void vince_profile_begin_launch(int tag, double work, void* stream, void** token);
+void vince_profile_end_launch(void* token, void* stream);
 
 #define VINCE_CHECK_ARG(cond, code, ...)   \
     do {                                   \

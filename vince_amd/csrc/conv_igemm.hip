@@ -322,6 +322,15 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     const int CT = narrow ? 64 : 128;
     p.ctiles = (d.Co + CT - 1) / CT;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == VINCE_F32) return narrow ? launch<float, 64>(p, s) : launch<float, 128>(p, s);
-    return narrow ? launch<bf16_t, 64>(p, s) : launch<bf16_t, 128>(p, s);
+    void* tok = nullptr;
+    if (vince_profile_enabled()) {
+        // algorithmic FLOPs: the stem's input channels are padded 3 -> CH; count the 3 real ones
+        const double ci_alg = (d.Ci == CH && T > 1) ? 3.0 : (double)d.Ci;
+        vince_profile_begin_launch((dtype == VINCE_F32 ? 0 : 2) + (narrow ? 0 : 1), 2.0 * p.M * d.Co * T * ci_alg, stream, &tok);
+    }
+    int rc;
+    if (dtype == VINCE_F32) rc = narrow ? launch<float, 64>(p, s) : launch<float, 128>(p, s);
+    else rc = narrow ? launch<bf16_t, 64>(p, s) : launch<bf16_t, 128>(p, s);
+    if (tok) vince_profile_end_launch(tok, stream);
+    return rc;
 }

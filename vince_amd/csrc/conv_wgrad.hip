@@ -275,5 +275,10 @@ extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.dy = dy; p.dw = dw; p.Ci_dw = Ci_dw; p.variant = variant;
     hipStream_t s = (hipStream_t)stream;
-    return dtype == VINCE_F32 ? dispatch<float>(p, s) : dispatch<bf16_t>(p, s);
+    void* tok = nullptr;
+    if (vince_profile_enabled())
+        vince_profile_begin_launch(dtype == VINCE_F32 ? 4 : 5, 2.0 * p.M * d.Co * T * (double)Ci_dw, stream, &tok);
+    const int rc = dtype == VINCE_F32 ? dispatch<float>(p, s) : dispatch<bf16_t>(p, s);
+    if (tok) vince_profile_end_launch(tok, stream);
+    return rc;
 }

@@ -15,3 +15,51 @@ void vince_set_error(const char* fmt, ...) {
 
 extern "C" const char* vince_last_error(void) { return g_err; }
 extern "C" int vince_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-kernel event timing (bench.py's roofline leg): while enabled, the instrumented launchers bracket every launch
+// with a hipEvent pair on the launch stream; vince_profile_collect() synchronises and sums duration / work per tag.
+#include <hip/hip_runtime.h>
+#include <vector>
+
+namespace {
+struct ProfRec { int tag; double work; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+bool vince_profile_enabled() { return g_prof_on; }
+
+void vince_profile_begin_launch(int tag, double work, void* stream, void** token) {
+    ProfRec r;
+    r.tag = tag; r.work = work;
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, (hipStream_t)stream);
+    g_prof.push_back(r);
+    *token = (void*)(uintptr_t)g_prof.size();
+}
+
+void vince_profile_end_launch(void* token, void* stream) {
+    size_t idx = (size_t)(uintptr_t)token - 1;
+    hipEventRecord(g_prof[idx].b, (hipStream_t)stream);
+}
+
+extern "C" int vince_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int vince_profile_collect(int32_t ntags, double* ms, double* work, int64_t* count) {
+    for (int i = 0; i < ntags; ++i) { ms[i] = 0; work[i] = 0; count[i] = 0; }
+    for (auto& r : g_prof) {
+        hipEventSynchronize(r.b);
+        float t = 0;
+        hipEventElapsedTime(&t, r.a, r.b);
+        if (r.tag >= 0 && r.tag < ntags) { ms[r.tag] += t; work[r.tag] += r.work; count[r.tag] += 1; }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return 0;
+}
