@@ -99,6 +99,10 @@ def lib():
             raise RuntimeError(
                 "vince_amd: %s is missing -- build the HIP extension first (python -m vince_amd.build). "
                 "There is no CPU fallback." % LIB_PATH)
+        # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Loading it FIRST makes the dynamic linker bind
+        # our NEEDED libamdhip64.so.7 to that same runtime instance; the other order loads a second HIP runtime from
+        # /opt/rocm whose streams / device state are not torch's ("no ROCm-capable device" on the first stream op).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)   # AttributeError if the .so does not export a declared symbol
