@@ -72,12 +72,17 @@ typedef struct vince_conv_desc {
     int32_t osh, osw, oh0, ow0; /* grid -> output pixel */
 } vince_conv_desc;
 
+/* Per-channel BatchNorm reductions are accumulated with fp64 atomics into VINCE_STATS_REPLICAS interleaved copies
+ * (workgroup b adds into copy b % R) so that tens of thousands of workgroups do not serialise on one L2 line per
+ * channel; the consumer (vince_bn_finalize / vince_bn_bwd_apply) sums the copies.  Layout: double[R][C][2]. */
+#define VINCE_STATS_REPLICAS 16
+
 /* epilogue flags */
 #define VINCE_EPI_ACCUMULATE 1 /* out += result (residual-gradient add) */
 #define VINCE_EPI_RELU 2       /* max(.,0) after bias */
 
 /* in/w/out have element type `dtype`; `out_f32 != 0` stores float output regardless of dtype (f32 only today).
- * bias: optional float[Co].  stats: optional double[Co][2] -- per-channel (sum, sum of squares) of the STORED
+ * bias: optional float[Co].  stats: optional double[R][Co][2] -- per-channel (sum, sum of squares) of the STORED
  * output values, atomically accumulated (feeds vince_bn_finalize; nn.BatchNorm2d train mode, resnet.py:69). */
 int vince_conv_igemm(const vince_conv_desc* d, int dtype, const void* in, const void* w, void* out,
                      const float* bias, double* stats, int flags, void* stream);
@@ -107,12 +112,13 @@ int vince_bn_apply(int dtype, const void* y, const float* scale, const float* sh
                    void* stream);
 
 /* Backward pass 1: g = dz * (mask_src > 0 if mask_src else 1);  sums[c] += (sum g, sum g*xhat),
- * xhat = (y - mean)*invstd.  sums is double[C][2], zeroed by the caller. */
+ * xhat = (y - mean)*invstd.  sums is double[R][C][2], zeroed by the caller. */
 int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_src, const void* y, const float* mean,
                         const float* invstd, double* sums, int64_t rows, int32_t C, void* stream);
 
 /* Backward pass 2: dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count); optional g_out = g (the
- * residual branch's gradient); dgamma += sum_gx, dbeta += sum_g (float[C], atomically exclusive per channel). */
+ * residual branch's gradient); dgamma += sum_gx, dbeta += sum_g (float[C]).  `sums` (the R replicas written by
+ * vince_bn_bwd_reduce) is folded in place into replica 0 first, hence not const in effect. */
 int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_src, const void* y, const float* mean,
                        const float* invstd, const float* gamma, const double* sums, int64_t count, void* dy,
                        void* g_out, float* dgamma, float* dbeta, int64_t rows, int32_t C, void* stream);

@@ -81,8 +81,9 @@ def test_conv_fwd_stats(cfg, dtype):
     wk, _ = weights_krsc(w, dtype)
     d = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
     out = torch.empty(N, d.Ho, d.Wo, Co, device=DEV, dtype=dtype)
-    stats = torch.zeros(Co, 2, device=DEV, dtype=torch.float64)
+    stats = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
     ops.conv_igemm(d, to_nhwc(x, dtype), wk, out, stats=stats)
+    stats = stats.sum(0)
     assert_close(from_nhwc(out), ref, dtype, what="conv fwd")
     o = out.float().cpu().reshape(-1, Co).double()
     np.testing.assert_allclose(stats[:, 0].cpu().numpy(), o.sum(0).numpy(), rtol=1e-5, atol=1e-3)
@@ -185,7 +186,8 @@ def test_bn_train_fwd_bwd(C, shape, dtype):
     # GPU: statistics come from the conv epilogue in production; here from the values directly
     yg = to_nhwc(y.detach(), dtype)
     yy = yg.float().reshape(-1, C).double()
-    stats = torch.stack([yy.sum(0), (yy * yy).sum(0)], 1).contiguous()
+    stats = torch.zeros(ops.STATS_REPLICAS, C, 2, device=DEV, dtype=torch.float64)
+    stats[3] = torch.stack([yy.sum(0), (yy * yy).sum(0)], 1)
     rmg, rvg = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     nbt = torch.zeros((), dtype=torch.int64, device=DEV)
     consts = ops.bn_finalize(stats, N * H * W, gamma.detach().to(DEV), beta.detach().to(DEV), rmg, rvg, nbt, True)

@@ -49,8 +49,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
     if (c >= C) return;
     float mean, invstd;
     if (train) {
-        double m = stats[2 * c] / count;
-        double var = stats[2 * c + 1] / count - m * m;
+        double s1 = 0, s2 = 0;
+        for (int r = 0; r < VINCE_STATS_REPLICAS; ++r) {
+            s1 += stats[((size_t)r * C + c) * 2];
+            s2 += stats[((size_t)r * C + c) * 2 + 1];
+        }
+        double m = s1 / count;
+        double var = s2 / count - m * m;
         if (var < 0) var = 0;
         mean = (float)m;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -160,8 +165,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         float s = 0.f;
         for (int rr = 0; rr < w.rpp; ++rr) s += red[(rr * w.tpc + c_) * 2 * CH + slot];
         const int ch = gcol * CH + (slot % CH), which = slot / CH;
-        unsafeAtomicAdd(sums + (size_t)ch * 2 + which, (double)s);
+        unsafeAtomicAdd(sums + ((size_t)(blockIdx.y % VINCE_STATS_REPLICAS) * C + ch) * 2 + which, (double)s);
     }
+}
+
+// Folds the R replica sums into replica 0 and emits dgamma / dbeta (one thread per channel).
+__global__ void bn_bwd_fold_kernel(double* sums, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sg = 0, sgx = 0;
+    for (int r = 0; r < VINCE_STATS_REPLICAS; ++r) {
+        sg += sums[((size_t)r * C + c) * 2];
+        sgx += sums[((size_t)r * C + c) * 2 + 1];
+    }
+    sums[2 * c] = sg;
+    sums[2 * c + 1] = sgx;
+    if (dgamma) dgamma[c] += (float)sgx;
+    if (dbeta) dbeta[c] += (float)sg;
 }
 
 template <typename T>
@@ -182,12 +202,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         mu[e] = mean[c];
         is[e] = invstd[c];
         k1[e] = gamma[c] * is[e];
-        ma[e] = (float)(sums[2 * c] * inv_count);
+        ma[e] = (float)(sums[2 * c] * inv_count);       // replica 0 holds the folded totals (bn_bwd_fold_kernel)
         mb[e] = (float)(sums[2 * c + 1] * inv_count);
-        if (blockIdx.y == 0 && threadIdx.x / w.tpc == 0) {
-            if (dgamma) dgamma[c] += (float)sums[2 * c + 1];
-            if (dbeta) dbeta[c] += (float)sums[2 * c];
-        }
     }
     const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + threadIdx.x / w.tpc;
     const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
@@ -428,6 +444,8 @@ extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_sr
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 4096);
     dim3 grid(w.colgroups, w.rowblocks);
     const double inv_count = 1.0 / (double)count;
+    hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double*)sums, C, dgamma,
+                       dbeta);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
                            (const float*)mask_src, (const float*)y, mean, invstd, gamma, sums, inv_count, (float*)dy,

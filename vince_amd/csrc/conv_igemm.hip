@@ -37,7 +37,6 @@ struct ConvParams {
 };
 
 constexpr int PT = 128;   // pixels per workgroup tile
-constexpr int RS = 80;    // LDS row stride in bytes for the 64-byte K slices
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -59,20 +58,23 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int CT>
+template <typename T, int CT, int KC>
 struct Smem {
+    static constexpr int RS = KC * 16 + 16;    // LDS row stride: KC 16-byte K chunks + one pad chunk (odd multiple of 16 B)
     static constexpr int MAIN = 2 * (CT + PT) * RS;
     static constexpr int CRS = CT * (int)sizeof(T) + 16;   // epilogue tile row stride (bytes)
     static constexpr int EPI = PT * CRS + 4 * CT * 2 * 4;   // + statistics scratch
     static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
 };
 
-template <typename T, int CT>
+template <typename T, int CT, int KC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64;          // 32-channel MFMA tiles per wave
-    constexpr int WROWS = CT / 64;       // weight rows staged per thread (64 rows per pass)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Smem<T, CT>::BYTES];
+    constexpr int RSTEP = 256 / KC;      // rows covered by one staging pass
+    constexpr int XROWS = PT / RSTEP, WROWS = CT / RSTEP;
+    constexpr int RS = Smem<T, CT, KC>::RS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Smem<T, CT, KC>::BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave & 1, wp = wave >> 1;
@@ -81,14 +83,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int p0 = ptile * PT, c0 = ctile * CT;
     const vince_conv_desc& d = p.d;
 
-    // ---- per-thread staging assignment: chunk column cj of rows r and r+64 --------------------------------
-    const int cj = tid & 3, r = tid >> 2;
-    int hb[2], wb[2];
-    size_t nb[2];
-    bool rv[2];
+    // ---- per-thread staging assignment: chunk column cj of rows r + e*RSTEP ------------------------------
+    const int cj = tid % KC, r = tid / KC;
+    int hb[XROWS], wb[XROWS];
+    size_t nb[XROWS];
+    bool rv[XROWS];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        uint32_t m = p0 + r + e * 64;
+    for (int e = 0; e < XROWS; ++e) {
+        uint32_t m = p0 + r + e * RSTEP;
         rv[e] = m < (uint32_t)p.M;
         uint32_t mm = rv[e] ? m : 0;
         uint32_t n = fastdiv(mm, p.div_howo);
@@ -102,16 +104,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const T* __restrict__ in = (const T*)p.in;
     const T* __restrict__ wgt = (const T*)p.w;
 
-    uint4 xr[2], wr[WROWS];
+    uint4 xr[XROWS], wr[WROWS];
     auto load_tile = [&](int kt) {
-        const int q = kt * 4 + cj;
+        const int q = kt * KC + cj;
         const int tap = q >> p.log2_cpt, cc = q & p.cpt_mask;
         const int a = (int)(((uint32_t)tap * p.tb_mul) >> 16), b = tap - a * d.TB;
         const int dh = d.dh0 + a * d.dhs, dw = d.dw0 + b * d.dws;
         const int widx = d.wt0 + a * d.wta + b * d.wtb;
         const bool qv = q < p.total_chunks;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < XROWS; ++e) {
             const int hi = hb[e] + dh, wi = wb[e] + dw;
             const bool ok = rv[e] && qv && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
 #pragma unroll
         for (int e = 0; e < WROWS; ++e) {
-            const int co = c0 + r + e * 64;
+            const int co = c0 + r + e * RSTEP;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (qv && co < d.Co) v = *(const uint4*)(wgt + ((size_t)co * d.WT + widx) * d.Ci + (size_t)cc * CH);
             wr[e] = v;
@@ -130,9 +132,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         unsigned char* ws = smem + buf * (CT + PT) * RS;
         unsigned char* xs = ws + CT * RS;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) *(uint4*)(xs + (r + e * 64) * RS + cj * 16) = xr[e];
+        for (int e = 0; e < XROWS; ++e) *(uint4*)(xs + (r + e * RSTEP) * RS + cj * 16) = xr[e];
 #pragma unroll
-        for (int e = 0; e < WROWS; ++e) *(uint4*)(ws + (r + e * 64) * RS + cj * 16) = wr[e];
+        for (int e = 0; e < WROWS; ++e) *(uint4*)(ws + (r + e * RSTEP) * RS + cj * 16) = wr[e];
     };
 
     f32x16_t acc[CJ][2];
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const unsigned char* ws = smem + buf * (CT + PT) * RS + (wc * (CT / 2)) * RS + frag_off;
         const unsigned char* xs = smem + buf * (CT + PT) * RS + CT * RS + (wp * 64) * RS + frag_off;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KC / 2; ++s) {
             uint4 wf[CJ], xf[2];
 #pragma unroll
             for (int j = 0; j < CJ; ++j) wf[j] = *(const uint4*)(ws + j * 32 * RS + s * 32);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 
     // ---- epilogue: accumulators -> LDS [pixel][channel] as T -> coalesced 16-byte stores --------------------
-    constexpr int CRS = Smem<T, CT>::CRS;
+    constexpr int CRS = Smem<T, CT, KC>::CRS;
 #pragma unroll
     for (int j = 0; j < CJ; ++j)
 #pragma unroll
@@ -267,14 +269,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) s += red[((w * CPR + ck) * CH + e) * 2 + which];
-            if (c0 + ch < d.Co) unsafeAtomicAdd(p.stats + (size_t)(c0 + ch) * 2 + which, (double)s);
+            if (c0 + ch < d.Co)
+                unsafeAtomicAdd(p.stats + ((size_t)(tile % VINCE_STATS_REPLICAS) * d.Co + (c0 + ch)) * 2 + which, (double)s);
         }
     }
 }
 
 template <typename T, int CT>
-int launch(const ConvParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL((conv_igemm_kernel<T, CT>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+int launch(ConvParams& p, hipStream_t stream) {
+    // K tile = 128 bytes per row (8 chunks) when the reduction is long enough to pipeline, else 64 bytes
+    if (p.total_chunks * (16 / (int)sizeof(T)) >= 1024) {   // K >= 1024 elements
+        p.nkt = (p.total_chunks + 7) / 8;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 8>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+    } else {
+        p.nkt = (p.total_chunks + 3) / 4;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 4>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+    }
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
@@ -327,6 +337,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
         // algorithmic FLOPs: the stem's input channels are padded 3 -> CH; count the 3 real ones
         const double ci_alg = (d.Ci == CH && T > 1) ? 3.0 : (double)d.Ci;
         vince_profile_begin_launch((dtype == VINCE_F32 ? 0 : 2) + (narrow ? 0 : 1), 2.0 * p.M * d.Co * T * ci_alg, stream, &tok);
+        vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh * 10 + d.osh, flags);
     }
     int rc;
     if (dtype == VINCE_F32) rc = narrow ? launch<float, 64>(p, s) : launch<float, 128>(p, s);

@@ -1,6 +1,7 @@
 // Thread-local error message + ABI version for libvince_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/vince_hip.h"
 
@@ -23,16 +24,23 @@ extern "C" int vince_abi_version(void) { return 1; }
 #include <vector>
 
 namespace {
-struct ProfRec { int tag; double work; hipEvent_t a, b; };
+struct ProfRec { int tag; double work; hipEvent_t a, b; int dims[6]; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
 
 bool vince_profile_enabled() { return g_prof_on; }
 
+void vince_profile_set_dims(void* token, int a, int b, int c, int d, int e, int f) {
+    size_t idx = (size_t)(uintptr_t)token - 1;
+    int* p = g_prof[idx].dims;
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d; p[4] = e; p[5] = f;
+}
+
 void vince_profile_begin_launch(int tag, double work, void* stream, void** token) {
     ProfRec r;
     r.tag = tag; r.work = work;
+    for (int i = 0; i < 6; ++i) r.dims[i] = 0;
     hipEventCreate(&r.a);
     hipEventCreate(&r.b);
     hipEventRecord(r.a, (hipStream_t)stream);
@@ -52,14 +60,20 @@ extern "C" int vince_profile_enable(int on) {
 
 extern "C" int vince_profile_collect(int32_t ntags, double* ms, double* work, int64_t* count) {
     for (int i = 0; i < ntags; ++i) { ms[i] = 0; work[i] = 0; count[i] = 0; }
+    const char* dump = getenv("VINCE_PROFILE_DUMP");
+    FILE* f = dump ? fopen(dump, "w") : nullptr;
+    if (f) fprintf(f, "tag,M,Co,K,taps,stride,flags,us,tflops\n");
     for (auto& r : g_prof) {
         hipEventSynchronize(r.b);
         float t = 0;
         hipEventElapsedTime(&t, r.a, r.b);
+        if (f) fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.2f,%.1f\n", r.tag, r.dims[0], r.dims[1], r.dims[2], r.dims[3], r.dims[4],
+                       r.dims[5], t * 1000.0, r.work / (t * 1e-3) / 1e12);
         if (r.tag >= 0 && r.tag < ntags) { ms[r.tag] += t; work[r.tag] += r.work; count[r.tag] += 1; }
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
     }
+    if (f) fclose(f);
     g_prof.clear();
     return 0;
 }

@@ -116,7 +116,7 @@ struct Planner {
         t->pbn.push_back(b.index);
         t->pshape.push_back({C, 0, 0, 0});
         b.stats = nd; b.sums = nd;   // sums live in a parallel region of the same size
-        nd += (size_t)2 * C;
+        nd += (size_t)2 * C * VINCE_STATS_REPLICAS;
         b.consts = nf;
         nf += (size_t)4 * C;
         return b;

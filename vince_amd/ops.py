@@ -11,6 +11,7 @@ from . import _lib
 from ._lib import ConvDesc, InfoNCEDesc, VINCE_BF16, VINCE_F32, check, lib
 
 EPI_ACCUMULATE, EPI_RELU = _lib.EPI_ACCUMULATE, _lib.EPI_RELU
+STATS_REPLICAS = 16   # VINCE_STATS_REPLICAS in include/vince_hip.h
 
 
 def _ptr(t):
@@ -163,7 +164,7 @@ def bn_bwd(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, want_g=False):
     require_gpu(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta)
     C = y.shape[-1]
     rows = y.numel() // C
-    sums = torch.zeros(C, 2, device=y.device, dtype=torch.float64)
+    sums = torch.zeros(STATS_REPLICAS, C, 2, device=y.device, dtype=torch.float64)
     check(lib().vince_bn_bwd_reduce(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums),
                                     rows, C, stream_ptr()))
     dy = torch.empty_like(y)
