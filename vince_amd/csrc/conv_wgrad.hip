@@ -25,10 +25,12 @@ struct WgradParams {
     float* dw;
 };
 
-constexpr int KP = 32;  // pixels per K tile
+constexpr int KP = 64;  // pixels per K tile
 
 template <typename T, int CT, int NT>
 struct WSmem {
+    // (+64 B padding, which puts the 4 rows of a ds_read_b64_tr_b16 half-wave on disjoint bank groups, measured no
+    // faster than +16 B on MI355X and costs a workgroup per CU at KP=64)
     static constexpr int YRS = CT * (int)sizeof(T) + 16;
     static constexpr int XRS = NT * (int)sizeof(T) + 16;
     static constexpr int BUF = KP * (YRS + XRS);
