@@ -1,0 +1,112 @@
+"""world_size-2 tests of the data-parallel glue on CPU (gloo, 127.0.0.1): key all-gather order + replicated queue
+(golden set G7 by composition with the oracle), cross-rank key shuffle, bucketed gradient all-reduce."""
+import os
+import socket
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import vince_oracle as vo
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def run2(fn, world=2):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn, ret)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return dict(ret)
+
+
+def _keys_case(rank, world):
+    from vince_amd import dp
+    from vince_amd.utils.queue_index import enqueue_segments
+    K, D, B = 96, 8, 20
+    queue = np.full((K, D), -1.0, np.float32)
+    tail, full = 0, False
+    tails = []
+    for step in range(4):
+        local = torch.full((B, D), float(step * 1000 + rank * B)) + torch.arange(B, dtype=torch.float32)[:, None]
+        gathered = dp.gather_keys(local)
+        assert gathered.shape == (world * B, D)
+        segs, tail, wrapped = enqueue_segments(tail, gathered.shape[0], K)
+        for dst, src, ln in segs:
+            queue[dst:dst + ln] = gathered[src:src + ln].numpy()
+        full = full or wrapped
+        tails.append(tail)
+    return queue, tails, full
+
+
+def test_replicated_queue_identical_and_matches_oracle():
+    out = run2(_keys_case)
+    q0, t0, f0 = out[0]
+    q1, t1, f1 = out[1]
+    np.testing.assert_array_equal(q0, q1)
+    assert t0 == t1 and f0 == f1
+    # single-process emulation (G7): keys concatenated in rank order into the oracle queue
+    oq = vo.OracleQueue(96, 8, init=-np.ones((96, 8), np.float32))
+    for step in range(4):
+        blocks = [np.full((20, 8), float(step * 1000 + r * 20), np.float32) + np.arange(20, dtype=np.float32)[:, None]
+                  for r in range(2)]
+        oq.enqueue(np.concatenate(blocks))
+    np.testing.assert_array_equal(q0, oq.vectors)
+    assert t0[-1] == oq.current_tail and f0 == oq.full
+
+
+def _shuffle_case(rank, world):
+    from vince_amd import dp
+    B = 6
+    local = (torch.arange(B, dtype=torch.float32) + rank * B)[:, None].repeat(1, 3)   # global row id in every column
+    perm = dp.global_permutation(world * B, step=7, seed=1)
+    mine = dp.exchange_rows(local, perm)
+    want = perm[rank * B:(rank + 1) * B].float()
+    assert torch.equal(mine[:, 0], want), (mine[:, 0], want)
+    # "encode" = identity; gather and un-permute -> natural global order on every rank
+    nat = dp.unpermute_gathered(dp.gather_keys(mine), perm)
+    assert torch.equal(nat[:, 0], torch.arange(world * B, dtype=torch.float32))
+    return perm.tolist()
+
+
+def test_cross_rank_key_shuffle_roundtrip():
+    out = run2(_shuffle_case)
+    assert out[0] == out[1]           # same permutation on every rank
+    assert sorted(out[0]) == list(range(12))
+
+
+def _reduce_case(rank, world):
+    from vince_amd import dp
+    n = 1000
+    model = types.SimpleNamespace(_flat=torch.zeros(n), _flat_grad=torch.arange(n, dtype=torch.float32) * (rank + 1),
+                                  _n_train=n, _stage_offsets={"layer1": 100, "layer2": 300, "layer3": 500, "layer4": 800},
+                                  _bucket_events=None)
+    red = dp.GradientReducer(model, (2, 2, 2, 2))
+    red.reduce_after_backward()
+    return model._flat_grad.clone()
+
+
+def test_bucketed_gradient_allreduce_sums_every_element_once():
+    out = run2(_reduce_case)
+    want = torch.arange(1000, dtype=torch.float32) * 3
+    assert torch.equal(out[0], want) and torch.equal(out[1], want)

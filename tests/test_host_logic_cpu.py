@@ -1,0 +1,133 @@
+"""CPU-only tests of the host-side logic: ring-buffer index arithmetic vs the reference golden, LR schedule, argument
+post-processing, batch splitting, state-dict layout / checkpoint key compatibility, gradient bucket plan."""
+import math
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vince_oracle as vo
+from vince_amd.utils.queue_index import enqueue_segments
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["k512", "k96"])
+def test_queue_index_arithmetic_bit_exact_vs_reference_golden(name):
+    g = np.load(os.path.join(GOLDEN, "g1_queue.npz"))
+    K = int(g[name + "_K"])
+    owner = np.full(K, -1, np.int64)
+    tail, full, nid = 0, False, 0
+    for step, n in enumerate(g[name + "_sizes"]):
+        segs, tail, wrapped = enqueue_segments(tail, int(n), K)
+        for dst, src, ln in segs:
+            owner[dst:dst + ln] = nid + np.arange(src, src + ln)
+        nid += int(n)
+        full = full or wrapped
+        assert tail == int(g[name + "_tails"][step]) and full == bool(g[name + "_fulls"][step])
+        np.testing.assert_array_equal(owner, g[name + "_owners"][step])
+    assert enqueue_segments(300, 300, 512) == ([(300, 0, 212), (0, 212, 88)], 88, True)   # SURVEY 8(a) a12 probe
+    assert enqueue_segments(0, 0, 8) == ([], 0, False)
+    assert enqueue_segments(5, 3, 8) == ([(5, 0, 3)], 8, False)       # exact fit does not wrap ...
+    assert enqueue_segments(8, 1, 8) == ([(0, 0, 1)], 1, True)        # ... the next write does
+
+
+def test_state_dict_layout_matches_reference_and_loads_strictly():
+    from vince_amd.config import make_args
+    from vince_amd.models.vince_model import VinceModel
+    for arch, embed, jig in [("ResNet18", 64, False), ("ResNet50", 128, False), ("ResNet18", 64, True)]:
+        spec = vo.model_spec(arch, embed, jig)
+        model = VinceModel(make_args(backbone=arch, vince_embedding_size=embed, jigsaw=jig))
+        sd = model.state_dict()
+        assert list(sd.keys()) == [n for n, _, _ in spec]
+        assert all(tuple(sd[n].shape) == tuple(s) for n, s, _ in spec)
+        seeded = vo.seeded_state(spec, 3)
+        model.load_state_dict(seeded)   # strict
+        for n in ["feature_extractor.model.layer2.0.conv1.weight", "embedding.2.bias", "feature_extractor.model.bn1.running_var"]:
+            torch.testing.assert_close(model.state_dict()[n], seeded[n], rtol=0, atol=0)
+        # conv weights are channels_last views of the flat buffer: memory order [Co][kh][kw][Ci]
+        w = dict(model.named_parameters())["feature_extractor.model.layer1.0.conv1.weight"]
+        assert w.stride()[1] == 1 and w.data_ptr() >= model._flat.data_ptr()
+        # DataParallel-era prefix
+        renamed = {k.replace("feature_extractor.", "feature_extractor.module."): v for k, v in seeded.items()}
+        model.load_state_dict(renamed)
+        # vince_parameters(): trunk (+fc) + embedding (+ jigsaw), BN buffers excluded (vince_model.py:96-104)
+        assert sum(p.numel() for p in model.vince_parameters()) == sum(seeded[n].numel() for n in vo.param_names(spec))
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from vince_amd.config import make_args
+    from vince_amd.models.vince_model import VinceModel
+    args = make_args(save=True, restore=True, checkpoint_dir=str(tmp_path / "ck"), long_save_checkpoint_dir=str(tmp_path / "long"))
+    m = VinceModel(args)
+    m.load_state_dict(vo.seeded_state(vo.model_spec("ResNet18", 64), 9))
+    for it in (100, 200, 300):
+        m.save(it, num_to_keep=2)
+    files = sorted(f for _, _, fs in os.walk(args.checkpoint_dir) for f in fs)
+    assert files == ["000000200.pt", "000000300.pt"]
+    m2 = VinceModel(args)
+    assert m2.restore() == 300
+    for k, v in m.state_dict().items():
+        torch.testing.assert_close(m2.state_dict()[k], v, rtol=0, atol=0)
+
+
+def test_lr_schedule_and_warmup_contract():
+    from vince_amd.solvers.base_solver import BaseSolver
+
+    class S(BaseSolver):
+        def __init__(self, args):
+            self.args, self.epoch, self.iteration, self.train_logger = args, 0, 0, None
+            self.optimizer = types.SimpleNamespace(param_groups=[{"lr": args.base_lr, "initial_lr": args.base_lr}])
+            self.model = None
+
+    a = types.SimpleNamespace(base_lr=0.03, epochs=200, lr_decay_type="cos", lr_step_schedule=[120, 160])
+    s = S(a)
+    for ep in (0, 1, 100, 199):
+        s.epoch = ep
+        assert math.isclose(s.adjust_learning_rate(), 0.03 * 0.5 * (1 + math.cos(math.pi * ep / 200)), rel_tol=1e-12)
+    a.lr_decay_type = "step"
+    for ep, f in ((0, 1), (119, 1), (120, .1), (160, .01)):
+        s.epoch = ep
+        assert math.isclose(s.adjust_learning_rate(), 0.03 * f, rel_tol=1e-9)
+
+
+def test_arg_parser_keeps_reference_flags():
+    from vince_amd import arg_parser
+    a = arg_parser.parse_args("--title t --description d --solver VinceSolver --backbone ResNet50 --batch-size 256 "
+                              "--base-lr 0.03 --vince-embedding-size 128 --vince-queue-size 65536 --vince-momentum 0.999 "
+                              "--vince-temperature 0.2 --epochs 200 --lr-decay-type cos --iterations-per-epoch 5005 "
+                              "--input-width 224 --input-height 224 --num-frames 1 --num-workers 40 --pytorch-gpu-ids 0 "
+                              "--feature-extractor-gpu-ids 0,1,2,3,4,5,6,7 --transform MoCoV2ImagenetTransform".split())
+    assert a.backbone.__name__ == "ResNet50" and a.input_size == (224, 224) and a.vince_queue_size == 65536
+    assert a.compute_dtype == "bf16" and a.use_warmup and a.save and a.restore
+    with pytest.raises(AssertionError):
+        arg_parser.parse_args(["--inter-batch-comparison", "--num-frames", "3"])
+    with pytest.raises(AssertionError):
+        arg_parser.parse_args(["--self-batch-comparison"])
+
+
+def test_split_dict_by_type_and_stack():
+    from vince_amd.models.vince_model import VinceModel
+    from vince_amd.solvers.vince_solver import stack_dicts_in_list
+    d = {"data": torch.arange(10).view(5, 2), "batch_types": ["a", "b"], "batch_sizes": [2, 3], "tags": ["x", "y"]}
+    out = VinceModel.split_dict_by_type(d["batch_types"], d["batch_sizes"], d)
+    assert [o["batch_type"] for o in out] == ["a", "b"] and out[1]["data"].shape[0] == 3 and out[0]["tags"] == "x"
+    s = stack_dicts_in_list([{"l": torch.tensor(1.0), "n": "q"}, {"l": torch.tensor(3.0), "n": "r"}])
+    assert float(s["l"].mean()) == 2.0 and s["n"] == ["q", "r"]
+
+
+def test_gradient_bucket_plan_partitions_the_flat_buffer():
+    from vince_amd import dp
+    from vince_amd.config import make_args
+    from vince_amd.models.vince_model import VinceModel
+    for arch, layers in [("ResNet18", (2, 2, 2, 2)), ("ResNet50", (3, 4, 6, 3))]:
+        m = VinceModel(make_args(backbone=arch))
+        plan = dp.bucket_plan(m, layers)
+        ranges = sorted((a, b) for _, a, b in plan)
+        assert ranges[0][0] == 0 and ranges[-1][1] == m._n_train
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1))
+        # buckets come in the order backward finishes them: layer4 (+heads) first, stem/layer1 last
+        assert [blk for blk, _, _ in plan] == [sum(layers[:3]), sum(layers[:2]), layers[0], None]
+        assert plan[0][2] - plan[0][1] > plan[-1][2] - plan[-1][1]
