@@ -19,6 +19,8 @@
 //          reduced in registers -> shuffles -> LDS -> one fp64 atomic per channel per workgroup.
 //   Grid:  1-D, remapped so that each XCD (private L2) owns a contiguous range of tiles; channel tiles of the
 //          same pixel tile are adjacent and re-read the activation tile from that L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -31,6 +33,7 @@ struct ConvParams {
     const void* in;
     const void* w;
     void* out;
+    uint32_t in_bytes, w_bytes;   // buffer-descriptor ranges for the direct-to-LDS variant (0 = tensor too large)
     const float* bias;
     double* stats;
     int flags;
@@ -66,6 +69,116 @@ struct Smem {
     static constexpr int EPI = PT * CRS + 4 * CT * 2 * 4;   // + statistics scratch
     static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
 };
+
+template <typename T, int CT, int CRS>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char* smem, f32x16_t (&acc)[CT / 64][2],
+                                              uint32_t tile, int p0, int c0, int tid, int lane, int wave, int wp, int wc) {
+    constexpr int CH = Elem<T>::CH;
+    constexpr int CJ = CT / 64;
+    const vince_conv_desc& d = p.d;
+    // ---- epilogue: accumulators -> LDS [pixel][channel] as T -> coalesced 16-byte stores --------------------
+#pragma unroll
+    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pix = wp * 64 + i * 32 + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = wc * (CT / 2) + j * 32 + 8 * g + 4 * (lane >> 5);
+                unsigned char* dst = smem + pix * CRS + ch * (int)sizeof(T);
+                if constexpr (sizeof(T) == 4) {
+                    *(float4*)dst = make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2],
+                                                acc[j][i][4 * g + 3]);
+                } else {
+                    *(uint2*)dst = make_uint2(pack_bf16x2(acc[j][i][4 * g], acc[j][i][4 * g + 1]),
+                                              pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]));
+                }
+            }
+        }
+    __syncthreads();
+
+    constexpr int CPR = CT * (int)sizeof(T) / 16;   // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CPR;                  // rows per pass
+    const int chunk = tid % CPR, row0 = tid / CPR;
+    const int cbase = c0 + chunk * CH;
+    const bool cvalid = cbase < d.Co;
+    float bias_v[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) bias_v[e] = (p.bias && cvalid) ? p.bias[cbase + e] : 0.f;
+    float ssum[CH], ssq[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) ssum[e] = ssq[e] = 0.f;
+    T* __restrict__ out = (T*)p.out;
+    const bool identity_map = (d.osh == 1 && d.osw == 1 && d.oh0 == 0 && d.ow0 == 0 && d.OH == d.Ho && d.OW == d.Wo);
+    for (int row = row0; row < PT; row += RPP) {
+        const uint32_t m = p0 + row;
+        if (m >= (uint32_t)p.M || !cvalid) continue;
+        size_t opix = m;
+        if (!identity_map) {
+            uint32_t n = fastdiv(m, p.div_howo);
+            uint32_t rem = m - n * p.div_howo.d;
+            uint32_t ho = fastdiv(rem, p.div_wo);
+            uint32_t wo = rem - ho * p.div_wo.d;
+            opix = ((size_t)n * d.OH + (ho * d.osh + d.oh0)) * d.OW + (wo * d.osw + d.ow0);
+        }
+        uint4 v = *(const uint4*)(smem + row * CRS + chunk * 16);
+        T* optr = out + opix * d.Co + cbase;
+        if (p.bias || (p.flags & (VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU))) {
+            float f[CH];
+            Chunk<T>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) f[e] += bias_v[e];
+            if (p.flags & VINCE_EPI_ACCUMULATE) {
+                float o[CH];
+                Chunk<T>::unpack(*(const uint4*)optr, o);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) f[e] += o[e];
+            }
+            if (p.flags & VINCE_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
+            }
+            v = Chunk<T>::pack(f);
+        }
+        *(uint4*)optr = v;
+        if (p.stats) {
+            float f[CH];
+            Chunk<T>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) { ssum[e] += f[e]; ssq[e] += f[e] * f[e]; }
+        }
+    }
+    if (p.stats) {   // uniform branch
+        float* red = (float*)(smem + PT * CRS);      // [4 waves][CPR][CH][2]
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], o, 64);
+                ssq[e] += __shfl_xor(ssq[e], o, 64);
+            }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                red[((wave * CPR + lane) * CH + e) * 2 + 0] = ssum[e];
+                red[((wave * CPR + lane) * CH + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        // CPR <= 32: chunk column ck sits in lane ck of every wave; thread t finalises (channel, which) = (t>>1, t&1)
+        static_assert(CPR <= 32, "statistics reduction assumes at most 32 chunks per tile row");
+        for (int t = tid; t < CT * 2; t += 256) {
+            const int ch = t >> 1, which = t & 1;
+            const int ck = ch / CH, e = ch % CH;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += red[((w * CPR + ck) * CH + e) * 2 + which];
+            if (c0 + ch < d.Co)
+                unsafeAtomicAdd(p.stats + ((size_t)(tile % VINCE_STATS_REPLICAS) * d.Co + (c0 + ch)) * 2 + which, (double)s);
+        }
+    }
+}
 
 template <typename T, int CT, int KC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
@@ -170,115 +283,173 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> LDS [pixel][channel] as T -> coalesced 16-byte stores --------------------
-    constexpr int CRS = Smem<T, CT, KC>::CRS;
+    conv_epilogue<T, CT, Smem<T, CT, KC>::CRS>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (long reductions).  The K tile is 128 bytes per row and is filled by
+// `buffer_load_dwordx4 ... lds` (LDS-DMA): no staging VGPRs, no ds_write pass, loads of tile k+1 are in flight while
+// tile k feeds the matrix cores, one barrier per tile.  An LDS-DMA instruction writes wave-uniform-base + lane*16,
+// i.e. 8 rows x 128 B per wave instruction, so rows cannot be padded; bank conflicts of the ds_read_b128 fragment reads
+// are removed instead by an XOR swizzle applied on the SOURCE side: the lane that fills 16-byte slot `pos` of row R
+// fetches logical K chunk pos ^ ((R>>1)&7), and the fragment read of chunk c goes to slot c ^ ((R>>1)&7) -- 16
+// consecutive rows then cover all 16 slots of the 256-byte bank window.  Out-of-image taps and tile tails are zero
+// filled by the buffer descriptor's range check (offset forced past num_records).
+template <typename T, int CT>
+struct SmemD {
+    static constexpr int XB = PT * 128, WB = CT * 128, STAGE = XB + WB;
+    static constexpr int MAIN = 2 * STAGE;
+    static constexpr int CRS = CT * (int)sizeof(T) + 16;
+    static constexpr int EPI = PT * CRS + 4 * CT * 2 * 4;
+    static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(4))) int v4i_t;
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from (descriptor, per-lane byte offset) to LDS[m0 + lane*16].
+// Issued through inline asm so that hipcc neither tracks it (it would wait vmcnt(0) before every later ds_read of
+// the same __shared__ array, serialising load and compute) nor reuses M0 across it; the caller owns the waits:
+// s_waitcnt vmcnt(N) + barrier before any wave reads the destination.
+__device__ __forceinline__ void lds_dma16(uint32_t lds_addr_uniform, uint32_t voff, v4i_t rsrc) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr_uniform), "v"(voff), "s"(rsrc)
+        : "memory");
+}
+
+__device__ __forceinline__ v4i_t make_rsrc(const void* ptr, uint32_t bytes) {
+    const uint64_t a = (uint64_t)ptr;
+    v4i_t r;
+    r[0] = (int)(uint32_t)a;
+    r[1] = (int)(uint32_t)(a >> 32);      // stride 0
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+
+template <typename T, int CT>
+__global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p) {
+    constexpr int CH = Elem<T>::CH;
+    constexpr int CJ = CT / 64;
+    constexpr int XROWS = PT / 32, WROWS = CT / 32;
+    using S = SmemD<T, CT>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave & 1, wp = wave >> 1;
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int ptile = tile / p.ctiles, ctile = tile - ptile * p.ctiles;
+    const int p0 = ptile * PT, c0 = ctile * CT;
+    const vince_conv_desc& d = p.d;
+    constexpr uint32_t OOB = 0xfffffff0u;
+
+    const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
+    const v4i_t rsrc_w = make_rsrc(p.w, p.w_bytes);
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+
+    // lane -> (row r + 32e, slot cpos); the logical K chunk it fetches is cpos ^ ((r>>1)&7) for every e
+    const int cpos = tid & 7, r = tid >> 3;
+    const int c_log = cpos ^ ((r >> 1) & 7);
+    int hb[XROWS], wb[XROWS];
+    uint32_t nb[XROWS];
+    bool rv[XROWS];
+#pragma unroll
+    for (int e = 0; e < XROWS; ++e) {
+        uint32_t m = p0 + r + e * 32;
+        rv[e] = m < (uint32_t)p.M;
+        uint32_t mm = rv[e] ? m : 0;
+        uint32_t n = fastdiv(mm, p.div_howo);
+        uint32_t rem = mm - n * p.div_howo.d;
+        uint32_t ho = fastdiv(rem, p.div_wo);
+        uint32_t wo = rem - ho * p.div_wo.d;
+        hb[e] = ho * d.sh;
+        wb[e] = wo * d.sw;
+        nb[e] = n * (uint32_t)(d.Hi * d.Wi);
+    }
+
+    auto issue_tile = [&](int kt, int buf) {
+        const int q = kt * 8 + c_log;
+        const int tap = q >> p.log2_cpt, cc = q & p.cpt_mask;
+        const int a = (int)(((uint32_t)tap * p.tb_mul) >> 16), b = tap - a * d.TB;
+        const int dh = d.dh0 + a * d.dhs, dw = d.dw0 + b * d.dws;
+        const int widx = d.wt0 + a * d.wta + b * d.wtb;
+        const bool qv = q < p.total_chunks;
+        const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
+        const uint32_t ws = xs + S::XB;
+#pragma unroll
+        for (int e = 0; e < XROWS; ++e) {
+            const int hi = hb[e] + dh, wi = wb[e] + dw;
+            const bool ok = rv[e] && qv && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
+            const uint32_t off = ok ? ((nb[e] + (uint32_t)(hi * d.Wi + wi)) * (uint32_t)d.Ci + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
+            lds_dma16(xs + e * 4096, off, rsrc_x);
+        }
+#pragma unroll
+        for (int e = 0; e < WROWS; ++e) {
+            const int co = c0 + r + e * 32;
+            const bool ok = qv && co < d.Co;
+            const uint32_t off = ok ? (((uint32_t)co * (uint32_t)d.WT + (uint32_t)widx) * (uint32_t)d.Ci + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
+            lds_dma16(ws + e * 4096, off, rsrc_w);
+        }
+    };
+
+    f32x16_t acc[CJ][2];
 #pragma unroll
     for (int j = 0; j < CJ; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pix = wp * 64 + i * 32 + (lane & 31);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch = wc * (CT / 2) + j * 32 + 8 * g + 4 * (lane >> 5);
-                unsigned char* dst = smem + pix * CRS + ch * (int)sizeof(T);
-                if constexpr (sizeof(T) == 4) {
-                    *(float4*)dst = make_float4(acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2],
-                                                acc[j][i][4 * g + 3]);
-                } else {
-                    *(uint2*)dst = make_uint2(pack_bf16x2(acc[j][i][4 * g], acc[j][i][4 * g + 1]),
-                                              pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]));
-                }
-            }
-        }
-    __syncthreads();
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
-    constexpr int CPR = CT * (int)sizeof(T) / 16;   // 16-byte chunks per tile row
-    constexpr int RPP = 256 / CPR;                  // rows per pass
-    const int chunk = tid % CPR, row0 = tid / CPR;
-    const int cbase = c0 + chunk * CH;
-    const bool cvalid = cbase < d.Co;
-    float bias_v[CH];
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int sw = ((lane & 31) >> 1) & 7, khalf = lane >> 5;
+    const int row_off = (lane & 31) * 128;
+    for (int kt = 0; kt < p.nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < p.nkt) issue_tile(kt + 1, buf ^ 1);
+        const unsigned char* xs = smem + buf * S::STAGE + (wp * 64) * 128 + row_off;
+        const unsigned char* ws = smem + buf * S::STAGE + S::XB + (wc * (CT / 2)) * 128 + row_off;
 #pragma unroll
-    for (int e = 0; e < CH; ++e) bias_v[e] = (p.bias && cvalid) ? p.bias[cbase + e] : 0.f;
-    float ssum[CH], ssq[CH];
+        for (int s = 0; s < 4; ++s) {
+            const int slot = ((s * 2 + khalf) ^ sw) * 16;
+            uint4 wf[CJ], xf[2];
 #pragma unroll
-    for (int e = 0; e < CH; ++e) ssum[e] = ssq[e] = 0.f;
-    T* __restrict__ out = (T*)p.out;
-    const bool identity_map = (d.osh == 1 && d.osw == 1 && d.oh0 == 0 && d.ow0 == 0 && d.OH == d.Ho && d.OW == d.Wo);
-    for (int row = row0; row < PT; row += RPP) {
-        const uint32_t m = p0 + row;
-        if (m >= (uint32_t)p.M || !cvalid) continue;
-        size_t opix = m;
-        if (!identity_map) {
-            uint32_t n = fastdiv(m, p.div_howo);
-            uint32_t rem = m - n * p.div_howo.d;
-            uint32_t ho = fastdiv(rem, p.div_wo);
-            uint32_t wo = rem - ho * p.div_wo.d;
-            opix = ((size_t)n * d.OH + (ho * d.osh + d.oh0)) * d.OW + (wo * d.osw + d.ow0);
+            for (int j = 0; j < CJ; ++j) wf[j] = *(const uint4*)(ws + j * 32 * 128 + slot);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xf[i] = *(const uint4*)(xs + i * 32 * 128 + slot);
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
         }
-        uint4 v = *(const uint4*)(smem + row * CRS + chunk * 16);
-        T* optr = out + opix * d.Co + cbase;
-        if (p.bias || (p.flags & (VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU))) {
-            float f[CH];
-            Chunk<T>::unpack(v, f);
-#pragma unroll
-            for (int e = 0; e < CH; ++e) f[e] += bias_v[e];
-            if (p.flags & VINCE_EPI_ACCUMULATE) {
-                float o[CH];
-                Chunk<T>::unpack(*(const uint4*)optr, o);
-#pragma unroll
-                for (int e = 0; e < CH; ++e) f[e] += o[e];
-            }
-            if (p.flags & VINCE_EPI_RELU) {
-#pragma unroll
-                for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
-            }
-            v = Chunk<T>::pack(f);
-        }
-        *(uint4*)optr = v;
-        if (p.stats) {
-            float f[CH];
-            Chunk<T>::unpack(v, f);
-#pragma unroll
-            for (int e = 0; e < CH; ++e) { ssum[e] += f[e]; ssq[e] += f[e] * f[e]; }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt+1 has landed ...
+        __syncthreads();                                    // ... and so has everybody else's; reads of tile kt are done
     }
-    if (p.stats) {   // uniform branch
-        float* red = (float*)(smem + PT * CRS);      // [4 waves][CPR][CH][2]
-#pragma unroll
-        for (int e = 0; e < CH; ++e) {
-#pragma unroll
-            for (int o = CPR; o < 64; o <<= 1) {
-                ssum[e] += __shfl_xor(ssum[e], o, 64);
-                ssq[e] += __shfl_xor(ssq[e], o, 64);
-            }
-        }
-        if (lane < CPR) {
-#pragma unroll
-            for (int e = 0; e < CH; ++e) {
-                red[((wave * CPR + lane) * CH + e) * 2 + 0] = ssum[e];
-                red[((wave * CPR + lane) * CH + e) * 2 + 1] = ssq[e];
-            }
-        }
-        __syncthreads();
-        // CPR <= 32: chunk column ck sits in lane ck of every wave; thread t finalises (channel, which) = (t>>1, t&1)
-        static_assert(CPR <= 32, "statistics reduction assumes at most 32 chunks per tile row");
-        for (int t = tid; t < CT * 2; t += 256) {
-            const int ch = t >> 1, which = t & 1;
-            const int ck = ch / CH, e = ch % CH;
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) s += red[((w * CPR + ck) * CH + e) * 2 + which];
-            if (c0 + ch < d.Co)
-                unsafeAtomicAdd(p.stats + ((size_t)(tile % VINCE_STATS_REPLICAS) * d.Co + (c0 + ch)) * 2 + which, (double)s);
-        }
-    }
+    conv_epilogue<T, CT, S::CRS>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
 template <typename T, int CT>
 int launch(ConvParams& p, hipStream_t stream) {
+    static int dlds_min_k = getenv("VINCE_DLDS_MIN_K") ? atoi(getenv("VINCE_DLDS_MIN_K")) : 512;
+    const int k_elems = p.total_chunks * (16 / (int)sizeof(T));
+    if (p.in_bytes && p.w_bytes && k_elems >= dlds_min_k) {
+        p.nkt = (p.total_chunks + 7) / 8;
+        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+        VINCE_CHECK_LAUNCH();
+        return VINCE_OK;
+    }
     // K tile = 128 bytes per row (8 chunks) when the reduction is long enough to pipeline, else 64 bytes
-    if (p.total_chunks * (16 / (int)sizeof(T)) >= 1024) {   // K >= 1024 elements
+    if (k_elems >= 1024) {
         p.nkt = (p.total_chunks + 7) / 8;
         hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 8>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
     } else {
@@ -327,6 +498,12 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.div_howo = make_fastdiv((uint32_t)(d.Ho * d.Wo));
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.w = w; p.out = out; p.bias = bias; p.stats = stats; p.flags = flags;
+    {
+        const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;
+        const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * d.Ci * esz, wb = (unsigned long long)d.Co * d.WT * d.Ci * esz;
+        p.in_bytes = ib < 0xfffffff0ull ? (uint32_t)ib : 0;
+        p.w_bytes = wb < 0xfffffff0ull ? (uint32_t)wb : 0;
+    }
     p.ptiles = (p.M + PT - 1) / PT;
     const bool narrow = d.Co <= 64;
     const int CT = narrow ? 64 : 128;
