@@ -106,22 +106,28 @@ int vince_bn_finalize(const double* stats, int64_t count, int32_t C, const float
                       float eps, int train, float* scale, float* shift, float* save_mean, float* save_invstd,
                       void* stream);
 
-/* out = [relu]( y*scale + shift + (identity ? (id_scale ? identity*id_scale + id_shift : identity) : 0) ) */
+/* out = [relu]( y*scale + shift + (identity ? (id_scale ? identity*id_scale + id_shift : identity) : 0) ).
+ * mask_out (optional): one byte per 16-byte chunk of `out` (8 bf16 / 4 f32 channels), bit e = pre-ReLU value e > 0 --
+ * the ReLU mask backward needs, at 1/16 of the bytes of re-reading the activation. */
 int vince_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* identity,
-                   const float* id_scale, const float* id_shift, void* out, int64_t rows, int32_t C, int relu,
-                   void* stream);
+                   const float* id_scale, const float* id_shift, void* out, uint8_t* mask_out, int64_t rows, int32_t C,
+                   int relu, void* stream);
 
-/* Backward pass 1: g = dz * (mask_src > 0 if mask_src else 1);  sums[c] += (sum g, sum g*xhat),
- * xhat = (y - mean)*invstd.  sums is double[R][C][2], zeroed by the caller. */
-int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_src, const void* y, const float* mean,
-                        const float* invstd, double* sums, int64_t rows, int32_t C, void* stream);
+/* Backward pass 1: g = dz * relu_mask;  sums[c] += (sum g, sum g*xhat), xhat = (y - mean)*invstd.
+ * relu_mask comes from (first non-NULL wins) mask_bits (bytes written by vince_bn_apply), mask_scale/mask_shift
+ * (sign of y*scale+shift, recomputed from y: plain BN+ReLU), mask_src (sign of a materialised activation), else 1.
+ * sums is double[R][C][2], zeroed by the caller. */
+int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_src, const uint8_t* mask_bits, const float* mask_scale,
+                        const float* mask_shift, const void* y, const float* mean, const float* invstd, double* sums,
+                        int64_t rows, int32_t C, void* stream);
 
 /* Backward pass 2: dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count); optional g_out = g (the
  * residual branch's gradient); dgamma += sum_gx, dbeta += sum_g (float[C]).  `sums` (the R replicas written by
  * vince_bn_bwd_reduce) is folded in place into replica 0 first, hence not const in effect. */
-int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_src, const void* y, const float* mean,
-                       const float* invstd, const float* gamma, const double* sums, int64_t count, void* dy,
-                       void* g_out, float* dgamma, float* dbeta, int64_t rows, int32_t C, void* stream);
+int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_src, const uint8_t* mask_bits, const float* mask_scale,
+                       const float* mask_shift, const void* y, const float* mean, const float* invstd, const float* gamma,
+                       const double* sums, int64_t count, void* dy, void* g_out, float* dgamma, float* dbeta, int64_t rows,
+                       int32_t C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pooling (K6 MaxPool2d 3x3/s2/p1 resnet.py:173, fused with the stem's BN-apply + ReLU; K7 AdaptiveAvgPool2d

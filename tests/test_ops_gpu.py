@@ -202,6 +202,37 @@ def test_bn_train_fwd_bwd(C, shape, dtype):
     assert_close(from_nhwc(g), idn.grad, dtype, what="residual g")
     assert_close(dgam, gamma.grad, dtype, f32=1e-4, bf16=3e-2, what="dgamma")
     assert_close(dbet, beta.grad, dtype, f32=1e-4, bf16=3e-2, what="dbeta")
+    # the production path reads the ReLU mask as 1 byte per 16-byte chunk written by bn_apply: identical results
+    zg2, bits = ops.bn_apply(yg, consts[0], consts[1], identity=to_nhwc(idn.detach(), dtype), relu=True, want_mask=True)
+    assert torch.equal(zg2, zg)
+    dgam2, dbet2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dy2, g2 = ops.bn_bwd(to_nhwc(dz, dtype), None, yg, consts[2], consts[3], gamma.detach().to(DEV), dgam2, dbet2, want_g=True,
+                         mask_bits=bits)
+    assert torch.equal(dy2, dy) and torch.equal(g2, g)
+    torch.testing.assert_close(dgam2, dgam, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_bwd_mask_recomputed_from_y(dtype):
+    """Plain BN+ReLU (no residual): the mask is the sign of y*scale+shift, recomputed from the conv output."""
+    ops = _ops()
+    N, C, H, W = 3, 128, 6, 5
+    y = q(rnd(N, C, H, W, seed=60) * 1.3 - 0.2, dtype).requires_grad_(True)
+    gamma = (1 + 0.2 * rnd(C, seed=61)).requires_grad_(True)
+    beta = (0.2 * rnd(C, seed=62)).requires_grad_(True)
+    a = F.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5))
+    dz = q(rnd(N, C, H, W, seed=63), dtype)
+    a.backward(dz)
+    yg = to_nhwc(y.detach(), dtype)
+    yy = yg.float().reshape(-1, C).double()
+    stats = torch.zeros(ops.STATS_REPLICAS, C, 2, device=DEV, dtype=torch.float64)
+    stats[0] = torch.stack([yy.sum(0), (yy * yy).sum(0)], 1)
+    consts = ops.bn_finalize(stats, N * H * W, gamma.detach().to(DEV), beta.detach().to(DEV), None, None, None, True)
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dy, _ = ops.bn_bwd(to_nhwc(dz, dtype), None, yg, consts[2], consts[3], gamma.detach().to(DEV), dgam, dbet,
+                       mask_scale=consts[0], mask_shift=consts[1])
+    assert_close(from_nhwc(dy), y.grad, dtype, f32=1e-4, bf16=3e-2, what="bn dy (mask from y)")
+    assert_close(dgam, gamma.grad, dtype, f32=1e-4, bf16=3e-2, what="dgamma")
 
 
 def test_bn_eval_and_downsample_identity():

@@ -40,6 +40,36 @@ inline RowWalk make_rowwalk(int64_t rows, int C, int CH, int target_blocks = 204
     return w;
 }
 
+
+// How the backward kernels obtain the ReLU mask of the activation that followed this BatchNorm:
+//   bits  : 1 byte per 16-byte chunk written by bn_apply (bit e = output e > 0)  -- residual outputs
+//   from y: sign of y*scale + shift recomputed from the conv output that is read anyway -- plain BN+ReLU
+//   src   : sign of a materialised activation tensor (2 bytes / element; legacy, tests)
+struct MaskArgs {
+    const void* src;
+    const uint8_t* bits;
+    const float* scale;
+    const float* shift;
+};
+
+template <typename T, int CH>
+__device__ __forceinline__ void apply_mask(const MaskArgs& ma, size_t off, size_t chunk_index, const float (&yy)[CH],
+                                           const float (&msc)[CH], const float (&msh)[CH], float (&g)[CH]) {
+    if (ma.bits) {
+        const uint32_t b = ma.bits[chunk_index];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) g[e] = ((b >> e) & 1u) ? g[e] : 0.f;
+    } else if (ma.scale) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) g[e] = (yy[e] * msc[e] + msh[e]) > 0.f ? g[e] : 0.f;
+    } else if (ma.src) {
+        float m[CH];
+        Chunk<T>::unpack(*(const uint4*)((const T*)ma.src + off), m);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+    }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, int C, const float* gamma,
                                    const float* beta, float* rmean, float* rvar, int64_t* nbt, float momentum,
                                    float eps, int train, float* scale, float* shift, float* save_mean,
@@ -79,7 +109,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ idn,
                                                        const float* __restrict__ ids, const float* __restrict__ idt,
-                                                       T* __restrict__ out, int64_t rows, int C, int relu, RowWalk w) {
+                                                       T* __restrict__ out, uint8_t* __restrict__ mask_out, int64_t rows,
+                                                       int C, int relu, RowWalk w) {
     constexpr int CH = Elem<T>::CH;
     const int col = blockIdx.x * w.tpc + (threadIdx.x % w.tpc);
     if (col >= w.cpr) return;
@@ -105,6 +136,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
             for (int e = 0; e < CH; ++e) f[e] += g[e] * isc[e] + ish[e];
         }
+        if (mask_out) {
+            uint32_t b = 0;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
+            mask_out[(size_t)r * w.cpr + col] = (uint8_t)b;
+        }
         if (relu) {
 #pragma unroll
             for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
@@ -114,7 +151,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ msk,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const MaskArgs msk,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, double* sums,
                                                             int64_t rows, int C, RowWalk w) {
@@ -123,11 +160,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const int tc = threadIdx.x % w.tpc, tr = threadIdx.x / w.tpc;
     const int col = blockIdx.x * w.tpc + tc;
     const bool cv = col < w.cpr;
-    float mu[CH], is[CH], sg[CH], sgx[CH];
+    float mu[CH], is[CH], sg[CH], sgx[CH], msc[CH], msh[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
         mu[e] = cv ? mean[col * CH + e] : 0.f;
         is[e] = cv ? invstd[col * CH + e] : 0.f;
+        msc[e] = (cv && msk.scale) ? msk.scale[col * CH + e] : 0.f;
+        msh[e] = (cv && msk.scale) ? msk.shift[col * CH + e] : 0.f;
         sg[e] = sgx[e] = 0.f;
     }
     const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + tr;
@@ -138,12 +177,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             float g[CH], yy[CH];
             Chunk<T>::unpack(*(const uint4*)(dz + off), g);
             Chunk<T>::unpack(*(const uint4*)(y + off), yy);
-            if (msk) {
-                float m[CH];
-                Chunk<T>::unpack(*(const uint4*)(msk + off), m);
-#pragma unroll
-                for (int e = 0; e < CH; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
-            }
+            apply_mask<T, CH>(msk, off, (size_t)r * w.cpr + col, yy, msc, msh, g);
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
                 sg[e] += g[e];
@@ -185,7 +219,7 @@ __global__ void bn_bwd_fold_kernel(double* sums, int C, float* dgamma, float* db
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ msk,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const MaskArgs msk,
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
@@ -195,10 +229,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     constexpr int CH = Elem<T>::CH;
     const int col = blockIdx.x * w.tpc + (threadIdx.x % w.tpc);
     if (col >= w.cpr) return;
-    float mu[CH], is[CH], k1[CH], ma[CH], mb[CH];
+    float mu[CH], is[CH], k1[CH], ma[CH], mb[CH], msc[CH], msh[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
         const int c = col * CH + e;
+        msc[e] = msk.scale ? msk.scale[c] : 0.f;
+        msh[e] = msk.scale ? msk.shift[c] : 0.f;
         mu[e] = mean[c];
         is[e] = invstd[c];
         k1[e] = gamma[c] * is[e];
@@ -212,12 +248,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         float g[CH], yy[CH];
         Chunk<T>::unpack(*(const uint4*)(dz + off), g);
         Chunk<T>::unpack(*(const uint4*)(y + off), yy);
-        if (msk) {
-            float m[CH];
-            Chunk<T>::unpack(*(const uint4*)(msk + off), m);
-#pragma unroll
-            for (int e = 0; e < CH; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
-        }
+        apply_mask<T, CH>(msk, off, (size_t)r * w.cpr + col, yy, msc, msh, g);
         if (gout) *(uint4*)(gout + off) = Chunk<T>::pack(g);
         float o[CH];
 #pragma unroll
@@ -400,8 +431,8 @@ extern "C" int vince_bn_finalize(const double* stats, int64_t count, int32_t C, 
 }
 
 extern "C" int vince_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* identity,
-                              const float* id_scale, const float* id_shift, void* out, int64_t rows, int32_t C,
-                              int relu, void* stream) {
+                              const float* id_scale, const float* id_shift, void* out, uint8_t* mask_out, int64_t rows,
+                              int32_t C, int relu, void* stream) {
     DTYPE_OK("vince_bn_apply");
     VINCE_CHECK_ARG(y && scale && shift && out && rows > 0, VINCE_E_ARG, "vince_bn_apply: bad arguments");
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
@@ -409,16 +440,18 @@ extern "C" int vince_bn_apply(int dtype, const void* y, const float* scale, cons
     dim3 grid(w.colgroups, w.rowblocks);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, scale, shift,
-                           (const float*)identity, id_scale, id_shift, (float*)out, rows, C, relu, w);
+                           (const float*)identity, id_scale, id_shift, (float*)out, mask_out, rows, C, relu, w);
     else
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, scale,
-                           shift, (const bf16_t*)identity, id_scale, id_shift, (bf16_t*)out, rows, C, relu, w);
+                           shift, (const bf16_t*)identity, id_scale, id_shift, (bf16_t*)out, mask_out, rows, C, relu, w);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
 
-extern "C" int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_src, const void* y, const float* mean,
+extern "C" int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_src, const uint8_t* mask_bits,
+                                   const float* mask_scale, const float* mask_shift, const void* y, const float* mean,
                                    const float* invstd, double* sums, int64_t rows, int32_t C, void* stream) {
+    const MaskArgs msk{mask_src, mask_bits, mask_scale, mask_shift};
     DTYPE_OK("vince_bn_bwd_reduce");
     VINCE_CHECK_ARG(dz && y && mean && invstd && sums && rows > 0, VINCE_E_ARG, "vince_bn_bwd_reduce: bad arguments");
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_bwd_reduce: C=%d not a multiple of %d", C, CH_OF(dtype));
@@ -426,17 +459,19 @@ extern "C" int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_s
     dim3 grid(w.colgroups, w.rowblocks);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
-                           (const float*)mask_src, (const float*)y, mean, invstd, sums, rows, C, w);
+                           msk, (const float*)y, mean, invstd, sums, rows, C, w);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz,
-                           (const bf16_t*)mask_src, (const bf16_t*)y, mean, invstd, sums, rows, C, w);
+                           msk, (const bf16_t*)y, mean, invstd, sums, rows, C, w);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
 
-extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_src, const void* y, const float* mean,
+extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_src, const uint8_t* mask_bits,
+                                  const float* mask_scale, const float* mask_shift, const void* y, const float* mean,
                                   const float* invstd, const float* gamma, const double* sums, int64_t count, void* dy,
                                   void* g_out, float* dgamma, float* dbeta, int64_t rows, int32_t C, void* stream) {
+    const MaskArgs msk{mask_src, mask_bits, mask_scale, mask_shift};
     DTYPE_OK("vince_bn_bwd_apply");
     VINCE_CHECK_ARG(dz && y && mean && invstd && gamma && sums && dy && rows > 0 && count > 0, VINCE_E_ARG,
                     "vince_bn_bwd_apply: bad arguments");
@@ -448,11 +483,11 @@ extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_sr
                        dbeta);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
-                           (const float*)mask_src, (const float*)y, mean, invstd, gamma, sums, inv_count, (float*)dy,
+                           msk, (const float*)y, mean, invstd, gamma, sums, inv_count, (float*)dy,
                            (float*)g_out, dgamma, dbeta, rows, C, w);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz,
-                           (const bf16_t*)mask_src, (const bf16_t*)y, mean, invstd, gamma, sums, inv_count, (bf16_t*)dy,
+                           msk, (const bf16_t*)y, mean, invstd, gamma, sums, inv_count, (bf16_t*)dy,
                            (bf16_t*)g_out, dgamma, dbeta, rows, C, w);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;

@@ -36,7 +36,7 @@ struct Blk {
     bool has_ds;
     ConvL cd;
     BnL bd;
-    size_t x_in, y[3], a[2], yd, z;   // byte offsets in workspace
+    size_t x_in, y[3], a[2], yd, z, zmask;   // byte offsets in workspace (zmask: 1 byte per 16-B chunk of z)
 };
 
 constexpr size_t NONE = (size_t)-1;
@@ -229,6 +229,8 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
             }
             if (b.has_ds) b.yd = P.alloc_act((size_t)N * Ho * Wo * outp);
             b.z = P.alloc_act((size_t)N * Ho * Wo * outp);
+            b.zmask = P.ws;
+            P.ws = align_up(P.ws + (size_t)N * Ho * Wo * outp / t->CH);
             cur = b.z;
             inpl = outp; H = Ho; W = Wo;
             t->blocks.push_back(b);
@@ -335,14 +337,18 @@ int wgrad(Ctx& c, const ConvL& cv, const void* in, const void* dy, float* dw) {
     return vince_conv_wgrad(&d, c.dtype, in, dy, dw, cv.Ci, 0, c.stream);
 }
 
-// BN backward for y (conv output) given the gradient dz wrt the post-BN(+ReLU) activation `act` (mask source).
-int bn_bwd(Ctx& c, const BnL& bn, const void* dz, const void* mask_src, size_t y_off, int64_t rows, void* dy, void* g_out,
-           float* const* grads, bool reduce_done = false) {
-    if (!reduce_done)
-        RC(vince_bn_bwd_reduce(c.dtype, dz, mask_src, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3), c.sums(bn), rows, bn.C,
-                               c.stream));
-    RC(vince_bn_bwd_apply(c.dtype, dz, mask_src, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3), c.params[bn.gamma],
-                          c.sums(bn), rows, dy, g_out, grads[bn.gamma], grads[bn.beta], rows, bn.C, c.stream));
+// BN backward for y (conv output) given the gradient dz wrt the activation that followed this BatchNorm.
+// ReLU mask: `bits` (residual outputs: bytes written by the forward bn_apply), `self_mask` (plain BN+ReLU: the sign
+// of y*scale+shift is recomputed from y, which is read anyway), or none (no ReLU: the stem's pooled gradient).
+int bn_bwd(Ctx& c, const BnL& bn, const void* dz, const uint8_t* bits, bool self_mask, size_t y_off, int64_t rows, void* dy,
+           void* g_out, float* const* grads) {
+    const float* msc = self_mask ? c.consts(bn, 0) : nullptr;
+    const float* msh = self_mask ? c.consts(bn, 1) : nullptr;
+    RC(vince_bn_bwd_reduce(c.dtype, dz, nullptr, bits, msc, msh, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3), c.sums(bn),
+                           rows, bn.C, c.stream));
+    RC(vince_bn_bwd_apply(c.dtype, dz, nullptr, bits, msc, msh, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3),
+                          c.params[bn.gamma], c.sums(bn), rows, dy, g_out, grads[bn.gamma], grads[bn.beta], rows, bn.C,
+                          c.stream));
     return VINCE_OK;
 }
 
@@ -387,7 +393,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             if (ci < b.nconv - 1) {
                 const int64_t rows = (int64_t)N * b.c[ci].Ho * b.c[ci].Wo;
                 RC(vince_bn_apply(c.dtype, at(workspace, b.y[ci]), c.consts(b.b[ci], 0), c.consts(b.b[ci], 1), nullptr, nullptr,
-                                  nullptr, at(workspace, b.a[ci]), rows, b.c[ci].Co, 1, stream));
+                                  nullptr, at(workspace, b.a[ci]), nullptr, rows, b.c[ci].Co, 1, stream));
                 in = b.a[ci];
             }
         }
@@ -397,10 +403,11 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
         if (b.has_ds) {
             RC(conv_bn_fwd(c, b.cd, b.bd, b.x_in, b.yd, bn_running, bn_nbt, train_bn));
             RC(vince_bn_apply(c.dtype, at(workspace, b.y[b.nconv - 1]), c.consts(lbn, 0), c.consts(lbn, 1), at(workspace, b.yd),
-                              c.consts(b.bd, 0), c.consts(b.bd, 1), at(workspace, b.z), rows, last.Co, 1, stream));
+                              c.consts(b.bd, 0), c.consts(b.bd, 1), at(workspace, b.z), (uint8_t*)at(workspace, b.zmask), rows,
+                              last.Co, 1, stream));
         } else {
             RC(vince_bn_apply(c.dtype, at(workspace, b.y[b.nconv - 1]), c.consts(lbn, 0), c.consts(lbn, 1), at(workspace, b.x_in),
-                              nullptr, nullptr, at(workspace, b.z), rows, last.Co, 1, stream));
+                              nullptr, nullptr, at(workspace, b.z), (uint8_t*)at(workspace, b.zmask), rows, last.Co, 1, stream));
         }
     }
     RC(vince_avgpool_fwd(c.dtype, at(workspace, t->blocks.back().z), pooled, N, t->outH * t->outW, t->outC, stream));
@@ -424,16 +431,16 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         const int L = b.nconv - 1;
         const ConvL& last = b.c[L];
         const int64_t rows_out = (int64_t)N * last.Ho * last.Wo;
-        const void* z = at(workspace, b.z);
+        const uint8_t* zbits = (const uint8_t*)at(workspace, b.zmask);
         const void* x_in = at(workspace, b.x_in);
         // z = relu(bn_L(y_L) + identity): g = dz * (z > 0) is the gradient of both addends
         if (b.has_ds) {
-            RC(bn_bwd(c, b.bd, Z, z, b.yd, rows_out, DY, nullptr, grads));
+            RC(bn_bwd(c, b.bd, Z, zbits, false, b.yd, rows_out, DY, nullptr, grads));
             RC(wgrad(c, b.cd, x_in, DY, grads[b.cd.param]));
             RC(dgrad(c, b.cd, DY, DX, false));
-            RC(bn_bwd(c, b.b[L], Z, z, b.y[L], rows_out, DY, nullptr, grads));
+            RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, nullptr, grads));
         } else {
-            RC(bn_bwd(c, b.b[L], Z, z, b.y[L], rows_out, DY, DX, grads));   // DX <- g (identity branch)
+            RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, DX, grads));   // DX <- g (identity branch)
         }
         for (int ci = L; ci >= 0; --ci) {
             const void* in_act = ci == 0 ? x_in : at(workspace, b.a[ci - 1]);
@@ -441,7 +448,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             if (ci > 0) {
                 RC(dgrad(c, b.c[ci], DY, DA, false));
                 const int64_t rows = (int64_t)N * b.c[ci - 1].Ho * b.c[ci - 1].Wo;
-                RC(bn_bwd(c, b.b[ci - 1], DA, at(workspace, b.a[ci - 1]), b.y[ci - 1], rows, DY, nullptr, grads));
+                RC(bn_bwd(c, b.b[ci - 1], DA, nullptr, true, b.y[ci - 1], rows, DY, nullptr, grads));
             } else {
                 RC(dgrad(c, b.c[0], DY, DX, true));
             }
@@ -453,7 +460,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     }
     // stem: Z = gradient wrt the pooled stem output
     RC(vince_stem_pool_bwd(c.dtype, Z, (const uint8_t*)at(workspace, t->off_amax), DA, N, t->sH, t->sW, 64, stream));
-    RC(bn_bwd(c, t->stem_bn, DA, nullptr, t->off_ystem, (int64_t)N * t->sH * t->sW, DY, nullptr, grads));
+    RC(bn_bwd(c, t->stem_bn, DA, nullptr, false, t->off_ystem, (int64_t)N * t->sH * t->sW, DY, nullptr, grads));
     {
         vince_conv_desc d = fwd_desc(t, t->stem);
         RC(vince_conv_wgrad(&d, c.dtype, at(workspace, t->off_x0), DY, grads[t->stem.param], 3, 0, stream));

@@ -151,26 +151,30 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, nbt, train
     return consts  # scale, shift, mean, invstd
 
 
-def bn_apply(y, scale, shift, identity=None, id_scale=None, id_shift=None, relu=True):
+def bn_apply(y, scale, shift, identity=None, id_scale=None, id_shift=None, relu=True, want_mask=False):
     require_gpu(y, scale, shift, identity, id_scale, id_shift)
     out = torch.empty_like(y)
     C = y.shape[-1]
+    ch = 4 if y.dtype == torch.float32 else 8
+    mask = torch.empty(y.numel() // ch, device=y.device, dtype=torch.uint8) if want_mask else None
     check(lib().vince_bn_apply(dtype_code(y), _ptr(y), _ptr(scale), _ptr(shift), _ptr(identity), _ptr(id_scale),
-                               _ptr(id_shift), _ptr(out), y.numel() // C, C, int(relu), stream_ptr()))
-    return out
+                               _ptr(id_shift), _ptr(out), _ptr(mask), y.numel() // C, C, int(relu), stream_ptr()))
+    return (out, mask) if want_mask else out
 
 
-def bn_bwd(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, want_g=False):
-    require_gpu(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta)
+def bn_bwd(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, want_g=False, mask_bits=None, mask_scale=None,
+           mask_shift=None):
+    require_gpu(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, mask_bits, mask_scale, mask_shift)
     C = y.shape[-1]
     rows = y.numel() // C
     sums = torch.zeros(STATS_REPLICAS, C, 2, device=y.device, dtype=torch.float64)
-    check(lib().vince_bn_bwd_reduce(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums),
-                                    rows, C, stream_ptr()))
+    check(lib().vince_bn_bwd_reduce(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(mask_bits), _ptr(mask_scale),
+                                    _ptr(mask_shift), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums), rows, C, stream_ptr()))
     dy = torch.empty_like(y)
     g = torch.empty_like(y) if want_g else None
-    check(lib().vince_bn_bwd_apply(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
-                                   _ptr(sums), rows, _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), rows, C, stream_ptr()))
+    check(lib().vince_bn_bwd_apply(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(mask_bits), _ptr(mask_scale),
+                                   _ptr(mask_shift), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), rows,
+                                   _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), rows, C, stream_ptr()))
     return dy, g
 
 
