@@ -296,10 +296,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // fetches logical K chunk pos ^ ((R>>1)&7), and the fragment read of chunk c goes to slot c ^ ((R>>1)&7) -- 16
 // consecutive rows then cover all 16 slots of the 256-byte bank window.  Out-of-image taps and tile tails are zero
 // filled by the buffer descriptor's range check (offset forced past num_records).
-template <typename T, int CT>
+template <typename T, int CT, int KC, int STAGES>
 struct SmemD {
-    static constexpr int XB = PT * 128, WB = CT * 128, STAGE = XB + WB;
-    static constexpr int MAIN = 2 * STAGE;
+    static constexpr int KB = KC * 16;                       // bytes of K per row per stage
+    static constexpr int XB = PT * KB, WB = CT * KB, STAGE = XB + WB;
+    static constexpr int MAIN = STAGES * STAGE;
     static constexpr int CRS = CT * (int)sizeof(T) + 16;
     static constexpr int EPI = PT * CRS + 4 * CT * 2 * 4;
     static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
@@ -335,12 +336,31 @@ __device__ __forceinline__ v4i_t make_rsrc(const void* ptr, uint32_t bytes) {
     return r;
 }
 
-template <typename T, int CT>
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "add the vmcnt literal");
+}
+
+// K tile = KC 16-byte chunks per row; STAGES-deep LDS ring, prefetch distance STAGES-1 tiles, counted vmcnt so that the
+// younger tiles stay in flight across the barrier (one barrier per K tile).
+template <typename T, int CT, int KC, int STAGES>
 __global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64;
-    constexpr int XROWS = PT / 32, WROWS = CT / 32;
-    using S = SmemD<T, CT>;
+    using S = SmemD<T, CT, KC, STAGES>;
+    constexpr int KB = S::KB;
+    constexpr int RPW = 1024 / KB;                 // rows per wave DMA instruction (8 or 16)
+    constexpr int RPP = 4 * RPW;                   // rows per pass of the 4 waves
+    constexpr int XROWS = PT / RPP, WROWS = CT / RPP;
+    constexpr int PER_STAGE = XROWS + WROWS;       // DMA instructions per thread per stage
+    constexpr int SWSH = KC == 8 ? 1 : 2, SWMASK = KC - 1;   // slot swizzle = (row >> SWSH) & SWMASK
     __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -356,15 +376,15 @@ __global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p
     const v4i_t rsrc_w = make_rsrc(p.w, p.w_bytes);
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
 
-    // lane -> (row r + 32e, slot cpos); the logical K chunk it fetches is cpos ^ ((r>>1)&7) for every e
-    const int cpos = tid & 7, r = tid >> 3;
-    const int c_log = cpos ^ ((r >> 1) & 7);
+    // lane -> (row r + RPP*e, slot cpos); the logical K chunk it fetches is cpos ^ swizzle(r), the same for every e
+    const int cpos = tid % KC, r = tid / KC;
+    const int c_log = cpos ^ ((r >> SWSH) & SWMASK);
     int hb[XROWS], wb[XROWS];
     uint32_t nb[XROWS];
     bool rv[XROWS];
 #pragma unroll
     for (int e = 0; e < XROWS; ++e) {
-        uint32_t m = p0 + r + e * 32;
+        uint32_t m = p0 + r + e * RPP;
         rv[e] = m < (uint32_t)p.M;
         uint32_t mm = rv[e] ? m : 0;
         uint32_t n = fastdiv(mm, p.div_howo);
@@ -377,12 +397,12 @@ __global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p
     }
 
     auto issue_tile = [&](int kt, int buf) {
-        const int q = kt * 8 + c_log;
+        const int q = kt * KC + c_log;
         const int tap = q >> p.log2_cpt, cc = q & p.cpt_mask;
         const int a = (int)(((uint32_t)tap * p.tb_mul) >> 16), b = tap - a * d.TB;
         const int dh = d.dh0 + a * d.dhs, dw = d.dw0 + b * d.dws;
         const int widx = d.wt0 + a * d.wta + b * d.wtb;
-        const bool qv = q < p.total_chunks;
+        const bool qv = q < p.total_chunks;       // also false for kt >= nkt: the whole tile is zero filled
         const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
         const uint32_t ws = xs + S::XB;
 #pragma unroll
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p
         }
 #pragma unroll
         for (int e = 0; e < WROWS; ++e) {
-            const int co = c0 + r + e * 32;
+            const int co = c0 + r + e * RPP;
             const bool ok = qv && co < d.Co;
             const uint32_t off = ok ? (((uint32_t)co * (uint32_t)d.WT + (uint32_t)widx) * (uint32_t)d.Ci + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
             lds_dma16(ws + e * 4096, off, rsrc_w);
@@ -409,42 +429,65 @@ __global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
-    issue_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int sw = ((lane & 31) >> 1) & 7, khalf = lane >> 5;
-    const int row_off = (lane & 31) * 128;
-    for (int kt = 0; kt < p.nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < p.nkt) issue_tile(kt + 1, buf ^ 1);
-        const unsigned char* xs = smem + buf * S::STAGE + (wp * 64) * 128 + row_off;
-        const unsigned char* ws = smem + buf * S::STAGE + S::XB + (wc * (CT / 2)) * 128 + row_off;
+    // prologue: STAGES-1 tiles in flight (tiles past the end are issued as all-zero fills so the counts stay uniform)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+    for (int st = 0; st < STAGES - 1; ++st) issue_tile(st, st);
+    wait_vmcnt<(STAGES - 2) * PER_STAGE>();
+    __syncthreads();
+    const int sw = ((lane & 31) >> SWSH) & SWMASK, khalf = lane >> 5;
+    const int row_off = (lane & 31) * KB;
+    int buf = 0, nbuf = STAGES - 1;
+    for (int kt = 0; kt < p.nkt; ++kt) {
+        issue_tile(kt + STAGES - 1, nbuf);
+        const unsigned char* xs = smem + buf * S::STAGE + (wp * 64) * KB + row_off;
+        const unsigned char* ws = smem + buf * S::STAGE + S::XB + (wc * (CT / 2)) * KB + row_off;
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
             const int slot = ((s * 2 + khalf) ^ sw) * 16;
             uint4 wf[CJ], xf[2];
 #pragma unroll
-            for (int j = 0; j < CJ; ++j) wf[j] = *(const uint4*)(ws + j * 32 * 128 + slot);
+            for (int j = 0; j < CJ; ++j) wf[j] = *(const uint4*)(ws + j * 32 * KB + slot);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) xf[i] = *(const uint4*)(xs + i * 32 * 128 + slot);
+            for (int i = 0; i < 2; ++i) xf[i] = *(const uint4*)(xs + i * 32 * KB + slot);
 #pragma unroll
             for (int j = 0; j < CJ; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt+1 has landed ...
-        __syncthreads();                                    // ... and so has everybody else's; reads of tile kt are done
+        // tile kt+1 must have landed (this wave's share; the barrier extends it to all waves); the STAGES-2 younger
+        // tiles stay in flight across the barrier
+        wait_vmcnt<(STAGES - 2) * PER_STAGE>();
+        __syncthreads();
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
     }
+    wait_vmcnt<0>();
+    __syncthreads();
     conv_epilogue<T, CT, S::CRS>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
 template <typename T, int CT>
 int launch(ConvParams& p, hipStream_t stream) {
-    static int dlds_min_k = getenv("VINCE_DLDS_MIN_K") ? atoi(getenv("VINCE_DLDS_MIN_K")) : 512;
+    static int dlds_min_k = getenv("VINCE_DLDS_MIN_K") ? atoi(getenv("VINCE_DLDS_MIN_K")) : 0;
     const int k_elems = p.total_chunks * (16 / (int)sizeof(T));
+    // ring configuration: 1 = 64-byte K rows x 3 stages (48 KB, 3 workgroups/CU; best overall on MI355X),
+    // 0 = 128-byte rows x 2 stages, 2 = 64-byte rows x 4 stages, 3 = 128-byte rows x 3 stages
+    static int dlds_cfg = getenv("VINCE_DLDS_CFG") ? atoi(getenv("VINCE_DLDS_CFG")) : 1;
     if (p.in_bytes && p.w_bytes && k_elems >= dlds_min_k) {
-        p.nkt = (p.total_chunks + 7) / 8;
-        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+        const dim3 grid(p.ptiles * p.ctiles);
+        if (dlds_cfg == 0) {
+            p.nkt = (p.total_chunks + 7) / 8;
+            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 2>), grid, dim3(256), 0, stream, p);
+        } else if (dlds_cfg == 1) {
+            p.nkt = (p.total_chunks + 3) / 4;
+            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3>), grid, dim3(256), 0, stream, p);
+        } else if (dlds_cfg == 2) {
+            p.nkt = (p.total_chunks + 3) / 4;
+            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 4>), grid, dim3(256), 0, stream, p);
+        } else {
+            p.nkt = (p.total_chunks + 7) / 8;
+            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 3>), grid, dim3(256), 0, stream, p);
+        }
         VINCE_CHECK_LAUNCH();
         return VINCE_OK;
     }

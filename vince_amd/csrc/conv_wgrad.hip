@@ -11,6 +11,8 @@
 // ds_read_b64_tr_b16 (bf16) or with conflict-free ds_read_b32 (f32: one k per lane per v_mfma_f32_32x32x2_f32).
 // Work split: (Co tile) x (tap*Ci tile) x (split of the pixel range); partial tiles are accumulated with
 // fp32 atomics straight into the gradient buffer (rows of 32 consecutive floats per wave instruction).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -224,9 +226,12 @@ int dispatch(WgradParams& p, hipStream_t stream) {
     p.ctiles = (d.Co + CT - 1) / CT;
     p.ntiles = (ntot + NT - 1) / NT;
     p.nkt_total = (p.M + KP - 1) / KP;
-    // enough workgroups to fill 256 CUs a few times over, but at least 8 K-tiles (256 pixels) per split
+    // Split the pixel range so that the grid is about one resident wave of workgroups (256 CUs x 2): every extra split
+    // costs Co*T*Ci fp32 atomics in the epilogue, and the L2 atomic rate -- not MFMA -- bounds this kernel when the grid
+    // is cut 3x finer.  At least 8 K-tiles per split.
+    static int target_blocks = getenv("VINCE_WGRAD_BLOCKS") ? atoi(getenv("VINCE_WGRAD_BLOCKS")) : 512;
     const int tiles = p.ctiles * p.ntiles;
-    int splits = (1536 + tiles - 1) / tiles;
+    int splits = (target_blocks + tiles - 1) / tiles;
     const int max_splits = (p.nkt_total + 7) / 8;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
