@@ -27,7 +27,7 @@ namespace {
 
 struct ConvParams {
     vince_conv_desc d;
-    int log2_cpt, cpt_mask, total_chunks, nkt, M, ptiles, ctiles;
+    int log2_cpt, cpt_mask, total_chunks, nkt, M, ptiles, ctiles, uniform_taps;
     uint32_t tb_mul;
     FastDiv div_howo, div_wo;
     const void* in;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p
     const int ptile = tile / p.ctiles, ctile = tile - ptile * p.ctiles;
     const int p0 = ptile * PT, c0 = ctile * CT;
     const vince_conv_desc& d = p.d;
-    constexpr uint32_t OOB = 0xfffffff0u;
+    constexpr uint32_t OOB = 0x80000000u;   // descriptors cover < 2 GiB, so this (and small increments of it) reads as zero
 
     const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
     const v4i_t rsrc_w = make_rsrc(p.w, p.w_bytes);
@@ -396,29 +396,51 @@ __global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p
         nb[e] = n * (uint32_t)(d.Hi * d.Wi);
     }
 
-    auto issue_tile = [&](int kt, int buf) {
-        const int q = kt * KC + c_log;
+    // Per-lane byte offsets of the current K tile.  When a tap spans a whole number of K tiles (Ci*sizeof(T) multiple of
+    // the tile width: every layer but the stem) all lanes change tap together, so between tap changes a K step is just
+    // "offset += KB" -- the address arithmetic (tap decode, bounds tests, multiplies) runs once per tap, not per tile.
+    uint32_t offx[XROWS], offw[WROWS];
+    int cur_tap = -1;
+    auto compute_offsets = [&](int q) {
         const int tap = q >> p.log2_cpt, cc = q & p.cpt_mask;
         const int a = (int)(((uint32_t)tap * p.tb_mul) >> 16), b = tap - a * d.TB;
         const int dh = d.dh0 + a * d.dhs, dw = d.dw0 + b * d.dws;
         const int widx = d.wt0 + a * d.wta + b * d.wtb;
         const bool qv = q < p.total_chunks;       // also false for kt >= nkt: the whole tile is zero filled
-        const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
-        const uint32_t ws = xs + S::XB;
 #pragma unroll
         for (int e = 0; e < XROWS; ++e) {
             const int hi = hb[e] + dh, wi = wb[e] + dw;
             const bool ok = rv[e] && qv && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
-            const uint32_t off = ok ? ((nb[e] + (uint32_t)(hi * d.Wi + wi)) * (uint32_t)d.Ci + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
-            lds_dma16(xs + e * 4096, off, rsrc_x);
+            offx[e] = ok ? ((nb[e] + (uint32_t)(hi * d.Wi + wi)) * (uint32_t)d.Ci + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
         }
 #pragma unroll
         for (int e = 0; e < WROWS; ++e) {
             const int co = c0 + r + e * RPP;
             const bool ok = qv && co < d.Co;
-            const uint32_t off = ok ? (((uint32_t)co * (uint32_t)d.WT + (uint32_t)widx) * (uint32_t)d.Ci + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
-            lds_dma16(ws + e * 4096, off, rsrc_w);
+            offw[e] = ok ? (((uint32_t)co * (uint32_t)d.WT + (uint32_t)widx) * (uint32_t)d.Ci + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
         }
+    };
+    auto issue_tile = [&](int kt, int buf) {
+        if (p.uniform_taps) {
+            const int tap = kt >= p.nkt ? 0x7fffff : ((kt * KC) >> p.log2_cpt);   // wave-uniform
+            if (tap != cur_tap) {
+                compute_offsets(kt * KC + c_log);
+                cur_tap = tap;
+            } else {
+#pragma unroll
+                for (int e = 0; e < XROWS; ++e) offx[e] += KB;    // OOB (>= 2 GiB) stays out of range
+#pragma unroll
+                for (int e = 0; e < WROWS; ++e) offw[e] += KB;
+            }
+        } else {
+            compute_offsets(kt * KC + c_log);
+        }
+        const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
+        const uint32_t ws = xs + S::XB;
+#pragma unroll
+        for (int e = 0; e < XROWS; ++e) lds_dma16(xs + e * 4096, offx[e], rsrc_x);
+#pragma unroll
+        for (int e = 0; e < WROWS; ++e) lds_dma16(ws + e * 4096, offw[e], rsrc_w);
     };
 
     f32x16_t acc[CJ][2];
@@ -475,6 +497,9 @@ int launch(ConvParams& p, hipStream_t stream) {
     static int dlds_cfg = getenv("VINCE_DLDS_CFG") ? atoi(getenv("VINCE_DLDS_CFG")) : 1;
     if (p.in_bytes && p.w_bytes && k_elems >= dlds_min_k) {
         const dim3 grid(p.ptiles * p.ctiles);
+        const int kc = (dlds_cfg == 0 || dlds_cfg == 3) ? 8 : 4;
+        const int cpt = p.cpt_mask == 0x7fffffff ? p.total_chunks : p.cpt_mask + 1;
+        p.uniform_taps = (cpt % kc == 0) && (p.total_chunks % kc == 0);
         if (dlds_cfg == 0) {
             p.nkt = (p.total_chunks + 7) / 8;
             hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 2>), grid, dim3(256), 0, stream, p);
@@ -544,11 +569,14 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     {
         const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;
         const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * d.Ci * esz, wb = (unsigned long long)d.Co * d.WT * d.Ci * esz;
-        p.in_bytes = ib < 0xfffffff0ull ? (uint32_t)ib : 0;
-        p.w_bytes = wb < 0xfffffff0ull ? (uint32_t)wb : 0;
+        p.in_bytes = ib < 0x7ff00000ull ? (uint32_t)ib : 0;   // the direct-to-LDS path addresses with 31-bit offsets
+        p.w_bytes = wb < 0x7ff00000ull ? (uint32_t)wb : 0;
     }
     p.ptiles = (p.M + PT - 1) / PT;
-    const bool narrow = d.Co <= 64;
+    // 64-channel tiles for short reductions: such layers are HBM-bound and the smaller accumulator footprint buys
+    // occupancy (5 waves/SIMD vs 3), which is what a streaming kernel needs
+    static int ct64_max_k = getenv("VINCE_CT64_MAX_K") ? atoi(getenv("VINCE_CT64_MAX_K")) : 0;
+    const bool narrow = d.Co <= 64 || (d.TA * d.TB * d.Ci <= ct64_max_k);
     const int CT = narrow ? 64 : 128;
     p.ctiles = (d.Co + CT - 1) / CT;
     hipStream_t s = (hipStream_t)stream;
