@@ -148,3 +148,49 @@ __device__ inline float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA (buffer_load ... lds) helpers shared by the direct-to-LDS kernels
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(4))) int v4i_t;
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from (descriptor, per-lane byte offset) to LDS[m0 + lane*16].
+// Issued through inline asm so that hipcc neither tracks it (it would wait vmcnt(0) before every later ds_read of
+// the same __shared__ array, serialising load and compute) nor reuses M0 across it; the caller owns the waits:
+// s_waitcnt vmcnt(N) + barrier before any wave reads the destination.
+static __device__ __forceinline__ void lds_dma16(uint32_t lds_addr_uniform, uint32_t voff, v4i_t rsrc) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr_uniform), "v"(voff), "s"(rsrc)
+        : "memory");
+}
+
+static __device__ __forceinline__ v4i_t make_rsrc(const void* ptr, uint32_t bytes) {
+    const uint64_t a = (uint64_t)ptr;
+    v4i_t r;
+    r[0] = (int)(uint32_t)a;
+    r[1] = (int)(uint32_t)(a >> 32);      // stride 0
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+
+template <int N> static __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "add the vmcnt literal");
+}
+

@@ -306,48 +306,6 @@ struct SmemD {
     static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
 };
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef __attribute__((ext_vector_type(4))) int v4i_t;
-
-// One LDS-DMA instruction: 64 lanes x 16 bytes from (descriptor, per-lane byte offset) to LDS[m0 + lane*16].
-// Issued through inline asm so that hipcc neither tracks it (it would wait vmcnt(0) before every later ds_read of
-// the same __shared__ array, serialising load and compute) nor reuses M0 across it; the caller owns the waits:
-// s_waitcnt vmcnt(N) + barrier before any wave reads the destination.
-__device__ __forceinline__ void lds_dma16(uint32_t lds_addr_uniform, uint32_t voff, v4i_t rsrc) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds_addr_uniform), "v"(voff), "s"(rsrc)
-        : "memory");
-}
-
-__device__ __forceinline__ v4i_t make_rsrc(const void* ptr, uint32_t bytes) {
-    const uint64_t a = (uint64_t)ptr;
-    v4i_t r;
-    r[0] = (int)(uint32_t)a;
-    r[1] = (int)(uint32_t)(a >> 32);      // stride 0
-    r[2] = (int)bytes;
-    r[3] = 0x00020000;
-    return r;
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else static_assert(N == 0, "add the vmcnt literal");
-}
-
 // K tile = KC 16-byte chunks per row; STAGES-deep LDS ring, prefetch distance STAGES-1 tiles, counted vmcnt so that the
 // younger tiles stay in flight across the barrier (one barrier per K tile).
 template <typename T, int CT, int KC, int STAGES>
@@ -576,7 +534,17 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     // 64-channel tiles for short reductions: such layers are HBM-bound and the smaller accumulator footprint buys
     // occupancy (5 waves/SIMD vs 3), which is what a streaming kernel needs
     static int ct64_max_k = getenv("VINCE_CT64_MAX_K") ? atoi(getenv("VINCE_CT64_MAX_K")) : 0;
-    const bool narrow = d.Co <= 64 || (d.TA * d.TB * d.Ci <= ct64_max_k);
+    static double ct64_cost = getenv("VINCE_CT64_COST") ? atof(getenv("VINCE_CT64_COST")) : 0.0;
+    bool narrow = d.Co <= 64 || (d.TA * d.TB * d.Ci <= ct64_max_k);
+    // tiny-M GEMMs (the projection MLP: 256 rows -> 2 pixel tiles): 64-channel tiles double the workgroup count
+    if (!narrow && (long)p.ptiles * ((d.Co + 127) / 128) < 128) narrow = true;
+    if (!narrow && ct64_cost > 0 && d.TA * d.TB * d.Ci >= 512) {
+        // wave quantisation: 128-channel tiles hold 3 workgroups per CU, 64-channel tiles 4; pick the one whose number of
+        // full-chip rounds times relative tile cost is smaller (784 tiles on 768 slots is two rounds)
+        const long t128 = (long)p.ptiles * ((d.Co + 127) / 128), t64 = (long)p.ptiles * ((d.Co + 63) / 64);
+        const double c128 = (double)((t128 + 767) / 768), c64 = (double)((t64 + 1023) / 1024) * ct64_cost;
+        narrow = c64 < c128;
+    }
     const int CT = narrow ? 64 : 128;
     p.ctiles = (d.Co + CT - 1) / CT;
     hipStream_t s = (hipStream_t)stream;

@@ -25,6 +25,8 @@ struct WgradParams {
     const void* in;
     const void* dy;
     float* dw;
+    uint32_t in_bytes, dy_bytes;   // descriptor ranges for the direct-to-LDS variant (0 = tensor too large)
+    int linear_x;                  // 1x1 / stride 1 / no padding: the input pixel IS the output pixel
 };
 
 constexpr int KP = 64;  // pixels per K tile
@@ -211,8 +213,196 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant: both tiles are filled by LDS-DMA into a STAGES-deep ring of 32-pixel slices (counted vmcnt,
+// one barrier per slice, no staging VGPRs, no ds_write pass).  Rows are unpadded (a DMA instruction writes
+// wave-base + lane*16), so the four pixel rows a ds_read_b64_tr_b16 half-wave touches are de-conflicted by XOR-ing
+// the 64-byte block index of a row with a function of the row, applied to the per-lane SOURCE address.
+constexpr int KPD = 32;
+
+template <typename T, int CT, int NT, int STAGES>
+struct WSmemD {
+    static constexpr int YRB = CT * (int)sizeof(T), XRB = NT * (int)sizeof(T);   // row bytes
+    static constexpr int YB = KPD * YRB, XB = KPD * XRB, STAGE = YB + XB;
+    static constexpr int BYTES = STAGES * STAGE;
+};
+
+// block swizzle of a row (bf16 only; the f32 path reads with conflict-free ds_read_b32)
+template <typename T, int ROWBYTES>
+__device__ __forceinline__ int row_swz(int row) {
+    if constexpr (sizeof(T) == 4) return 0;
+    else if constexpr (ROWBYTES == 128) return (row >> 1) & 1;
+    else return row & 3;
+}
+
+template <typename T, int ROWBYTES> struct FragD;
+template <int ROWBYTES> struct FragD<bf16_t, ROWBYTES> {
+    static constexpr int KSTEPS = KPD / 16;
+    __device__ static inline uint4 load(const unsigned char* tile, int col0, int ks, int lane) {
+        const int g = lane >> 4, t = lane & 15;
+        const int colb = (col0 + 16 * (g & 1) + (t & 3) * 4) * 2;
+        const int row = ks * 16 + (g >> 1) * 8 + (t >> 2);
+        const int sw = row_swz<bf16_t, ROWBYTES>(row);          // identical for row and row + 4
+        const unsigned char* a0 = tile + row * ROWBYTES + (((colb >> 6) ^ sw) << 6) + (colb & 63);
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 4 * ROWBYTES));
+        uint4 out;
+        __builtin_memcpy(&out.x, &lo, 8);
+        __builtin_memcpy(&out.z, &hi, 8);
+        return out;
+    }
+};
+template <int ROWBYTES> struct FragD<float, ROWBYTES> {
+    static constexpr int KSTEPS = KPD / 8;
+    __device__ static inline uint4 load(const unsigned char* tile, int col0, int ks, int lane) {
+        const unsigned char* a0 = tile + (ks * 8 + (lane >> 5) * 4) * ROWBYTES + (col0 + (lane & 31)) * 4;
+        return make_uint4(*(const uint32_t*)a0, *(const uint32_t*)(a0 + ROWBYTES), *(const uint32_t*)(a0 + 2 * ROWBYTES),
+                          *(const uint32_t*)(a0 + 3 * ROWBYTES));
+    }
+};
+
+template <typename T, int CT, int NT, int STAGES>
+__global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams p) {
+    constexpr int CH = Elem<T>::CH;
+    using S = WSmemD<T, CT, NT, STAGES>;
+    constexpr int SPRY = S::YRB / 16, SPRX = S::XRB / 16;          // 16-byte slots per row
+    constexpr int RPPY = 256 / SPRY, RPPX = 256 / SPRX;           // rows per pass of the 4 waves
+    constexpr int NY = KPD / RPPY, NX = KPD / RPPX;                // DMA instructions per thread per stage
+    constexpr int PER_STAGE = NY + NX;
+    constexpr int CJ = CT / 64, NJ = NT / 64;
+    constexpr uint32_t OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave & 1, wn = wave >> 1;
+    const int ctile = blockIdx.x % p.ctiles, ntile = blockIdx.x / p.ctiles;
+    const int c0 = ctile * CT, n0 = ntile * NT;
+    const vince_conv_desc& d = p.d;
+    const int kt_begin = blockIdx.y * p.kt_per_split;
+    const int kt_end = min(kt_begin + p.kt_per_split, p.nkt_total);
+    if (kt_begin >= kt_end) return;
+    const int nkt = kt_end - kt_begin;
+
+    const v4i_t rsrc_y = make_rsrc(p.dy, p.dy_bytes);
+    const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+
+    // dy: slot -> logical 16-byte chunk of the channel tile (64-byte blocks XOR-swizzled by row)
+    const int yrow = tid / SPRY, yslot = tid % SPRY;
+    const int ychunk = (((yslot >> 2) ^ row_swz<T, S::YRB>(yrow)) << 2) | (yslot & 3);
+    const bool yvalid_c = (c0 + ychunk * CH) < d.Co;
+    const uint32_t ycol_off = (uint32_t)(c0 + ychunk * CH) * (uint32_t)sizeof(T);
+    // x: slot -> (tap, ci chunk), fixed for the whole kernel
+    const int xrow = tid / SPRX, xslot = tid % SPRX;
+    const int xchunk = (((xslot >> 2) ^ row_swz<T, S::XRB>(xrow)) << 2) | (xslot & 3);
+    const int qn = n0 / CH + xchunk;
+    const int tap = qn >> p.log2_cpt, cc = qn & p.cpt_mask;
+    const int ta = (int)(((uint32_t)tap * p.tb_mul) >> 16), tb = tap - ta * d.TB;
+    const int dh = d.dh0 + ta * d.dhs, dw_ = d.dw0 + tb * d.dws;
+    const bool xvalid_c = qn < p.total_nchunks;
+    const uint32_t xcol_off = (uint32_t)cc * CH * (uint32_t)sizeof(T);
+
+    auto issue_slice = [&](int kt, int buf) {      // kt is the absolute slice index (32 pixels)
+        const uint32_t pix0 = (uint32_t)kt * KPD;
+        const bool live = kt < kt_end;
+        const uint32_t ys = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
+        const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + S::YB + wave * 1024);
+#pragma unroll
+        for (int e = 0; e < NY; ++e) {
+            const uint32_t pix = pix0 + yrow + e * RPPY;
+            const uint32_t off = (live && yvalid_c && pix < (uint32_t)p.M) ? pix * (uint32_t)d.Co * (uint32_t)sizeof(T) + ycol_off : OOB;
+            lds_dma16(ys + e * 4096, off, rsrc_y);
+        }
+#pragma unroll
+        for (int e = 0; e < NX; ++e) {
+            const uint32_t pix = pix0 + xrow + e * RPPX;
+            uint32_t off = OOB;
+            if (live && xvalid_c && pix < (uint32_t)p.M) {
+                if (p.linear_x) {
+                    off = pix * (uint32_t)d.Ci * (uint32_t)sizeof(T) + xcol_off;
+                } else {
+                    const uint32_t n = fastdiv(pix, p.div_howo);
+                    const uint32_t rem = pix - n * p.div_howo.d;
+                    const uint32_t ho = fastdiv(rem, p.div_wo);
+                    const uint32_t wo = rem - ho * p.div_wo.d;
+                    const int hi = (int)(ho * d.sh) + dh, wi = (int)(wo * d.sw) + dw_;
+                    if ((unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi)
+                        off = ((n * (uint32_t)d.Hi + hi) * (uint32_t)d.Wi + wi) * (uint32_t)d.Ci * (uint32_t)sizeof(T) + xcol_off;
+                }
+            }
+            lds_dma16(xs + e * 4096, off, rsrc_x);
+        }
+    };
+
+    f32x16_t acc[CJ][NJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st) issue_slice(kt_begin + st, st);
+    wait_vmcnt<(STAGES - 2) * PER_STAGE>();
+    __syncthreads();
+    int buf = 0, nbuf = STAGES - 1;
+    for (int it = 0; it < nkt; ++it) {
+        issue_slice(kt_begin + it + STAGES - 1, nbuf);
+        const unsigned char* ys = smem + buf * S::STAGE;
+        const unsigned char* xs = ys + S::YB;
+#pragma unroll
+        for (int ks = 0; ks < FragD<T, S::YRB>::KSTEPS; ++ks) {
+            uint4 af[CJ], bf[NJ];
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) af[j] = FragD<T, S::YRB>::load(ys, wc * (CT / 2) + j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) bf[i] = FragD<T, S::XRB>::load(xs, wn * (NT / 2) + i * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) FragT<T>::mma(af[j], bf[i], acc[j][i]);
+        }
+        wait_vmcnt<(STAGES - 2) * PER_STAGE>();
+        __syncthreads();
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
+    }
+    wait_vmcnt<0>();
+
+    const int T_ = d.TA * d.TB;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        const int n = n0 + wn * (NT / 2) + i * 32 + (lane & 31);
+        const int tp = (T_ == 1) ? 0 : (n >> p.log2_ci);
+        const int ci = (T_ == 1) ? n : (n & ((1 << p.log2_ci) - 1));
+        if (tp >= T_ || ci >= p.Ci_dw || (T_ == 1 && n >= d.Ci)) continue;
+        const int a = (int)(((uint32_t)tp * p.tb_mul) >> 16), b = tp - a * d.TB;
+        const int widx = d.wt0 + a * d.wta + b * d.wtb;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = c0 + wc * (CT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < d.Co) unsafeAtomicAdd(p.dw + ((size_t)co * d.WT + widx) * p.Ci_dw + ci, acc[j][i][r]);
+            }
+        }
+    }
+}
+
 template <typename T, int CT, int NT>
 int launch(const WgradParams& p, int splits, hipStream_t stream) {
+    static int use_dlds = getenv("VINCE_WGRAD_DLDS") ? atoi(getenv("VINCE_WGRAD_DLDS")) : 1;
+    if (use_dlds && p.in_bytes && p.dy_bytes && p.variant == 0) {
+        if (use_dlds == 2)
+            hipLaunchKernelGGL((conv_wgrad_dlds_kernel<T, CT, NT, 4>), dim3(p.ctiles * p.ntiles, splits), dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL((conv_wgrad_dlds_kernel<T, CT, NT, 3>), dim3(p.ctiles * p.ntiles, splits), dim3(256), 0, stream, p);
+        VINCE_CHECK_LAUNCH();
+        return VINCE_OK;
+    }
     hipLaunchKernelGGL((conv_wgrad_kernel<T, CT, NT>), dim3(p.ctiles * p.ntiles, splits), dim3(256), 0, stream, p);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
@@ -225,14 +415,17 @@ int dispatch(WgradParams& p, hipStream_t stream) {
     const int CT = d.Co <= 64 ? 64 : 128, NT = ntot <= 64 ? 64 : 128;
     p.ctiles = (d.Co + CT - 1) / CT;
     p.ntiles = (ntot + NT - 1) / NT;
-    p.nkt_total = (p.M + KP - 1) / KP;
+    static int use_dlds_d = getenv("VINCE_WGRAD_DLDS") ? atoi(getenv("VINCE_WGRAD_DLDS")) : 1;
+    const bool dlds = use_dlds_d && p.in_bytes && p.dy_bytes && p.variant == 0;
+    const int kp = dlds ? KPD : KP;                 // pixels per K slice of the kernel that will run
+    p.nkt_total = (p.M + kp - 1) / kp;
     // Split the pixel range so that the grid is about one resident wave of workgroups (256 CUs x 2): every extra split
     // costs Co*T*Ci fp32 atomics in the epilogue, and the L2 atomic rate -- not MFMA -- bounds this kernel when the grid
     // is cut 3x finer.  At least 8 K-tiles per split.
     static int target_blocks = getenv("VINCE_WGRAD_BLOCKS") ? atoi(getenv("VINCE_WGRAD_BLOCKS")) : 512;
     const int tiles = p.ctiles * p.ntiles;
     int splits = (target_blocks + tiles - 1) / tiles;
-    const int max_splits = (p.nkt_total + 7) / 8;
+    const int max_splits = (p.nkt_total * kp / 64 + 7) / 8;   // at least 512 pixels per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     p.kt_per_split = (p.nkt_total + splits - 1) / splits;
@@ -281,6 +474,13 @@ extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void
     p.div_howo = make_fastdiv((uint32_t)(d.Ho * d.Wo));
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.dy = dy; p.dw = dw; p.Ci_dw = Ci_dw; p.variant = variant;
+    {
+        const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;
+        const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * d.Ci * esz, yb = (unsigned long long)p.M * d.Co * esz;
+        p.in_bytes = ib < 0x7ff00000ull ? (uint32_t)ib : 0;
+        p.dy_bytes = yb < 0x7ff00000ull ? (uint32_t)yb : 0;
+        p.linear_x = (T == 1 && d.sh == 1 && d.sw == 1 && d.dh0 == 0 && d.dw0 == 0 && d.Hi == d.Ho && d.Wi == d.Wo) ? 1 : 0;
+    }
     hipStream_t s = (hipStream_t)stream;
     void* tok = nullptr;
     if (vince_profile_enabled())
