@@ -27,7 +27,7 @@ namespace {
 
 struct ConvParams {
     vince_conv_desc d;
-    int log2_cpt, cpt_mask, total_chunks, nkt, M, ptiles, ctiles, uniform_taps;
+    int log2_cpt, cpt_mask, total_chunks, nkt, M, ptiles, ctiles, uniform_taps, ablate;
     uint32_t tb_mul;
     FastDiv div_howo, div_wo;
     const void* in;
@@ -308,8 +308,8 @@ struct SmemD {
 
 // K tile = KC 16-byte chunks per row; STAGES-deep LDS ring, prefetch distance STAGES-1 tiles, counted vmcnt so that the
 // younger tiles stay in flight across the barrier (one barrier per K tile).
-template <typename T, int CT, int KC, int STAGES>
-__global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p) {
+template <typename T, int CT, int KC, int STAGES, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64;
     using S = SmemD<T, CT, KC, STAGES>;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p
     const int row_off = (lane & 31) * KB;
     int buf = 0, nbuf = STAGES - 1;
     for (int kt = 0; kt < p.nkt; ++kt) {
-        issue_tile(kt + STAGES - 1, nbuf);
+        if (!(p.ablate & 1)) issue_tile(kt + STAGES - 1, nbuf);
         const unsigned char* xs = smem + buf * S::STAGE + (wp * 64) * KB + row_off;
         const unsigned char* ws = smem + buf * S::STAGE + S::XB + (wc * (CT / 2)) * KB + row_off;
 #pragma unroll
@@ -429,15 +429,22 @@ __global__ __launch_bounds__(256) void conv_igemm_dlds_kernel(const ConvParams p
             for (int j = 0; j < CJ; ++j) wf[j] = *(const uint4*)(ws + j * 32 * KB + slot);
 #pragma unroll
             for (int i = 0; i < 2; ++i) xf[i] = *(const uint4*)(xs + i * 32 * KB + slot);
+            if (p.ablate & 2) {   // measurement aid: keep the LDS reads, drop the matrix work
 #pragma unroll
-            for (int j = 0; j < CJ; ++j)
+                for (int j = 0; j < CJ; ++j) asm volatile("" ::"v"(wf[j].x), "v"(wf[j].w));
 #pragma unroll
-                for (int i = 0; i < 2; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+                for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(xf[i].x), "v"(xf[i].w));
+            } else {
+#pragma unroll
+                for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+            }
         }
         // tile kt+1 must have landed (this wave's share; the barrier extends it to all waves); the STAGES-2 younger
         // tiles stay in flight across the barrier
         wait_vmcnt<(STAGES - 2) * PER_STAGE>();
-        __syncthreads();
+        if (!(p.ablate & 4)) __syncthreads();
         buf = buf + 1 == STAGES ? 0 : buf + 1;
         nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
     }
@@ -455,7 +462,7 @@ int launch(ConvParams& p, hipStream_t stream) {
     static int dlds_cfg = getenv("VINCE_DLDS_CFG") ? atoi(getenv("VINCE_DLDS_CFG")) : 1;
     if (p.in_bytes && p.w_bytes && k_elems >= dlds_min_k) {
         const dim3 grid(p.ptiles * p.ctiles);
-        const int kc = (dlds_cfg == 0 || dlds_cfg == 3) ? 8 : 4;
+        const int kc = (dlds_cfg == 0 || dlds_cfg == 3) ? 8 : 4;   // cfg 1, 2, 4 use 64-byte rows
         const int cpt = p.cpt_mask == 0x7fffffff ? p.total_chunks : p.cpt_mask + 1;
         p.uniform_taps = (cpt % kc == 0) && (p.total_chunks % kc == 0);
         if (dlds_cfg == 0) {
@@ -467,6 +474,9 @@ int launch(ConvParams& p, hipStream_t stream) {
         } else if (dlds_cfg == 2) {
             p.nkt = (p.total_chunks + 3) / 4;
             hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 4>), grid, dim3(256), 0, stream, p);
+        } else if (dlds_cfg == 4) {   // 64-byte rows x 2 stages, registers capped for 4 workgroups per CU
+            p.nkt = (p.total_chunks + 3) / 4;
+            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4>), grid, dim3(256), 0, stream, p);
         } else {
             p.nkt = (p.total_chunks + 7) / 8;
             hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 3>), grid, dim3(256), 0, stream, p);
@@ -524,6 +534,8 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.div_howo = make_fastdiv((uint32_t)(d.Ho * d.Wo));
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.w = w; p.out = out; p.bias = bias; p.stats = stats; p.flags = flags;
+    static int ablate = getenv("VINCE_CONV_ABLATE") ? atoi(getenv("VINCE_CONV_ABLATE")) : 0;   // measurement aid only
+    p.ablate = ablate;
     {
         const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;
         const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * d.Ci * esz, wb = (unsigned long long)d.Co * d.WT * d.Ci * esz;
