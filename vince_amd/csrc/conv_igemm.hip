@@ -70,18 +70,18 @@ struct Smem {
     static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
 };
 
-template <typename T, int CT, int CRS>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char* smem, f32x16_t (&acc)[CT / 64][2],
+template <typename T, int CT, int CRS, int PTL = PT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char* smem, f32x16_t (&acc)[CT / 64][PTL / 64],
                                               uint32_t tile, int p0, int c0, int tid, int lane, int wave, int wp, int wc) {
     constexpr int CH = Elem<T>::CH;
-    constexpr int CJ = CT / 64;
+    constexpr int CJ = CT / 64, PI = PTL / 64;
     const vince_conv_desc& d = p.d;
     // ---- epilogue: accumulators -> LDS [pixel][channel] as T -> coalesced 16-byte stores --------------------
 #pragma unroll
     for (int j = 0; j < CJ; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pix = wp * 64 + i * 32 + (lane & 31);
+        for (int i = 0; i < PI; ++i) {
+            const int pix = wp * (PTL / 2) + i * 32 + (lane & 31);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = wc * (CT / 2) + j * 32 + 8 * g + 4 * (lane >> 5);
@@ -110,7 +110,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     for (int e = 0; e < CH; ++e) ssum[e] = ssq[e] = 0.f;
     T* __restrict__ out = (T*)p.out;
     const bool identity_map = (d.osh == 1 && d.osw == 1 && d.oh0 == 0 && d.ow0 == 0 && d.OH == d.Ho && d.OW == d.Wo);
-    for (int row = row0; row < PT; row += RPP) {
+    for (int row = row0; row < PTL; row += RPP) {
         const uint32_t m = p0 + row;
         if (m >= (uint32_t)p.M || !cvalid) continue;
         size_t opix = m;
@@ -149,7 +149,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
         }
     }
     if (p.stats) {   // uniform branch
-        float* red = (float*)(smem + PT * CRS);      // [4 waves][CPR][CH][2]
+        float* red = (float*)(smem + PTL * CRS);      // [4 waves][CPR][CH][2]
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
 #pragma unroll
@@ -296,27 +296,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // fetches logical K chunk pos ^ ((R>>1)&7), and the fragment read of chunk c goes to slot c ^ ((R>>1)&7) -- 16
 // consecutive rows then cover all 16 slots of the 256-byte bank window.  Out-of-image taps and tile tails are zero
 // filled by the buffer descriptor's range check (offset forced past num_records).
-template <typename T, int CT, int KC, int STAGES>
+template <typename T, int CT, int KC, int STAGES, int PTL = PT>
 struct SmemD {
     static constexpr int KB = KC * 16;                       // bytes of K per row per stage
-    static constexpr int XB = PT * KB, WB = CT * KB, STAGE = XB + WB;
+    static constexpr int XB = PTL * KB, WB = CT * KB, STAGE = XB + WB;
     static constexpr int MAIN = STAGES * STAGE;
     static constexpr int CRS = CT * (int)sizeof(T) + 16;
-    static constexpr int EPI = PT * CRS + 4 * CT * 2 * 4;
+    static constexpr int EPI = PTL * CRS + 4 * CT * 2 * 4;
     static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
 };
 
 // K tile = KC 16-byte chunks per row; STAGES-deep LDS ring, prefetch distance STAGES-1 tiles, counted vmcnt so that the
 // younger tiles stay in flight across the barrier (one barrier per K tile).
-template <typename T, int CT, int KC, int STAGES, int MINW = 1>
+// PTL = pixels per workgroup tile (128 or 256).  The L2 -> LDS fill rate of a CU (measured ~19 B/clk with every CU
+// streaming) caps a 128x128 tile at ~700 TFLOP/s chip-wide: 256 B of operands per K element feed 32768 FLOP.  The
+// 256-pixel tile moves 25 % fewer bytes per FLOP (each wave owns 128 pixels x CT/2 channels).
+template <typename T, int CT, int KC, int STAGES, int MINW = 1, int PTL = PT>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
-    constexpr int CJ = CT / 64;
-    using S = SmemD<T, CT, KC, STAGES>;
+    constexpr int CJ = CT / 64, PI = PTL / 64;
+    using S = SmemD<T, CT, KC, STAGES, PTL>;
     constexpr int KB = S::KB;
     constexpr int RPW = 1024 / KB;                 // rows per wave DMA instruction (8 or 16)
     constexpr int RPP = 4 * RPW;                   // rows per pass of the 4 waves
-    constexpr int XROWS = PT / RPP, WROWS = CT / RPP;
+    constexpr int XROWS = PTL / RPP, WROWS = CT / RPP;
     constexpr int PER_STAGE = XROWS + WROWS;       // DMA instructions per thread per stage
     constexpr int SWSH = KC == 8 ? 1 : 2, SWMASK = KC - 1;   // slot swizzle = (row >> SWSH) & SWMASK
     __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES];
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     const int wc = wave & 1, wp = wave >> 1;
     const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
     const int ptile = tile / p.ctiles, ctile = tile - ptile * p.ctiles;
-    const int p0 = ptile * PT, c0 = ctile * CT;
+    const int p0 = ptile * PTL, c0 = ctile * CT;
     const vince_conv_desc& d = p.d;
     constexpr uint32_t OOB = 0x80000000u;   // descriptors cover < 2 GiB, so this (and small increments of it) reads as zero
 
@@ -401,11 +404,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
         for (int e = 0; e < WROWS; ++e) lds_dma16(ws + e * 4096, offw[e], rsrc_w);
     };
 
-    f32x16_t acc[CJ][2];
+    f32x16_t acc[CJ][PI];
 #pragma unroll
     for (int j = 0; j < CJ; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < PI; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
@@ -419,26 +422,26 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     int buf = 0, nbuf = STAGES - 1;
     for (int kt = 0; kt < p.nkt; ++kt) {
         if (!(p.ablate & 1)) issue_tile(kt + STAGES - 1, nbuf);
-        const unsigned char* xs = smem + buf * S::STAGE + (wp * 64) * KB + row_off;
+        const unsigned char* xs = smem + buf * S::STAGE + (wp * (PTL / 2)) * KB + row_off;
         const unsigned char* ws = smem + buf * S::STAGE + S::XB + (wc * (CT / 2)) * KB + row_off;
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
             const int slot = ((s * 2 + khalf) ^ sw) * 16;
-            uint4 wf[CJ], xf[2];
+            uint4 wf[CJ], xf[PI];
 #pragma unroll
             for (int j = 0; j < CJ; ++j) wf[j] = *(const uint4*)(ws + j * 32 * KB + slot);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) xf[i] = *(const uint4*)(xs + i * 32 * KB + slot);
+            for (int i = 0; i < PI; ++i) xf[i] = *(const uint4*)(xs + i * 32 * KB + slot);
             if (p.ablate & 2) {   // measurement aid: keep the LDS reads, drop the matrix work
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) asm volatile("" ::"v"(wf[j].x), "v"(wf[j].w));
 #pragma unroll
-                for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(xf[i].x), "v"(xf[i].w));
+                for (int i = 0; i < PI; ++i) asm volatile("" ::"v"(xf[i].x), "v"(xf[i].w));
             } else {
 #pragma unroll
                 for (int j = 0; j < CJ; ++j)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+                    for (int i = 0; i < PI; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
             }
         }
         // tile kt+1 must have landed (this wave's share; the barrier extends it to all waves); the STAGES-2 younger
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     }
     wait_vmcnt<0>();
     __syncthreads();
-    conv_epilogue<T, CT, S::CRS>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
+    conv_epilogue<T, CT, S::CRS, PTL>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
 template <typename T, int CT>
@@ -459,10 +462,12 @@ int launch(ConvParams& p, hipStream_t stream) {
     const int k_elems = p.total_chunks * (16 / (int)sizeof(T));
     // ring configuration: 1 = 64-byte K rows x 3 stages (48 KB, 3 workgroups/CU; best overall on MI355X),
     // 0 = 128-byte rows x 2 stages, 2 = 64-byte rows x 4 stages, 3 = 128-byte rows x 3 stages
-    static int dlds_cfg = getenv("VINCE_DLDS_CFG") ? atoi(getenv("VINCE_DLDS_CFG")) : 1;
+    static int dlds_cfg = getenv("VINCE_DLDS_CFG") ? atoi(getenv("VINCE_DLDS_CFG")) : 5;
+    static int big_min_k = getenv("VINCE_BIG_MIN_K") ? atoi(getenv("VINCE_BIG_MIN_K")) : 1024;
+    static int big_min_tiles = getenv("VINCE_BIG_MIN_TILES") ? atoi(getenv("VINCE_BIG_MIN_TILES")) : 256;
     if (p.in_bytes && p.w_bytes && k_elems >= dlds_min_k) {
         const dim3 grid(p.ptiles * p.ctiles);
-        const int kc = (dlds_cfg == 0 || dlds_cfg == 3) ? 8 : 4;   // cfg 1, 2, 4 use 64-byte rows
+        const int kc = (dlds_cfg == 0 || dlds_cfg == 3) ? 8 : 4;   // cfg 1, 2, 4, 5 use 64-byte rows
         const int cpt = p.cpt_mask == 0x7fffffff ? p.total_chunks : p.cpt_mask + 1;
         p.uniform_taps = (cpt % kc == 0) && (p.total_chunks % kc == 0);
         if (dlds_cfg == 0) {
@@ -474,7 +479,15 @@ int launch(ConvParams& p, hipStream_t stream) {
         } else if (dlds_cfg == 2) {
             p.nkt = (p.total_chunks + 3) / 4;
             hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 4>), grid, dim3(256), 0, stream, p);
-        } else if (dlds_cfg == 4) {   // 64-byte rows x 2 stages, registers capped for 4 workgroups per CU
+        } else if (dlds_cfg == 5 && CT == 128 && k_elems >= big_min_k && (long)((p.M + 255) / 256) * p.ctiles >= big_min_tiles) {
+            // 256-pixel tiles, 64-byte rows x 3 stages (2 workgroups per CU): long reductions with enough tiles to fill
+            // the chip -- 25 % fewer operand bytes per FLOP through the L2 -> LDS path that bounds the 128-pixel tile
+            if constexpr (CT == 128) {
+                p.nkt = (p.total_chunks + 3) / 4;
+                p.ptiles = (p.M + 255) / 256;
+                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+            }
+        } else if (dlds_cfg == 4 || dlds_cfg == 5) {   // 64-byte rows x 2 stages, registers capped for 4 workgroups per CU
             p.nkt = (p.total_chunks + 3) / 4;
             hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4>), grid, dim3(256), 0, stream, p);
         } else {
