@@ -156,6 +156,34 @@ def main():
         "step_tflops_per_gpu": round(whole_step_tflops, 2),
     }
 
+    if not opt.no_extras:
+        # ---- forward + InfoNCE only (the quantity the north-star roofline target is stated on): query-encoder forward in
+        # train-mode BN + fused similarity / loss / metrics, no backward, no optimizer.  B frames per pass.
+        batch_fwd = pool(0)
+        batch_fwd = {"data": batch_fwd["data"], "batch_types": ["images"], "batch_sizes": [opt.batch]}
+        kq = solver.vince_queue.dequeue()["queue_vectors"]
+        keys = torch.nn.functional.normalize(torch.randn(opt.batch, opt.embed, device=device), dim=1)
+
+        def fwd_once():
+            with torch.no_grad():
+                o = solver.model.get_embeddings(batch_fwd)[0]
+                o.update(dict(queue_embeddings=keys, queue_vectors=kq, data_source="SYN", num_frames=1))
+                o = solver.model(o)
+                return solver.model.loss(o)["nce_loss"][1]
+
+        for _ in range(3):
+            fwd_once()
+        barrier()
+        tf0 = time.perf_counter()
+        nf = max(5, opt.steps)
+        for _ in range(nf):
+            fwd_once()
+        barrier()
+        tfwd = (time.perf_counter() - tf0) / nf
+        fwd_tflops = FWD_GFLOP_PER_FRAME.get(opt.backbone, 0.0) * opt.batch / 1000.0 / tfwd
+        out["fwd_infonce"] = {"frames_per_s_per_gpu": round(opt.batch / tfwd, 1), "ms": round(tfwd * 1000, 3),
+                              "tflops": round(fwd_tflops, 1), "mfma_frac": round(fwd_tflops / PEAK_TFLOPS[opt.dtype], 4)}
+
     if rank == 0 and world == 1 and not opt.no_extras:
         # ---- roofline leg: hipEvent pairs around every conv launch for a few extra steps -------------------------
         L = lib()
@@ -177,8 +205,18 @@ def main():
         dom_conv = "conv_igemm<%s,128>" % ("bf16" if opt.dtype == "bf16" else "f32")
         if dom_conv in kernels:
             k = kernels[dom_conv]
+            # HBM bytes per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note in
+            # MI355X_MICROARCH.md, + WRITE_SIZE), recorded by tools/rocpd_pmc.py into profiles/ -- bench.py cannot run
+            # the counter passes itself
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_conv_igemm.json")) as fh:
+                    pm = json.load(fh)
+                traffic = {"bytes_per_launch": pm["bytes_per_launch"], "source": pm["source"]}
+            except Exception:
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": dom_conv, "achieved": k["tflops"], "peak": PEAK_TFLOPS[opt.dtype],
-                               "unit": "TFLOP/s", "frac": round(k["tflops"] / PEAK_TFLOPS[opt.dtype], 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(k["tflops"] / PEAK_TFLOPS[opt.dtype], 4), "traffic": traffic,
                                "avg_us": k["avg_us"], "launches_per_step": k["launches_per_step"],
                                "ms_per_step": k["ms_per_step"], "longest_kernel_family": dom}
         out["kernels"] = kernels

@@ -155,6 +155,15 @@ int vince_jigsaw_nchw_to_nhwc(int dtype, const float* in, void* out, int32_t N, 
  * [Ci][T][Co] (dtype). */
 int vince_prepare_weight(int dtype, const float* w, void* wk, void* wt, int32_t Co, int32_t T, int32_t Ci,
                          int32_t Cip, void* stream);
+/* The same for many layers in ONE launch; `table_dev` is a device array of n entries. */
+typedef struct vince_prep_entry {
+    const void* w; /* float [Co][T][Ci] */
+    void* wk;      /* dtype [Co][T][Cip] */
+    void* wt;      /* dtype [Ci][T][Co] or NULL */
+    int32_t Co, T, Ci, Cip;
+} vince_prep_entry;
+int vince_prepare_weights_batched(int dtype, const vince_prep_entry* table_dev, int32_t n, void* stream);
+
 /* dtype NHWC -> float NCHW (spatial_features for callers that want the reference layout) */
 int vince_nhwc_to_nchw_f32(int dtype, const void* in, float* out, int32_t N, int32_t C, int32_t H, int32_t W,
                            void* stream);
@@ -246,7 +255,7 @@ int vince_trunk_bn_info(vince_trunk_t t, int32_t bn_index, char* name, int32_t n
 int32_t vince_trunk_out_channels(vince_trunk_t t);
 int32_t vince_trunk_out_hw(vince_trunk_t t, int32_t* h, int32_t* w);
 size_t vince_trunk_workspace_bytes(vince_trunk_t t);       /* activations + saved tensors + gradient scratch */
-size_t vince_trunk_weight_cache_bytes(vince_trunk_t t);    /* compute-dtype weight copies (per encoder) */
+size_t vince_trunk_weight_cache_bytes(vince_trunk_t t);    /* compute-dtype weight copies (per encoder) + descriptor table */
 
 /* fp32 master weights -> compute copies in `wcache`.  Call after every parameter update. */
 int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* params, void* wcache, void* stream);

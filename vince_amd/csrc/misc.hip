@@ -75,6 +75,27 @@ __global__ __launch_bounds__(256) void prepare_weight_kernel(const float* __rest
     }
 }
 
+// All conv layers of a trunk in one launch: blockIdx.y = layer (descriptor table in device memory), blockIdx.x strides
+// over that layer's elements.
+template <typename T>
+__global__ __launch_bounds__(256) void prepare_weights_batched_kernel(const vince_prep_entry* __restrict__ table) {
+    const vince_prep_entry e = table[blockIdx.y];
+    const float* __restrict__ w = (const float*)e.w;
+    T* __restrict__ wk = (T*)e.wk;
+    T* __restrict__ wt = (T*)e.wt;
+    const int64_t total = (int64_t)e.Co * e.T * e.Cip;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(idx % e.Cip);
+        const int64_t r = idx / e.Cip;
+        const int t = (int)(r % e.T);
+        const int co = (int)(r / e.T);
+        const float v = ci < e.Ci ? w[((size_t)co * e.T + t) * e.Ci + ci] : 0.f;
+        const T o = cvt_from_f32<T>(v);
+        wk[idx] = o;
+        if (wt && ci < e.Ci) wt[((size_t)ci * e.T + t) * e.Co + co] = o;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int N,
                                                            int C, int H, int W) {
@@ -231,6 +252,18 @@ extern "C" int vince_prepare_weight(int dtype, const float* w, void* wk, void* w
     else
         hipLaunchKernelGGL(prepare_weight_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w,
                            (bf16_t*)wk, (bf16_t*)wt, Co, T, Ci, Cip);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_prepare_weights_batched(int dtype, const vince_prep_entry* table_dev, int32_t n, void* stream) {
+    DTYPE_OK("vince_prepare_weights_batched");
+    VINCE_CHECK_ARG(table_dev && n > 0, VINCE_E_ARG, "vince_prepare_weights_batched: bad arguments");
+    const dim3 grid(64, n);
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(prepare_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
+    else
+        hipLaunchKernelGGL(prepare_weights_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

@@ -10,6 +10,8 @@
 //   stats / sums            fp64 [C][2] per BN for the forward statistics and the backward reductions
 //   consts                  per BN: scale, shift, batch mean, invstd (float[C] each)
 //   4 gradient scratch buffers of the largest activation size (dZ, dY, dA, dX roles rotate)
+#include <string.h>
+
 #include <array>
 #include <string>
 #include <vector>
@@ -58,7 +60,9 @@ struct vince_trunk {
     std::vector<std::string> bnnames;
     std::vector<int> bnC;
     size_t off_x0, off_ystem, off_amax, off_p0, off_stats, off_sums, off_consts, off_g[4];
-    size_t n_stats_doubles, n_consts_floats, max_act, ws_bytes, wc_bytes;
+    size_t n_stats_doubles, n_consts_floats, max_act, ws_bytes, wc_bytes, off_prep_table;
+    std::vector<vince_prep_entry> prep_table;   // last uploaded batched weight-prep descriptors
+    void* prep_table_dev = nullptr;
 };
 
 namespace {
@@ -246,7 +250,8 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     t->off_consts = P.ws; P.ws = align_up(P.ws + P.nf * sizeof(float));
     for (int i = 0; i < 4; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     t->ws_bytes = P.ws;
-    t->wc_bytes = P.wc;
+    t->off_prep_table = P.wc;
+    t->wc_bytes = align_up(P.wc + 128 * sizeof(vince_prep_entry));
     *out = t;
     return VINCE_OK;
 }
@@ -356,12 +361,34 @@ int bn_bwd(Ctx& c, const BnL& bn, const void* dz, const uint8_t* bits, bool self
 
 extern "C" int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* params, void* wcache, void* stream) {
     VINCE_CHECK_ARG(t && params && wcache, VINCE_E_ARG, "vince_trunk_prepare_weights: null pointer");
-    RC(prep_one(t, t->stem, params, wcache, stream));
+    // one launch for all conv layers: the descriptor table is staged at the tail of the weight cache
+    std::vector<vince_prep_entry> tab;
+    auto add = [&](const ConvL& c) {
+        vince_prep_entry e;
+        e.w = params[c.param];
+        e.wk = at(wcache, c.wk);
+        e.wt = c.wt == NONE ? nullptr : at(wcache, c.wt);
+        e.Co = c.Co; e.T = c.k * c.k; e.Ci = c.Ci; e.Cip = c.Cip;
+        tab.push_back(e);
+    };
+    add(t->stem);
     for (const Blk& b : t->blocks) {
-        for (int ci = 0; ci < b.nconv; ++ci) RC(prep_one(t, b.c[ci], params, wcache, stream));
-        if (b.has_ds) RC(prep_one(t, b.cd, params, wcache, stream));
+        for (int ci = 0; ci < b.nconv; ++ci) add(b.c[ci]);
+        if (b.has_ds) add(b.cd);
     }
-    return VINCE_OK;
+    void* dev_table = at(wcache, t->off_prep_table);
+    // the table only changes when the caller's buffers move: upload it then (a pageable H2D copy synchronises the host
+    // with the stream, which must not happen every step)
+    const bool same = t->prep_table_dev == dev_table && t->prep_table.size() == tab.size() &&
+                      memcmp(t->prep_table.data(), tab.data(), tab.size() * sizeof(vince_prep_entry)) == 0;
+    if (!same) {
+        VINCE_CHECK_HIP(hipMemcpyAsync(dev_table, tab.data(), tab.size() * sizeof(vince_prep_entry), hipMemcpyHostToDevice,
+                                       (hipStream_t)stream));
+        VINCE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        t->prep_table = tab;
+        t->prep_table_dev = dev_table;
+    }
+    return vince_prepare_weights_batched(t->cfg.dtype, (const vince_prep_entry*)dev_table, (int32_t)tab.size(), stream);
 }
 
 extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void* wcache, float* const* bn_running,
