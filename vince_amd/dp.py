@@ -56,6 +56,8 @@ class GradientReducer:
         if self.on_gpu:
             self.comm_stream = torch.cuda.Stream()
             self.events = [torch.cuda.Event() for _ in self.plan]
+            for ev in self.events:
+                ev.record()          # torch creates the underlying hipEvent lazily; the engine needs a live handle
             self.done = torch.cuda.Event()
             model._bucket_events = [(blk, ev) for (blk, _, _), ev in zip(self.plan, self.events) if blk is not None]
 

@@ -84,7 +84,8 @@ class VinceSolver(BaseSolver):
         # vince_solver.py:252-265: SGD(lr=base_lr, weight_decay=1e-4, momentum=0.9) on model.parameters()
         self.optimizer = FlatSGD(self.model, lr=self.args.base_lr, momentum=0.9, weight_decay=0.0001)
         w, _ = dp.world()
-        if w > 1:
+        if w > 1 or (os.environ.get("VINCE_FORCE_DP") and torch.distributed.is_initialized()):
+            # (VINCE_FORCE_DP exercises the bucketed all-reduce machinery with a single-rank process group)
             self.reducer = dp.GradientReducer(self.model, ARCH_LAYERS[self.model.feature_extractor.arch])
             self.optimizer.grad_scale = 1.0 / w
         self.print_optimizer()
