@@ -345,7 +345,7 @@ def test_bucketed_allreduce_machinery_single_rank():
         solver.vince_queue.vector_queue.copy_(torch.nn.functional.normalize(
             torch.randn(64, 64, generator=torch.Generator().manual_seed(1)), dim=1))
         solver.reset_epoch()
-        losses = [float(solver.run_train_iteration()[0]["nce_loss"]) for _ in range(3)]
+        losses = [float(solver.run_train_iteration()[0]["nce_loss"]) for _ in range(2)]
         return losses, solver.model._flat.clone(), solver.reducer is not None
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -358,11 +358,10 @@ def test_bucketed_allreduce_machinery_single_rank():
         os.environ.pop("VINCE_FORCE_DP", None)
         dist.destroy_process_group()
     assert not r0 and r1
-    # fp32 atomics make the weight gradients order-dependent in the last bits; the third step amplifies that (chaotic
-    # dynamics of a freshly initialised encoder), so it gets the looser bound
-    np.testing.assert_allclose(l1[:2], l0[:2], rtol=1e-5)
-    np.testing.assert_allclose(l1[2], l0[2], rtol=5e-3)
-    assert rel(p1.cpu(), p0.cpu()) < 5e-3
+    # (two steps only: fp32 atomics make weight gradients order-dependent in the last bits and a freshly initialised
+    # encoder amplifies that chaotically from the third step on)
+    np.testing.assert_allclose(l1, l0, rtol=1e-5)
+    assert rel(p1.cpu(), p0.cpu()) < 2e-3
 
 
 def test_cpu_model_forward_raises():
