@@ -56,6 +56,8 @@ class VinceSolver(BaseSolver):
         self.kill_thread = False
         self.drawn_this_epoch = False
         self.reducer = None
+        self._key_stream = None
+        self.overlap_key_encoder = bool(int(os.environ.get("VINCE_OVERLAP_KEY", "1")))
         super(VinceSolver, self).__init__(args, train_logger, val_logger)
 
     # ------------------------------------------------------------------------------------------ setup
@@ -200,17 +202,31 @@ class VinceSolver(BaseSolver):
         self.time_meters["data_cache_time"].update(t_end - t_start)
         t_start = time.time()
 
-        # key encoder (no grad) then query encoder (vince_solver.py:397-406)
+        # key encoder (no grad) and query encoder (vince_solver.py:397-406).  The two forwards are independent (different
+        # weights, different workspaces), so the key encoder runs on a side HIP stream and its kernels fill the launch
+        # tails of the query encoder's; the main stream joins it before the similarity stage.
         if self.args.jigsaw:
-            if random.random() < 0.5:
-                queue_batches = self.queue_model(image_batch_concat, jigsaw=True, shuffle=True)
-                outputs = self.model.get_embeddings(image_batch_concat, jigsaw=False, shuffle=True)
-            else:
-                queue_batches = self.queue_model(image_batch_concat, jigsaw=False, shuffle=True)
-                outputs = self.model.get_embeddings(image_batch_concat, jigsaw=True, shuffle=True)
+            jig_key = random.random() < 0.5
+            jig_query = not jig_key
         else:
-            queue_batches = self.queue_model(image_batch_concat, shuffle=True)
-            outputs = self.model.get_embeddings(image_batch_concat, shuffle=True)
+            jig_key = jig_query = False
+        on_gpu = self.model.device.type == "cuda"
+        if on_gpu and self.overlap_key_encoder:
+            main = torch.cuda.current_stream()
+            if self._key_stream is None:
+                self._key_stream = torch.cuda.Stream()
+            self._key_stream.wait_stream(main)
+            with torch.cuda.stream(self._key_stream):
+                queue_batches = self.queue_model(image_batch_concat, jigsaw=jig_key, shuffle=True)
+            outputs = self.model.get_embeddings(image_batch_concat, jigsaw=jig_query, shuffle=True)
+            main.wait_stream(self._key_stream)
+            for qb in queue_batches:      # produced on the side stream, consumed (and later freed) on the main one
+                for v in qb.values():
+                    if isinstance(v, torch.Tensor):
+                        v.record_stream(main)
+        else:
+            queue_batches = self.queue_model(image_batch_concat, jigsaw=jig_key, shuffle=True)
+            outputs = self.model.get_embeddings(image_batch_concat, jigsaw=jig_query, shuffle=True)
 
         t_end = time.time()
         self.time_meters["forward_time"].update(t_end - t_start)
