@@ -10,6 +10,7 @@
 //   stats / sums            fp64 [C][2] per BN for the forward statistics and the backward reductions
 //   consts                  per BN: scale, shift, batch mean, invstd (float[C] each)
 //   4 gradient scratch buffers of the largest activation size (dZ, dY, dA, dX roles rotate)
+#include <stdlib.h>
 #include <string.h>
 
 #include <array>
@@ -59,10 +60,14 @@ struct vince_trunk {
     std::vector<std::array<int, 4>> pshape;
     std::vector<std::string> bnnames;
     std::vector<int> bnC;
-    size_t off_x0, off_ystem, off_amax, off_p0, off_stats, off_sums, off_consts, off_g[4];
+    size_t off_x0, off_ystem, off_amax, off_p0, off_stats, off_sums, off_consts, off_g[3], off_dy[3];
     size_t n_stats_doubles, n_consts_floats, max_act, ws_bytes, wc_bytes, off_prep_table;
     std::vector<vince_prep_entry> prep_table;   // last uploaded batched weight-prep descriptors
     void* prep_table_dev = nullptr;
+    // weight-gradient side stream (created on first backward) + per-slot events of the dY ring
+    hipStream_t side = nullptr;
+    hipEvent_t ev_dy[3] = {nullptr, nullptr, nullptr}, ev_wg[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr;
+    bool wg_pending[3] = {false, false, false};
 };
 
 namespace {
@@ -248,7 +253,8 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     t->off_stats = P.ws; P.ws = align_up(P.ws + P.nd * sizeof(double));
     t->off_sums = P.ws; P.ws = align_up(P.ws + P.nd * sizeof(double));
     t->off_consts = P.ws; P.ws = align_up(P.ws + P.nf * sizeof(float));
-    for (int i = 0; i < 4; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
+    for (int i = 0; i < 3; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
+    for (int i = 0; i < 3; ++i) { t->off_dy[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     t->ws_bytes = P.ws;
     t->off_prep_table = P.wc;
     t->wc_bytes = align_up(P.wc + 128 * sizeof(vince_prep_entry));
@@ -256,7 +262,16 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     return VINCE_OK;
 }
 
-extern "C" void vince_trunk_destroy(vince_trunk_t t) { delete t; }
+extern "C" void vince_trunk_destroy(vince_trunk_t t) {
+    if (!t) return;
+    if (t->side) {
+        hipStreamSynchronize(t->side);
+        for (int i = 0; i < 3; ++i) { hipEventDestroy(t->ev_dy[i]); hipEventDestroy(t->ev_wg[i]); }
+        hipEventDestroy(t->ev_join);
+        hipStreamDestroy(t->side);
+    }
+    delete t;
+}
 extern "C" int32_t vince_trunk_num_params(vince_trunk_t t) { return t ? t->nparams : 0; }
 extern "C" int32_t vince_trunk_num_bn(vince_trunk_t t) { return t ? t->nbn : 0; }
 extern "C" int32_t vince_trunk_num_blocks(vince_trunk_t t) { return t ? (int32_t)t->blocks.size() : 0; }
@@ -448,10 +463,47 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     Ctx c{t, params, wcache, workspace, stream, t->cfg.dtype};
     const int N = t->cfg.N;
     VINCE_CHECK_HIP(hipMemsetAsync(at(workspace, t->off_sums), 0, t->n_stats_doubles * sizeof(double), (hipStream_t)stream));
+    // Weight gradients run on a side stream: wgrad(layer) only needs dY(layer) and the saved activation, and nothing but
+    // the optimiser needs its result, so it overlaps the BatchNorm-backward / dgrad chain of the layers below (compute-
+    // bound MFMA work next to HBM-bound streams).  dY lives in a 3-slot ring; a slot is rewritten only after the wgrad
+    // that read it has finished (ev_wg), and a wgrad starts when its dY is complete (ev_dy).
+    static const bool overlap = !(getenv("VINCE_WGRAD_STREAM") && atoi(getenv("VINCE_WGRAD_STREAM")) == 0);
+    hipStream_t main_s = (hipStream_t)stream;
+    if (overlap && !t->side) {
+        VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+        for (int i = 0; i < 3; ++i) {
+            VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_dy[i], hipEventDisableTiming));
+            VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_wg[i], hipEventDisableTiming));
+        }
+        VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    }
+    for (int i = 0; i < 3; ++i) t->wg_pending[i] = false;
+    int slot = 0;
+    void* DY = nullptr;
+    auto next_dy = [&]() -> int {      // claim the next ring slot for writing on the main stream
+        slot = (slot + 1) % 3;
+        if (overlap && t->wg_pending[slot]) {
+            VINCE_CHECK_HIP(hipStreamWaitEvent(main_s, t->ev_wg[slot], 0));
+            t->wg_pending[slot] = false;
+        }
+        DY = at(workspace, t->off_dy[slot]);
+        return VINCE_OK;
+    };
+    auto wgrad_async = [&](const vince_conv_desc& d, const void* in, float* dw, int ci_dw) -> int {
+        if (!overlap) return vince_conv_wgrad(&d, c.dtype, in, DY, dw, ci_dw, 0, stream);
+        VINCE_CHECK_HIP(hipEventRecord(t->ev_dy[slot], main_s));
+        VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_dy[slot], 0));
+        RC(vince_conv_wgrad(&d, c.dtype, in, DY, dw, ci_dw, 0, (void*)t->side));
+        VINCE_CHECK_HIP(hipEventRecord(t->ev_wg[slot], t->side));
+        t->wg_pending[slot] = true;
+        return VINCE_OK;
+    };
+    auto wgrad_layer = [&](const ConvL& cv, const void* in) -> int {
+        return wgrad_async(fwd_desc(t, cv), in, grads[cv.param], cv.Ci);
+    };
     void* Z = at(workspace, t->off_g[0]);
-    void* DY = at(workspace, t->off_g[1]);
-    void* DA = at(workspace, t->off_g[2]);
-    void* DX = at(workspace, t->off_g[3]);
+    void* DA = at(workspace, t->off_g[1]);
+    void* DX = at(workspace, t->off_g[2]);
     RC(vince_avgpool_bwd(c.dtype, dpooled, Z, N, t->outH * t->outW, t->outC, stream));
     for (int bi = (int)t->blocks.size() - 1; bi >= 0; --bi) {
         const Blk& b = t->blocks[bi];
@@ -462,35 +514,53 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         const void* x_in = at(workspace, b.x_in);
         // z = relu(bn_L(y_L) + identity): g = dz * (z > 0) is the gradient of both addends
         if (b.has_ds) {
+            RC(next_dy());
             RC(bn_bwd(c, b.bd, Z, zbits, false, b.yd, rows_out, DY, nullptr, grads));
-            RC(wgrad(c, b.cd, x_in, DY, grads[b.cd.param]));
+            RC(wgrad_layer(b.cd, x_in));
             RC(dgrad(c, b.cd, DY, DX, false));
+            RC(next_dy());
             RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, nullptr, grads));
         } else {
+            RC(next_dy());
             RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, DX, grads));   // DX <- g (identity branch)
         }
         for (int ci = L; ci >= 0; --ci) {
             const void* in_act = ci == 0 ? x_in : at(workspace, b.a[ci - 1]);
-            RC(wgrad(c, b.c[ci], in_act, DY, grads[b.c[ci].param]));
+            RC(wgrad_layer(b.c[ci], in_act));
             if (ci > 0) {
                 RC(dgrad(c, b.c[ci], DY, DA, false));
                 const int64_t rows = (int64_t)N * b.c[ci - 1].Ho * b.c[ci - 1].Wo;
+                const void* dy_prev = DY;
+                (void)dy_prev;
+                RC(next_dy());
                 RC(bn_bwd(c, b.b[ci - 1], DA, nullptr, true, b.y[ci - 1], rows, DY, nullptr, grads));
             } else {
                 RC(dgrad(c, b.c[0], DY, DX, true));
             }
         }
         std::swap(Z, DX);
-        // gradient buckets: every parameter of blocks >= bi is final here -- let the caller start its all-reduce
+        // gradient buckets: every parameter of blocks >= bi is final once BOTH streams have passed this point -- the
+        // bucket event is recorded on the side stream behind a join with the main stream
         for (int e = 0; e < n_events; ++e)
-            if (event_blocks[e] == bi) VINCE_CHECK_HIP(hipEventRecord((hipEvent_t)events[e], (hipStream_t)stream));
+            if (event_blocks[e] == bi) {
+                if (overlap) {
+                    VINCE_CHECK_HIP(hipEventRecord(t->ev_join, main_s));
+                    VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_join, 0));
+                    VINCE_CHECK_HIP(hipEventRecord((hipEvent_t)events[e], t->side));
+                } else {
+                    VINCE_CHECK_HIP(hipEventRecord((hipEvent_t)events[e], main_s));
+                }
+            }
     }
     // stem: Z = gradient wrt the pooled stem output
     RC(vince_stem_pool_bwd(c.dtype, Z, (const uint8_t*)at(workspace, t->off_amax), DA, N, t->sH, t->sW, 64, stream));
+    RC(next_dy());
     RC(bn_bwd(c, t->stem_bn, DA, nullptr, false, t->off_ystem, (int64_t)N * t->sH * t->sW, DY, nullptr, grads));
-    {
-        vince_conv_desc d = fwd_desc(t, t->stem);
-        RC(vince_conv_wgrad(&d, c.dtype, at(workspace, t->off_x0), DY, grads[t->stem.param], 3, 0, stream));
+    RC(wgrad_async(fwd_desc(t, t->stem), at(workspace, t->off_x0), grads[t->stem.param], 3));
+    if (overlap) {   // the caller's stream continues only after every weight gradient has landed
+        VINCE_CHECK_HIP(hipEventRecord(t->ev_join, t->side));
+        VINCE_CHECK_HIP(hipStreamWaitEvent(main_s, t->ev_join, 0));
+        for (int i = 0; i < 3; ++i) t->wg_pending[i] = false;
     }
     return VINCE_OK;
 }
