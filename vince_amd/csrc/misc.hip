@@ -259,7 +259,7 @@ extern "C" int vince_prepare_weight(int dtype, const float* w, void* wk, void* w
 extern "C" int vince_prepare_weights_batched(int dtype, const vince_prep_entry* table_dev, int32_t n, void* stream) {
     DTYPE_OK("vince_prepare_weights_batched");
     VINCE_CHECK_ARG(table_dev && n > 0, VINCE_E_ARG, "vince_prepare_weights_batched: bad arguments");
-    const dim3 grid(64, n);
+    const dim3 grid(512, n);   // blocks beyond a small layer's element count fall through the grid-stride loop at once
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(prepare_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
     else
