@@ -189,16 +189,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + tr;
     const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
     if (cv) {
-        for (int64_t r = r0; r < r1; r += w.rpp) {
-            const size_t off = (size_t)r * C + (size_t)col * CH;
-            float g[CH], yy[CH];
-            Chunk<T>::unpack(*(const uint4*)(dz + off), g);
-            Chunk<T>::unpack(*(const uint4*)(y + off), yy);
-            apply_mask<T, CH>(msk, off, (size_t)r * w.cpr + col, yy, msc, msh, g);
+        constexpr int U = 4;   // rows per trip, all loads issued before the arithmetic (more bytes in flight)
+        for (int64_t rb = r0; rb < r1; rb += (int64_t)U * w.rpp) {
+            uint4 dv[U], yv[U];
 #pragma unroll
-            for (int e = 0; e < CH; ++e) {
-                sg[e] += g[e];
-                sgx[e] += g[e] * (yy[e] - mu[e]) * is[e];
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = rb + (int64_t)u * w.rpp;
+                if (r < r1) {
+                    const size_t off = (size_t)r * C + (size_t)col * CH;
+                    dv[u] = *(const uint4*)(dz + off);
+                    yv[u] = *(const uint4*)(y + off);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = rb + (int64_t)u * w.rpp;
+                if (r >= r1) break;
+                const size_t off = (size_t)r * C + (size_t)col * CH;
+                float g[CH], yy[CH];
+                Chunk<T>::unpack(dv[u], g);
+                Chunk<T>::unpack(yv[u], yy);
+                apply_mask<T, CH>(msk, off, (size_t)r * w.cpr + col, yy, msc, msh, g);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    sg[e] += g[e];
+                    sgx[e] += g[e] * (yy[e] - mu[e]) * is[e];
+                }
             }
         }
     }
@@ -260,17 +276,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
     const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + threadIdx.x / w.tpc;
     const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
-    for (int64_t r = r0; r < r1; r += w.rpp) {
-        const size_t off = (size_t)r * C + (size_t)col * CH;
-        float g[CH], yy[CH];
-        Chunk<T>::unpack(*(const uint4*)(dz + off), g);
-        Chunk<T>::unpack(*(const uint4*)(y + off), yy);
-        apply_mask<T, CH>(msk, off, (size_t)r * w.cpr + col, yy, msc, msh, g);
-        if (gout) *(uint4*)(gout + off) = Chunk<T>::pack(g);
-        float o[CH];
+    constexpr int U = 4;
+    for (int64_t rb = r0; rb < r1; rb += (int64_t)U * w.rpp) {
+        uint4 dv[U], yv[U];
 #pragma unroll
-        for (int e = 0; e < CH; ++e) o[e] = k1[e] * (g[e] - ma[e] - (yy[e] - mu[e]) * is[e] * mb[e]);
-        *(uint4*)(dy + off) = Chunk<T>::pack(o);
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + (int64_t)u * w.rpp;
+            if (r < r1) {
+                const size_t off = (size_t)r * C + (size_t)col * CH;
+                dv[u] = *(const uint4*)(dz + off);
+                yv[u] = *(const uint4*)(y + off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + (int64_t)u * w.rpp;
+            if (r >= r1) break;
+            const size_t off = (size_t)r * C + (size_t)col * CH;
+            float g[CH], yy[CH];
+            Chunk<T>::unpack(dv[u], g);
+            Chunk<T>::unpack(yv[u], yy);
+            apply_mask<T, CH>(msk, off, (size_t)r * w.cpr + col, yy, msc, msh, g);
+            if (gout) *(uint4*)(gout + off) = Chunk<T>::pack(g);
+            float o[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) o[e] = k1[e] * (g[e] - ma[e] - (yy[e] - mu[e]) * is[e] * mb[e]);
+            *(uint4*)(dy + off) = Chunk<T>::pack(o);
+        }
     }
 }
 
