@@ -186,11 +186,14 @@ def main():
 
     if rank == 0 and world == 1 and not opt.no_extras:
         # ---- roofline leg: hipEvent pairs around every conv launch for a few extra steps -------------------------
+        # (streams are serialised for these steps so that every launch's event pair times that kernel running alone)
         L = lib()
         L.vince_profile_enable(1)
+        saved_overlap, solver.overlap_key_encoder = solver.overlap_key_encoder, False
         for _ in range(opt.profile_steps):
             solver.run_train_iteration()
         torch.cuda.synchronize()
+        solver.overlap_key_encoder = saved_overlap
         L.vince_profile_enable(0)
         n = len(KERNEL_TAGS)
         ms, fl, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_int64 * n)()

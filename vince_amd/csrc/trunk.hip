@@ -467,7 +467,9 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     // the optimiser needs its result, so it overlaps the BatchNorm-backward / dgrad chain of the layers below (compute-
     // bound MFMA work next to HBM-bound streams).  dY lives in a 3-slot ring; a slot is rewritten only after the wgrad
     // that read it has finished (ev_wg), and a wgrad starts when its dY is complete (ev_dy).
-    static const bool overlap = !(getenv("VINCE_WGRAD_STREAM") && atoi(getenv("VINCE_WGRAD_STREAM")) == 0);
+    // (per-kernel event timing wants kernels to run alone: overlap is off while vince_profile_enable(1) is in effect)
+    static const bool overlap_env = !(getenv("VINCE_WGRAD_STREAM") && atoi(getenv("VINCE_WGRAD_STREAM")) == 0);
+    const bool overlap = overlap_env && !vince_profile_enabled();
     hipStream_t main_s = (hipStream_t)stream;
     if (overlap && !t->side) {
         VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
