@@ -78,14 +78,35 @@ typedef struct vince_conv_desc {
 #define VINCE_STATS_REPLICAS 16
 
 /* epilogue flags */
-#define VINCE_EPI_ACCUMULATE 1 /* out += result (residual-gradient add) */
+#define VINCE_EPI_ACCUMULATE 1 /* out = result + out (residual-gradient add); with acc_mask: out = result + out*mask */
 #define VINCE_EPI_RELU 2       /* max(.,0) after bias */
+
+/* Optional fused BatchNorm-backward reduction: when the tensor a dgrad launch writes is the gradient dz that a
+ * BatchNorm(+ReLU) backward consumes next, the epilogue also accumulates that BatchNorm's (sum g, sum g*xhat) over the
+ * values it stores -- g = stored dz * relu-mask, xhat = (y - mean) * invstd -- into sums[R][C][2], i.e. exactly what
+ * vince_bn_bwd_reduce would compute in a separate pass over dz and y (autograd of resnet.py:69-72,110-135).
+ * Mask: mask_bits (1 byte per 16-byte chunk, as written by vince_bn_apply), or mask_scale/mask_shift
+ * (sign of y*scale+shift), or neither (no ReLU). */
+typedef struct vince_bn_reduce {
+    const void* y;            /* BatchNorm input (conv output), same shape and dtype as this launch's `out` */
+    const uint8_t* mask_bits;
+    const float* mask_scale;
+    const float* mask_shift;
+    const float* mean;        /* saved batch mean / inverse std (vince_bn_finalize) */
+    const float* invstd;
+    double* sums;             /* double[R][C][2], zeroed by the caller, R = VINCE_STATS_REPLICAS */
+} vince_bn_reduce;
 
 /* in/w/out have element type `dtype`; `out_f32 != 0` stores float output regardless of dtype (f32 only today).
  * bias: optional float[Co].  stats: optional double[R][Co][2] -- per-channel (sum, sum of squares) of the STORED
- * output values, atomically accumulated (feeds vince_bn_finalize; nn.BatchNorm2d train mode, resnet.py:69). */
+ * output values, atomically accumulated (feeds vince_bn_finalize; nn.BatchNorm2d train mode, resnet.py:69).
+ * acc_mask: optional, only with VINCE_EPI_ACCUMULATE: one byte per 16-byte chunk of `out` (the ReLU bits written by
+ * vince_bn_apply); bit e gates element e of the chunk, so the residual join `out = dgrad + out * (z > 0)`
+ * (autograd of resnet.py:132-133) happens in place without materialising the masked gradient.
+ * bnred: optional (not together with stats), see vince_bn_reduce above. */
 int vince_conv_igemm(const vince_conv_desc* d, int dtype, const void* in, const void* w, void* out,
-                     const float* bias, double* stats, int flags, void* stream);
+                     const float* bias, double* stats, const uint8_t* acc_mask, const vince_bn_reduce* bnred,
+                     int flags, void* stream);
 
 /* Weight gradient (wgrad) of the same generalised conv, reduction over output pixels:
  *   dw[co, wt(a,b), ci] += sum_{n,ho,wo} dy[n,ho,wo,co] * in[n, ho*sh+dh0+a*dhs, wo*sw+dw0+b*dws, ci]

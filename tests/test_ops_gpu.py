@@ -141,6 +141,32 @@ def test_conv_dgrad_wgrad(cfg, dtype):
     for d in descs:
         ops.conv_igemm(d, dyg, wt, dx, flags=ops.EPI_ACCUMULATE)
     assert_close(from_nhwc(dx), 2 * x.grad, dtype, bf16=3e-2, what="dgrad accumulate")
+    if s == 1:
+        # masked accumulate (residual join): out = dgrad + out * bit, one byte per 16-byte chunk of `out`
+        ch = 4 if dtype == torch.float32 else 8
+        old = q(rnd(N, Ci, H, W, seed=21), dtype)
+        bits = torch.randint(0, 256, (N, H, W, Ci // ch), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+        keep = ((bits.unsqueeze(-1) >> torch.arange(ch, dtype=torch.uint8)) & 1).reshape(N, H, W, Ci).permute(0, 3, 1, 2)
+        dx = to_nhwc(old, dtype).clone()
+        ops.conv_igemm(descs[0], dyg, wt, dx, flags=ops.EPI_ACCUMULATE, acc_mask=bits.to(DEV))
+        assert_close(from_nhwc(dx), x.grad + old * keep.float(), dtype, bf16=3e-2, what="dgrad masked accumulate")
+    # fused BatchNorm-backward reduction in the dgrad epilogue == the stand-alone reduction over the stored gradient
+    yb = to_nhwc(q(rnd(N, Ci, H, W, seed=22), dtype), dtype)
+    mean, invstd = rnd(Ci, seed=23).to(DEV), (rnd(Ci, seed=24).abs() + 0.5).to(DEV)
+    msc, msh = rnd(Ci, seed=25).to(DEV), rnd(Ci, seed=26, scale=0.3).to(DEV)
+    ch = 4 if dtype == torch.float32 else 8
+    mbits = torch.randint(0, 256, (N, H, W, Ci // ch), dtype=torch.uint8, generator=torch.Generator().manual_seed(4)).to(DEV)
+    for kind in ("none", "bits", "self"):
+        kw = {"bits": dict(mask_bits=mbits), "self": dict(mask_scale=msc, mask_shift=msh), "none": {}}[kind]
+        sums = torch.zeros(ops.STATS_REPLICAS, Ci, 2, device=DEV, dtype=torch.float64)
+        dx = torch.zeros(N, H, W, Ci, device=DEV, dtype=dtype)
+        br = ops.bn_reduce_arg(yb, mean, invstd, sums, **kw)
+        for d in descs:
+            ops.conv_igemm(d, dyg, wt, dx, bnred=br)
+        want = ops.bn_bwd_reduce(dx, yb, mean, invstd, **kw)
+        got = sums.sum(0)
+        scale = float(want.abs().max()) + 1e-6
+        assert float((got - want).abs().max()) / scale < 1e-5, ("fused bn reduce", kind, float((got - want).abs().max()), scale)
     # wgrad, both operand-fetch variants
     fd = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
     ref_dw = w.grad.permute(0, 2, 3, 1).reshape(Co, k * k, Ci)

@@ -1,8 +1,12 @@
-"""Reads bench.py's JSON line on stdin and prints a brief summary (label from argv[1])."""
+"""Prints a brief summary of bench.py's JSON line.  Usage: bench_brief.py FILE [label]   (FILE '-' = stdin)"""
 import json
 import sys
 
-d = json.loads(sys.stdin.read())
+src = sys.argv[1] if len(sys.argv) > 1 else "-"
+text = sys.stdin.read() if src == "-" else open(src).read()
+line = [l for l in text.splitlines() if l.startswith("{")][-1]
+d = json.loads(line)
 k = d.get("kernels", {})
-print(sys.argv[1] if len(sys.argv) > 1 else "", d["value"], d["ms_per_step"],
-      {n: (v["ms_per_step"], v["tflops"]) for n, v in k.items()})
+r = d.get("roofline") or {}
+print(sys.argv[2] if len(sys.argv) > 2 else src, d["value"], d["ms_per_step"], r.get("achieved"), r.get("frac"),
+      d.get("fwd_infonce"), {n: (v["ms_per_step"], v["tflops"]) for n, v in k.items()})

@@ -18,6 +18,10 @@ class ConvDesc(ctypes.Structure):
         "wt0", "wta", "wtb", "WT", "OH", "OW", "osh", "osw", "oh0", "ow0")]
 
 
+class BnReduce(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("y", "mask_bits", "mask_scale", "mask_shift", "mean", "invstd", "sums")]
+
+
 class InfoNCEDesc(ctypes.Structure):
     _fields_ = [("B", c_int32), ("D", c_int32), ("Bk", c_int32), ("K", c_int32), ("frames", c_int32),
                 ("offdiag_neg", c_int32), ("inv_temperature", c_float)]
@@ -34,7 +38,8 @@ PROTOTYPES = {
     "vince_abi_version": (c_int, []),
     "vince_profile_enable": (c_int, [c_int]),
     "vince_profile_collect": (c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
-    "vince_conv_igemm": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vince_conv_igemm": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, P(BnReduce),
+                                 c_int, c_void_p]),
     "vince_conv_wgrad": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_void_p]),
     "vince_bn_finalize": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                   c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -20,6 +20,7 @@
 //   Grid:  1-D, remapped so that each XCD (private L2) owns a contiguous range of tiles; channel tiles of the
 //          same pixel tile are adjacent and re-read the activation tile from that L2.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -36,6 +37,8 @@ struct ConvParams {
     uint32_t in_bytes, w_bytes;   // buffer-descriptor ranges for the direct-to-LDS variant (0 = tensor too large)
     const float* bias;
     double* stats;
+    const uint8_t* acc_mask;
+    vince_bn_reduce br;   // br.y == nullptr: no fused BatchNorm-backward reduction
     int flags;
 };
 
@@ -70,7 +73,7 @@ struct Smem {
     static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
 };
 
-template <typename T, int CT, int CRS, int PTL = PT>
+template <typename T, int CT, int CRS, int PTL = PT, int UBM = 4>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char* smem, f32x16_t (&acc)[CT / 64][PTL / 64],
                                               uint32_t tile, int p0, int c0, int tid, int lane, int wave, int wp, int wc) {
     constexpr int CH = Elem<T>::CH;
@@ -110,45 +113,99 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     for (int e = 0; e < CH; ++e) ssum[e] = ssq[e] = 0.f;
     T* __restrict__ out = (T*)p.out;
     const bool identity_map = (d.osh == 1 && d.osw == 1 && d.oh0 == 0 && d.ow0 == 0 && d.OH == d.Ho && d.OW == d.Wo);
-    for (int row = row0; row < PTL; row += RPP) {
-        const uint32_t m = p0 + row;
-        if (m >= (uint32_t)p.M || !cvalid) continue;
-        size_t opix = m;
-        if (!identity_map) {
-            uint32_t n = fastdiv(m, p.div_howo);
-            uint32_t rem = m - n * p.div_howo.d;
-            uint32_t ho = fastdiv(rem, p.div_wo);
-            uint32_t wo = rem - ho * p.div_wo.d;
-            opix = ((size_t)n * d.OH + (ho * d.osh + d.oh0)) * d.OW + (wo * d.osw + d.ow0);
-        }
-        uint4 v = *(const uint4*)(smem + row * CRS + chunk * 16);
-        T* optr = out + opix * d.Co + cbase;
-        if (p.bias || (p.flags & (VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU))) {
-            float f[CH];
-            Chunk<T>::unpack(v, f);
+    const bool accum = (p.flags & VINCE_EPI_ACCUMULATE) != 0;
+    const bool touch = p.bias || (p.flags & (VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU));
+    // fused BatchNorm-backward reduction (p.br): per-channel constants of the BatchNorm that consumes this gradient
+    const T* __restrict__ br_y = (const T*)p.br.y;
+    float br_mu[CH], br_is[CH], br_sc[CH], br_sh[CH];
 #pragma unroll
-            for (int e = 0; e < CH; ++e) f[e] += bias_v[e];
-            if (p.flags & VINCE_EPI_ACCUMULATE) {
-                float o[CH];
-                Chunk<T>::unpack(*(const uint4*)optr, o);
+    for (int e = 0; e < CH; ++e) {
+        const bool on = br_y && cvalid;
+        br_mu[e] = on ? p.br.mean[cbase + e] : 0.f;
+        br_is[e] = on ? p.br.invstd[cbase + e] : 0.f;
+        br_sc[e] = (on && p.br.mask_scale) ? p.br.mask_scale[cbase + e] : 0.f;
+        br_sh[e] = (on && p.br.mask_scale) ? p.br.mask_shift[cbase + e] : 0.f;
+    }
+    constexpr int NR = PTL / RPP;            // rows this thread stores
+    constexpr int UB = NR < UBM ? NR : UBM;  // rows per batch: every global load of a batch is issued before its arithmetic
+    for (int rb = 0; rb < NR; rb += UB) {
+        size_t off[UB];
+        bool ok[UB];
+        uint4 oldv[UB], yv[UB];
+        uint32_t ab[UB], bb[UB];
 #pragma unroll
-                for (int e = 0; e < CH; ++e) f[e] += o[e];
+        for (int u = 0; u < UB; ++u) {
+            const int row = row0 + (rb + u) * RPP;
+            const uint32_t m = p0 + row;
+            ok[u] = cvalid && m < (uint32_t)p.M;
+            size_t opix = m;
+            if (!identity_map) {
+                uint32_t n = fastdiv(m, p.div_howo);
+                uint32_t rem = m - n * p.div_howo.d;
+                uint32_t ho = fastdiv(rem, p.div_wo);
+                uint32_t wo = rem - ho * p.div_wo.d;
+                opix = ((size_t)n * d.OH + (ho * d.osh + d.oh0)) * d.OW + (wo * d.osw + d.ow0);
             }
-            if (p.flags & VINCE_EPI_RELU) {
-#pragma unroll
-                for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
+            off[u] = opix * d.Co + cbase;
+            ab[u] = bb[u] = 0xffu;
+            if (ok[u]) {
+                if (accum) {
+                    oldv[u] = *(const uint4*)(out + off[u]);
+                    if (p.acc_mask) ab[u] = p.acc_mask[off[u] / CH];
+                }
+                if (br_y) {
+                    yv[u] = *(const uint4*)(br_y + off[u]);
+                    if (p.br.mask_bits) bb[u] = p.br.mask_bits[off[u] / CH];
+                }
             }
-            v = Chunk<T>::pack(f);
         }
-        *(uint4*)optr = v;
-        if (p.stats) {
-            float f[CH];
-            Chunk<T>::unpack(v, f);
 #pragma unroll
-            for (int e = 0; e < CH; ++e) { ssum[e] += f[e]; ssq[e] += f[e] * f[e]; }
+        for (int u = 0; u < UB; ++u) {
+            if (!ok[u]) continue;
+            const int row = row0 + (rb + u) * RPP;
+            uint4 v = *(const uint4*)(smem + row * CRS + chunk * 16);
+            if (touch) {
+                float f[CH];
+                Chunk<T>::unpack(v, f);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) f[e] += bias_v[e];
+                if (accum) {
+                    float o[CH];
+                    Chunk<T>::unpack(oldv[u], o);
+                    // residual join: the old value passes through the ReLU of the block output (acc_mask bits)
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) f[e] += ((ab[u] >> e) & 1u) ? o[e] : 0.f;
+                }
+                if (p.flags & VINCE_EPI_RELU) {
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
+                }
+                v = Chunk<T>::pack(f);
+            }
+            *(uint4*)(out + off[u]) = v;
+            if (p.stats) {
+                float f[CH];
+                Chunk<T>::unpack(v, f);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) { ssum[e] += f[e]; ssq[e] += f[e] * f[e]; }
+            } else if (br_y) {
+                // (sum g, sum g*xhat) of the STORED gradient g = v * relu-mask, exactly what vince_bn_bwd_reduce computes
+                float g[CH], yy[CH];
+                Chunk<T>::unpack(v, g);
+                Chunk<T>::unpack(yv[u], yy);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    bool keep = ((bb[u] >> e) & 1u) != 0;
+                    if (p.br.mask_scale) keep = (yy[e] * br_sc[e] + br_sh[e]) > 0.f;
+                    const float ge = keep ? g[e] : 0.f;
+                    ssum[e] += ge;
+                    ssq[e] += ge * (yy[e] - br_mu[e]) * br_is[e];
+                }
+            }
         }
     }
-    if (p.stats) {   // uniform branch
+    double* const red_out = p.stats ? p.stats : p.br.sums;
+    if (red_out) {   // uniform branch
         float* red = (float*)(smem + PTL * CRS);      // [4 waves][CPR][CH][2]
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
@@ -175,7 +232,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
 #pragma unroll
             for (int w = 0; w < 4; ++w) s += red[((w * CPR + ck) * CH + e) * 2 + which];
             if (c0 + ch < d.Co)
-                unsafeAtomicAdd(p.stats + ((size_t)(tile % VINCE_STATS_REPLICAS) * d.Co + (c0 + ch)) * 2 + which, (double)s);
+                unsafeAtomicAdd(red_out + ((size_t)(tile % VINCE_STATS_REPLICAS) * d.Co + (c0 + ch)) * 2 + which, (double)s);
         }
     }
 }
@@ -453,7 +510,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     }
     wait_vmcnt<0>();
     __syncthreads();
-    conv_epilogue<T, CT, S::CRS, PTL>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
+    // rows in flight per thread in the epilogue: the 128-VGPR (4 workgroups/CU) configuration has no room for more than 2
+    conv_epilogue<T, CT, S::CRS, PTL, (MINW >= 4 ? 2 : 4)>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
 template <typename T, int CT>
@@ -512,8 +570,14 @@ int launch(ConvParams& p, hipStream_t stream) {
 }  // namespace
 
 extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void* in, const void* w, void* out,
-                                const float* bias, double* stats, int flags, void* stream) {
+                                const float* bias, double* stats, const uint8_t* acc_mask, const vince_bn_reduce* bnred,
+                                int flags, void* stream) {
     VINCE_CHECK_ARG(dd && in && w && out, VINCE_E_ARG, "vince_conv_igemm: null pointer");
+    VINCE_CHECK_ARG(!acc_mask || (flags & VINCE_EPI_ACCUMULATE), VINCE_E_ARG, "vince_conv_igemm: acc_mask needs VINCE_EPI_ACCUMULATE");
+    VINCE_CHECK_ARG(!bnred || (bnred->y && bnred->mean && bnred->invstd && bnred->sums && !stats), VINCE_E_ARG,
+                    "vince_conv_igemm: bnred needs y, mean, invstd and sums, and excludes stats");
+    VINCE_CHECK_ARG(!bnred || (!bnred->mask_scale == !bnred->mask_shift), VINCE_E_ARG,
+                    "vince_conv_igemm: bnred mask_scale and mask_shift come together");
     VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_igemm: bad dtype %d", dtype);
     const vince_conv_desc& d = *dd;
     const int CH = dtype == VINCE_F32 ? 4 : 8;
@@ -546,7 +610,8 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.tb_mul = (65536 + d.TB - 1) / d.TB;
     p.div_howo = make_fastdiv((uint32_t)(d.Ho * d.Wo));
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
-    p.in = in; p.w = w; p.out = out; p.bias = bias; p.stats = stats; p.flags = flags;
+    p.in = in; p.w = w; p.out = out; p.bias = bias; p.stats = stats; p.acc_mask = acc_mask; p.flags = flags;
+    if (bnred) p.br = *bnred; else memset(&p.br, 0, sizeof(p.br));
     static int ablate = getenv("VINCE_CONV_ABLATE") ? atoi(getenv("VINCE_CONV_ABLATE")) : 0;   // measurement aid only
     p.ablate = ablate;
     {

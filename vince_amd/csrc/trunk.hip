@@ -332,7 +332,7 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
                 int64_t* const* bn_nbt, int train_bn) {
     vince_conv_desc d = fwd_desc(c.t, cv);
     RC(vince_conv_igemm(&d, c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), nullptr,
-                        train_bn ? c.stats(bn) : nullptr, 0, c.stream));
+                        train_bn ? c.stats(bn) : nullptr, nullptr, nullptr, 0, c.stream));
     const int64_t count = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
     RC(vince_bn_finalize(c.stats(bn), count, bn.C, c.params[bn.gamma], c.params[bn.beta], bn_running[2 * bn.index],
                          bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr, 0.1f, 1e-5f, train_bn,
@@ -340,14 +340,15 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
     return VINCE_OK;
 }
 
-int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate) {
+int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, const uint8_t* acc_mask = nullptr,
+          const vince_bn_reduce* bnred = nullptr) {
     vince_conv_desc ds[4];
     const int n = dgrad_descs(c.t, cv, ds);
     const int classes = cv.stride * cv.stride;
     if (!accumulate && n < classes)   // some pixel classes receive no gradient (1x1 stride 2): zero them
         VINCE_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)c.t->cfg.N * cv.Hi * cv.Wi * cv.Ci * c.t->esize, (hipStream_t)c.stream));
     for (int i = 0; i < n; ++i)
-        RC(vince_conv_igemm(&ds[i], c.dtype, dy, at((void*)c.wcache, cv.wt), dx, nullptr, nullptr,
+        RC(vince_conv_igemm(&ds[i], c.dtype, dy, at((void*)c.wcache, cv.wt), dx, nullptr, nullptr, acc_mask, bnred,
                             accumulate ? VINCE_EPI_ACCUMULATE : 0, c.stream));
     return VINCE_OK;
 }
@@ -360,16 +361,30 @@ int wgrad(Ctx& c, const ConvL& cv, const void* in, const void* dy, float* dw) {
 // BN backward for y (conv output) given the gradient dz wrt the activation that followed this BatchNorm.
 // ReLU mask: `bits` (residual outputs: bytes written by the forward bn_apply), `self_mask` (plain BN+ReLU: the sign
 // of y*scale+shift is recomputed from y, which is read anyway), or none (no ReLU: the stem's pooled gradient).
+// `reduced`: the (sum g, sum g*xhat) pass already ran inside the epilogue of the dgrad that produced dz (bn_reduce_of).
 int bn_bwd(Ctx& c, const BnL& bn, const void* dz, const uint8_t* bits, bool self_mask, size_t y_off, int64_t rows, void* dy,
-           void* g_out, float* const* grads) {
+           void* g_out, float* const* grads, bool reduced = false) {
     const float* msc = self_mask ? c.consts(bn, 0) : nullptr;
     const float* msh = self_mask ? c.consts(bn, 1) : nullptr;
-    RC(vince_bn_bwd_reduce(c.dtype, dz, nullptr, bits, msc, msh, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3), c.sums(bn),
-                           rows, bn.C, c.stream));
+    if (!reduced)
+        RC(vince_bn_bwd_reduce(c.dtype, dz, nullptr, bits, msc, msh, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3),
+                               c.sums(bn), rows, bn.C, c.stream));
     RC(vince_bn_bwd_apply(c.dtype, dz, nullptr, bits, msc, msh, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3),
                           c.params[bn.gamma], c.sums(bn), rows, dy, g_out, grads[bn.gamma], grads[bn.beta], rows, bn.C,
                           c.stream));
     return VINCE_OK;
+}
+
+vince_bn_reduce bn_reduce_of(Ctx& c, const BnL& bn, const uint8_t* bits, bool self_mask, size_t y_off) {
+    vince_bn_reduce r;
+    r.y = at(c.ws, y_off);
+    r.mask_bits = bits;
+    r.mask_scale = self_mask ? c.consts(bn, 0) : nullptr;
+    r.mask_shift = self_mask ? c.consts(bn, 1) : nullptr;
+    r.mean = c.consts(bn, 2);
+    r.invstd = c.consts(bn, 3);
+    r.sums = c.sums(bn);
+    return r;
 }
 
 }  // namespace
@@ -507,6 +522,10 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     void* DA = at(workspace, t->off_g[1]);
     void* DX = at(workspace, t->off_g[2]);
     RC(vince_avgpool_bwd(c.dtype, dpooled, Z, N, t->outH * t->outW, t->outC, stream));
+    // BatchNorm-backward reductions ride in the epilogue of the dgrad that produces their input gradient
+    // (VINCE_FUSE_BNRED=0 runs them as separate passes: measurement aid)
+    static const bool fuse_red = !(getenv("VINCE_FUSE_BNRED") && atoi(getenv("VINCE_FUSE_BNRED")) == 0);
+    bool last_reduced = false;   // was the last-BN reduction of the current block done by the block above it?
     for (int bi = (int)t->blocks.size() - 1; bi >= 0; --bi) {
         const Blk& b = t->blocks[bi];
         const int L = b.nconv - 1;
@@ -521,26 +540,35 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             RC(wgrad_layer(b.cd, x_in));
             RC(dgrad(c, b.cd, DY, DX, false));
             RC(next_dy());
-            RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, nullptr, grads));
+            RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, nullptr, grads, last_reduced));
         } else {
+            // identity branch: g = dz * (z > 0) is never materialised -- the block-input dgrad below joins it in place
             RC(next_dy());
-            RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, DX, grads));   // DX <- g (identity branch)
+            RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, nullptr, grads, last_reduced));
         }
         for (int ci = L; ci >= 0; --ci) {
             const void* in_act = ci == 0 ? x_in : at(workspace, b.a[ci - 1]);
             RC(wgrad_layer(b.c[ci], in_act));
             if (ci > 0) {
-                RC(dgrad(c, b.c[ci], DY, DA, false));
+                vince_bn_reduce br = bn_reduce_of(c, b.b[ci - 1], nullptr, true, b.y[ci - 1]);
+                RC(dgrad(c, b.c[ci], DY, DA, false, nullptr, fuse_red ? &br : nullptr));
                 const int64_t rows = (int64_t)N * b.c[ci - 1].Ho * b.c[ci - 1].Wo;
-                const void* dy_prev = DY;
-                (void)dy_prev;
                 RC(next_dy());
-                RC(bn_bwd(c, b.b[ci - 1], DA, nullptr, true, b.y[ci - 1], rows, DY, nullptr, grads));
+                RC(bn_bwd(c, b.b[ci - 1], DA, nullptr, true, b.y[ci - 1], rows, DY, nullptr, grads, fuse_red));
             } else {
-                RC(dgrad(c, b.c[0], DY, DX, true));
+                // block-input gradient; it is the dz of the block below, whose last BatchNorm's reduction is fused here
+                vince_bn_reduce br;
+                const bool fuse = fuse_red && bi > 0;
+                if (fuse) {
+                    const Blk& lo = t->blocks[bi - 1];
+                    br = bn_reduce_of(c, lo.b[lo.nconv - 1], (const uint8_t*)at(workspace, lo.zmask), false, lo.y[lo.nconv - 1]);
+                }
+                if (b.has_ds) RC(dgrad(c, b.c[0], DY, DX, true, nullptr, fuse ? &br : nullptr));
+                else RC(dgrad(c, b.c[0], DY, Z, true, zbits, fuse ? &br : nullptr));   // Z <- dgrad + Z * (z > 0)
+                last_reduced = fuse;
             }
         }
-        std::swap(Z, DX);
+        if (b.has_ds) std::swap(Z, DX);
         // gradient buckets: every parameter of blocks >= bi is final once BOTH streams have passed this point -- the
         // bucket event is recorded on the side stream behind a join with the main stream
         for (int e = 0; e < n_events; ++e)

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, InfoNCEDesc, VINCE_BF16, VINCE_F32, check, lib
+from ._lib import BnReduce, ConvDesc, InfoNCEDesc, VINCE_BF16, VINCE_F32, check, lib
 
 EPI_ACCUMULATE, EPI_RELU = _lib.EPI_ACCUMULATE, _lib.EPI_RELU
 STATS_REPLICAS = 16   # VINCE_STATS_REPLICAS in include/vince_hip.h
@@ -78,10 +78,20 @@ def linear_desc(rows, cin, cout):
     return conv_desc(rows, 1, 1, cin, cout, 1, 1, 0)
 
 
-def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0):
-    require_gpu(x, w, out, bias, stats)
+def bn_reduce_arg(y, mean, invstd, sums, mask_bits=None, mask_scale=None, mask_shift=None):
+    """vince_bn_reduce for conv_igemm(bnred=...): fuse a BatchNorm-backward reduction into a dgrad epilogue."""
+    require_gpu(y, mean, invstd, sums, mask_bits, mask_scale, mask_shift)
+    r = BnReduce(y.data_ptr(), None if mask_bits is None else mask_bits.data_ptr(),
+                 None if mask_scale is None else mask_scale.data_ptr(), None if mask_shift is None else mask_shift.data_ptr(),
+                 mean.data_ptr(), invstd.data_ptr(), sums.data_ptr())
+    r._keep = (y, mean, invstd, sums, mask_bits, mask_scale, mask_shift)
+    return r
+
+
+def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None):
+    require_gpu(x, w, out, bias, stats, acc_mask)
     check(lib().vince_conv_igemm(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(stats),
-                                 flags, stream_ptr()))
+                                 _ptr(acc_mask), None if bnred is None else ctypes.byref(bnred), flags, stream_ptr()))
     return out
 
 
@@ -160,6 +170,17 @@ def bn_apply(y, scale, shift, identity=None, id_scale=None, id_shift=None, relu=
     check(lib().vince_bn_apply(dtype_code(y), _ptr(y), _ptr(scale), _ptr(shift), _ptr(identity), _ptr(id_scale),
                                _ptr(id_shift), _ptr(out), _ptr(mask), y.numel() // C, C, int(relu), stream_ptr()))
     return (out, mask) if want_mask else out
+
+
+def bn_bwd_reduce(dz, y, mean, invstd, mask_src=None, mask_bits=None, mask_scale=None, mask_shift=None):
+    """(sum g, sum g*xhat) per channel, replicas folded: the stand-alone pass the fused dgrad epilogue replaces."""
+    require_gpu(dz, y, mean, invstd, mask_src, mask_bits, mask_scale, mask_shift)
+    C = y.shape[-1]
+    rows = y.numel() // C
+    sums = torch.zeros(STATS_REPLICAS, C, 2, device=y.device, dtype=torch.float64)
+    check(lib().vince_bn_bwd_reduce(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(mask_bits), _ptr(mask_scale),
+                                    _ptr(mask_shift), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums), rows, C, stream_ptr()))
+    return sums.sum(0)
 
 
 def bn_bwd(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, want_g=False, mask_bits=None, mask_scale=None,
