@@ -225,6 +225,8 @@ def main():
         out["kernels"] = kernels
         # ---- cpu_baseline leg ----------------------------------------------------------------------------------------
         try:
+            if opt.cpu_steps <= 0:
+                raise RuntimeError("skipped (--cpu-steps 0)")
             cores = torch.get_num_threads()
             cb, csteps = 16, opt.cpu_steps
             v = cpu_baseline(opt.backbone, opt.embed, opt.queue, opt.temperature, opt.size, cb, csteps)

@@ -79,7 +79,7 @@ typedef struct vince_conv_desc {
 
 /* epilogue flags */
 #define VINCE_EPI_ACCUMULATE 1 /* out = result + out (residual-gradient add); with acc_mask: out = result + out*mask */
-#define VINCE_EPI_RELU 2       /* max(.,0) after bias */
+#define VINCE_EPI_RELU 2       /* max(.,0) last */
 
 /* Optional fused BatchNorm-backward reduction: when the tensor a dgrad launch writes is the gradient dz that a
  * BatchNorm(+ReLU) backward consumes next, the epilogue also accumulates that BatchNorm's (sum g, sum g*xhat) over the
@@ -88,7 +88,7 @@ typedef struct vince_conv_desc {
  * Mask: mask_bits (1 byte per 16-byte chunk, as written by vince_bn_apply), or mask_scale/mask_shift
  * (sign of y*scale+shift), or neither (no ReLU). */
 typedef struct vince_bn_reduce {
-    const void* y;            /* BatchNorm input (conv output), same shape and dtype as this launch's `out` */
+    const void* y;            /* BatchNorm input (conv output), same shape and dtype as this launch's `out`; NULL = off */
     const uint8_t* mask_bits;
     const float* mask_scale;
     const float* mask_shift;
@@ -97,16 +97,21 @@ typedef struct vince_bn_reduce {
     double* sums;             /* double[R][C][2], zeroed by the caller, R = VINCE_STATS_REPLICAS */
 } vince_bn_reduce;
 
-/* in/w/out have element type `dtype`; `out_f32 != 0` stores float output regardless of dtype (f32 only today).
- * bias: optional float[Co].  stats: optional double[R][Co][2] -- per-channel (sum, sum of squares) of the STORED
- * output values, atomically accumulated (feeds vince_bn_finalize; nn.BatchNorm2d train mode, resnet.py:69).
- * acc_mask: optional, only with VINCE_EPI_ACCUMULATE: one byte per 16-byte chunk of `out` (the ReLU bits written by
- * vince_bn_apply); bit e gates element e of the chunk, so the residual join `out = dgrad + out * (z > 0)`
- * (autograd of resnet.py:132-133) happens in place without materialising the masked gradient.
- * bnred: optional (not together with stats), see vince_bn_reduce above. */
+typedef struct vince_conv_epi {
+    int32_t flags;            /* VINCE_EPI_* */
+    const float* bias;        /* optional float[Co] */
+    double* stats;            /* optional double[R][Co][2]: per-channel (sum, sum of squares) of the conv output as
+                               * stored in dtype, atomically accumulated (feeds vince_bn_finalize; BatchNorm2d train
+                               * mode, resnet.py:69) */
+    const uint8_t* acc_mask;  /* optional, only with VINCE_EPI_ACCUMULATE: one byte per 16-byte chunk of `out` (the ReLU
+                               * bits written by vince_bn_apply); bit e gates element e, so the residual join
+                               * out = dgrad + out * (z > 0) (autograd of resnet.py:132-133) happens in place */
+    vince_bn_reduce bnred;    /* excludes stats */
+} vince_conv_epi;
+
+/* in/w/out have element type `dtype`.  epi may be NULL (plain store). */
 int vince_conv_igemm(const vince_conv_desc* d, int dtype, const void* in, const void* w, void* out,
-                     const float* bias, double* stats, const uint8_t* acc_mask, const vince_bn_reduce* bnred,
-                     int flags, void* stream);
+                     const vince_conv_epi* epi, void* stream);
 
 /* Weight gradient (wgrad) of the same generalised conv, reduction over output pixels:
  *   dw[co, wt(a,b), ci] += sum_{n,ho,wo} dy[n,ho,wo,co] * in[n, ho*sh+dh0+a*dhs, wo*sw+dw0+b*dws, ci]
@@ -283,7 +288,7 @@ int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* params, voi
 
 /* input: float NCHW (perm optional, see vince_input_nchw_to_nhwc) or, when input_is_tiles != 0, jigsaw source
  * (N/9 images [3][srcH][srcW]).  bn_buffers: per BN {running_mean, running_var} float pointers; nbt: int64 ptrs.
- * train_bn: batch statistics + running-stat update.  save: keep what backward needs in the workspace.
+ * train_bn: batch statistics + running-stat update.
  * Outputs: pooled float[N][C]; spatial (the trunk output, dtype NHWC) stays in the workspace:
  * vince_trunk_spatial_ptr(). */
 int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void* wcache, float* const* bn_running,

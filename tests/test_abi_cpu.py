@@ -31,9 +31,9 @@ def test_every_declared_symbol_is_exported(L):
 def test_argument_validation_returns_codes(L):
     from vince_amd._lib import ConvDesc, InfoNCEDesc, TrunkCfg
     d = ConvDesc(N=1, Hi=4, Wi=4, Ci=6, Ho=4, Wo=4, Co=8, sh=1, sw=1, TA=1, TB=1, WT=1, OH=4, OW=4, osh=1, osw=1)
-    rc = L.vince_conv_igemm(ctypes.byref(d), 0, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, None, None, 0, None)
+    rc = L.vince_conv_igemm(ctypes.byref(d), 0, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None, None)
     assert rc == -1 and b"Ci=6" in L.vince_last_error()
-    rc = L.vince_conv_igemm(ctypes.byref(d), 7, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, None, None, 0, None)
+    rc = L.vince_conv_igemm(ctypes.byref(d), 7, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None, None)
     assert rc == -2
     i = InfoNCEDesc(B=32, D=96, Bk=32, K=64, frames=1, offdiag_neg=0, inv_temperature=1.0)
     assert L.vince_infonce_workspace_bytes(ctypes.byref(i)) == 0 and b"D=96" in L.vince_last_error()

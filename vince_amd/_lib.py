@@ -22,6 +22,11 @@ class BnReduce(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("y", "mask_bits", "mask_scale", "mask_shift", "mean", "invstd", "sums")]
 
 
+class ConvEpi(ctypes.Structure):
+    _fields_ = [("flags", c_int32), ("bias", c_void_p), ("stats", c_void_p), ("acc_mask", c_void_p),
+                ("bnred", BnReduce)]
+
+
 class InfoNCEDesc(ctypes.Structure):
     _fields_ = [("B", c_int32), ("D", c_int32), ("Bk", c_int32), ("K", c_int32), ("frames", c_int32),
                 ("offdiag_neg", c_int32), ("inv_temperature", c_float)]
@@ -38,8 +43,7 @@ PROTOTYPES = {
     "vince_abi_version": (c_int, []),
     "vince_profile_enable": (c_int, [c_int]),
     "vince_profile_collect": (c_int, [c_int32, c_void_p, c_void_p, c_void_p]),
-    "vince_conv_igemm": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, P(BnReduce),
-                                 c_int, c_void_p]),
+    "vince_conv_igemm": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, P(ConvEpi), c_void_p]),
     "vince_conv_wgrad": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_void_p]),
     "vince_bn_finalize": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                   c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -110,7 +114,7 @@ def lib():
         # our NEEDED libamdhip64.so.7 to that same runtime instance; the other order loads a second HIP runtime from
         # /opt/rocm whose streams / device state are not torch's ("no ROCm-capable device" on the first stream op).
         import torch  # noqa: F401
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(os.environ.get("VINCE_HIP_LIB", LIB_PATH))   # override: A/B measurements of kernel builds
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)   # AttributeError if the .so does not export a declared symbol
             fn.restype = res

@@ -35,11 +35,7 @@ struct ConvParams {
     const void* w;
     void* out;
     uint32_t in_bytes, w_bytes;   // buffer-descriptor ranges for the direct-to-LDS variant (0 = tensor too large)
-    const float* bias;
-    double* stats;
-    const uint8_t* acc_mask;
-    vince_bn_reduce br;   // br.y == nullptr: no fused BatchNorm-backward reduction
-    int flags;
+    vince_conv_epi e;   // epilogue options (bias, statistics, residual join, fused BatchNorm forward / backward-reduce)
 };
 
 constexpr int PT = 128;   // pixels per workgroup tile
@@ -73,7 +69,7 @@ struct Smem {
     static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
 };
 
-template <typename T, int CT, int CRS, int PTL = PT, int UBM = 4>
+template <typename T, int CT, int CRS, bool BWD, int PTL = PT, int UBM = 4>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char* smem, f32x16_t (&acc)[CT / 64][PTL / 64],
                                               uint32_t tile, int p0, int c0, int tid, int lane, int wave, int wp, int wc) {
     constexpr int CH = Elem<T>::CH;
@@ -107,24 +103,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     const bool cvalid = cbase < d.Co;
     float bias_v[CH];
 #pragma unroll
-    for (int e = 0; e < CH; ++e) bias_v[e] = (p.bias && cvalid) ? p.bias[cbase + e] : 0.f;
+    for (int e = 0; e < CH; ++e) bias_v[e] = (p.e.bias && cvalid) ? p.e.bias[cbase + e] : 0.f;
     float ssum[CH], ssq[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) ssum[e] = ssq[e] = 0.f;
     T* __restrict__ out = (T*)p.out;
     const bool identity_map = (d.osh == 1 && d.osw == 1 && d.oh0 == 0 && d.ow0 == 0 && d.OH == d.Ho && d.OW == d.Wo);
-    const bool accum = (p.flags & VINCE_EPI_ACCUMULATE) != 0;
-    const bool touch = p.bias || (p.flags & (VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU));
-    // fused BatchNorm-backward reduction (p.br): per-channel constants of the BatchNorm that consumes this gradient
-    const T* __restrict__ br_y = (const T*)p.br.y;
+    const int flags = p.e.flags;
+    // BWD (compile time): the gradient epilogues -- residual join (ACCUMULATE, acc_mask) and the fused BatchNorm-backward
+    // reduction (bnred).  Forward launches take the lean instantiation.
+    const bool accum = BWD && (flags & VINCE_EPI_ACCUMULATE) != 0;
+    const bool touch = p.e.bias || accum || (flags & VINCE_EPI_RELU);
+    const T* __restrict__ br_y = BWD ? (const T*)p.e.bnred.y : nullptr;
     float br_mu[CH], br_is[CH], br_sc[CH], br_sh[CH];
+    if constexpr (BWD) {
 #pragma unroll
-    for (int e = 0; e < CH; ++e) {
-        const bool on = br_y && cvalid;
-        br_mu[e] = on ? p.br.mean[cbase + e] : 0.f;
-        br_is[e] = on ? p.br.invstd[cbase + e] : 0.f;
-        br_sc[e] = (on && p.br.mask_scale) ? p.br.mask_scale[cbase + e] : 0.f;
-        br_sh[e] = (on && p.br.mask_scale) ? p.br.mask_shift[cbase + e] : 0.f;
+        for (int e = 0; e < CH; ++e) {
+            const bool on = br_y && cvalid;
+            br_mu[e] = on ? p.e.bnred.mean[cbase + e] : 0.f;
+            br_is[e] = on ? p.e.bnred.invstd[cbase + e] : 0.f;
+            br_sc[e] = (on && p.e.bnred.mask_scale) ? p.e.bnred.mask_scale[cbase + e] : 0.f;
+            br_sh[e] = (on && p.e.bnred.mask_scale) ? p.e.bnred.mask_shift[cbase + e] : 0.f;
+        }
     }
     constexpr int NR = PTL / RPP;            // rows this thread stores
     constexpr int UB = NR < UBM ? NR : UBM;  // rows per batch: every global load of a batch is issued before its arithmetic
@@ -147,15 +147,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
                 opix = ((size_t)n * d.OH + (ho * d.osh + d.oh0)) * d.OW + (wo * d.osw + d.ow0);
             }
             off[u] = opix * d.Co + cbase;
-            ab[u] = bb[u] = 0xffu;
-            if (ok[u]) {
-                if (accum) {
-                    oldv[u] = *(const uint4*)(out + off[u]);
-                    if (p.acc_mask) ab[u] = p.acc_mask[off[u] / CH];
-                }
-                if (br_y) {
-                    yv[u] = *(const uint4*)(br_y + off[u]);
-                    if (p.br.mask_bits) bb[u] = p.br.mask_bits[off[u] / CH];
+            if constexpr (BWD) {
+                ab[u] = bb[u] = 0xffu;
+                if (ok[u]) {
+                    if (accum) {
+                        oldv[u] = *(const uint4*)(out + off[u]);
+                        if (p.e.acc_mask) ab[u] = p.e.acc_mask[off[u] / CH];
+                    }
+                    if (br_y) {
+                        yv[u] = *(const uint4*)(br_y + off[u]);
+                        if (p.e.bnred.mask_bits) bb[u] = p.e.bnred.mask_bits[off[u] / CH];
+                    }
                 }
             }
         }
@@ -169,42 +171,47 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
                 Chunk<T>::unpack(v, f);
 #pragma unroll
                 for (int e = 0; e < CH; ++e) f[e] += bias_v[e];
-                if (accum) {
-                    float o[CH];
-                    Chunk<T>::unpack(oldv[u], o);
-                    // residual join: the old value passes through the ReLU of the block output (acc_mask bits)
+                if constexpr (BWD) {
+                    if (accum) {
+                        float o[CH];
+                        Chunk<T>::unpack(oldv[u], o);
+                        // residual join: the old value passes through the ReLU of the block output (acc_mask bits)
 #pragma unroll
-                    for (int e = 0; e < CH; ++e) f[e] += ((ab[u] >> e) & 1u) ? o[e] : 0.f;
+                        for (int e = 0; e < CH; ++e) f[e] += ((ab[u] >> e) & 1u) ? o[e] : 0.f;
+                    }
                 }
-                if (p.flags & VINCE_EPI_RELU) {
+                if (flags & VINCE_EPI_RELU) {
 #pragma unroll
                     for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
                 }
                 v = Chunk<T>::pack(f);
             }
             *(uint4*)(out + off[u]) = v;
-            if (p.stats) {
+            if (p.e.stats) {
                 float f[CH];
                 Chunk<T>::unpack(v, f);
 #pragma unroll
                 for (int e = 0; e < CH; ++e) { ssum[e] += f[e]; ssq[e] += f[e] * f[e]; }
-            } else if (br_y) {
-                // (sum g, sum g*xhat) of the STORED gradient g = v * relu-mask, exactly what vince_bn_bwd_reduce computes
-                float g[CH], yy[CH];
-                Chunk<T>::unpack(v, g);
-                Chunk<T>::unpack(yv[u], yy);
+            }
+            if constexpr (BWD) {
+                if (br_y) {
+                    // (sum g, sum g*xhat) of the STORED gradient g = v * relu-mask, exactly what vince_bn_bwd_reduce computes
+                    float g[CH], yy[CH];
+                    Chunk<T>::unpack(v, g);
+                    Chunk<T>::unpack(yv[u], yy);
 #pragma unroll
-                for (int e = 0; e < CH; ++e) {
-                    bool keep = ((bb[u] >> e) & 1u) != 0;
-                    if (p.br.mask_scale) keep = (yy[e] * br_sc[e] + br_sh[e]) > 0.f;
-                    const float ge = keep ? g[e] : 0.f;
-                    ssum[e] += ge;
-                    ssq[e] += ge * (yy[e] - br_mu[e]) * br_is[e];
+                    for (int e = 0; e < CH; ++e) {
+                        bool keep = ((bb[u] >> e) & 1u) != 0;
+                        if (p.e.bnred.mask_scale) keep = (yy[e] * br_sc[e] + br_sh[e]) > 0.f;
+                        const float ge = keep ? g[e] : 0.f;
+                        ssum[e] += ge;
+                        ssq[e] += ge * (yy[e] - br_mu[e]) * br_is[e];
+                    }
                 }
             }
         }
     }
-    double* const red_out = p.stats ? p.stats : p.br.sums;
+    double* const red_out = p.e.stats ? p.e.stats : (BWD ? p.e.bnred.sums : nullptr);
     if (red_out) {   // uniform branch
         float* red = (float*)(smem + PTL * CRS);      // [4 waves][CPR][CH][2]
 #pragma unroll
@@ -237,7 +244,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     }
 }
 
-template <typename T, int CT, int KC>
+template <typename T, int CT, int KC, bool BWD>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64;          // 32-channel MFMA tiles per wave
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         __syncthreads();
     }
 
-    conv_epilogue<T, CT, Smem<T, CT, KC>::CRS>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
+    conv_epilogue<T, CT, Smem<T, CT, KC>::CRS, BWD>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
 
@@ -368,7 +375,7 @@ struct SmemD {
 // PTL = pixels per workgroup tile (128 or 256).  The L2 -> LDS fill rate of a CU (measured ~19 B/clk with every CU
 // streaming) caps a 128x128 tile at ~700 TFLOP/s chip-wide: 256 B of operands per K element feed 32768 FLOP.  The
 // 256-pixel tile moves 25 % fewer bytes per FLOP (each wave owns 128 pixels x CT/2 channels).
-template <typename T, int CT, int KC, int STAGES, int MINW = 1, int PTL = PT>
+template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, bool BWD>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64, PI = PTL / 64;
@@ -511,57 +518,43 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     wait_vmcnt<0>();
     __syncthreads();
     // rows in flight per thread in the epilogue: the 128-VGPR (4 workgroups/CU) configuration has no room for more than 2
-    conv_epilogue<T, CT, S::CRS, PTL, (MINW >= 4 ? 2 : 4)>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
+    conv_epilogue<T, CT, S::CRS, BWD, PTL, (MINW >= 4 ? 2 : 4)>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
-template <typename T, int CT>
+template <typename T, int CT, bool BWD>
 int launch(ConvParams& p, hipStream_t stream) {
     static int dlds_min_k = getenv("VINCE_DLDS_MIN_K") ? atoi(getenv("VINCE_DLDS_MIN_K")) : 0;
     const int k_elems = p.total_chunks * (16 / (int)sizeof(T));
-    // ring configuration: 1 = 64-byte K rows x 3 stages (48 KB, 3 workgroups/CU; best overall on MI355X),
-    // 0 = 128-byte rows x 2 stages, 2 = 64-byte rows x 4 stages, 3 = 128-byte rows x 3 stages
+    // VINCE_DLDS_CFG=4 forces the 128-pixel tile everywhere (measurement aid); the default (5) adds the 256-pixel tile
     static int dlds_cfg = getenv("VINCE_DLDS_CFG") ? atoi(getenv("VINCE_DLDS_CFG")) : 5;
     static int big_min_k = getenv("VINCE_BIG_MIN_K") ? atoi(getenv("VINCE_BIG_MIN_K")) : 1024;
     static int big_min_tiles = getenv("VINCE_BIG_MIN_TILES") ? atoi(getenv("VINCE_BIG_MIN_TILES")) : 256;
     if (p.in_bytes && p.w_bytes && k_elems >= dlds_min_k) {
-        const dim3 grid(p.ptiles * p.ctiles);
-        const int kc = (dlds_cfg == 0 || dlds_cfg == 3) ? 8 : 4;   // cfg 1, 2, 4, 5 use 64-byte rows
         const int cpt = p.cpt_mask == 0x7fffffff ? p.total_chunks : p.cpt_mask + 1;
-        p.uniform_taps = (cpt % kc == 0) && (p.total_chunks % kc == 0);
-        if (dlds_cfg == 0) {
-            p.nkt = (p.total_chunks + 7) / 8;
-            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 2>), grid, dim3(256), 0, stream, p);
-        } else if (dlds_cfg == 1) {
-            p.nkt = (p.total_chunks + 3) / 4;
-            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3>), grid, dim3(256), 0, stream, p);
-        } else if (dlds_cfg == 2) {
-            p.nkt = (p.total_chunks + 3) / 4;
-            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 4>), grid, dim3(256), 0, stream, p);
-        } else if (dlds_cfg == 5 && CT == 128 && k_elems >= big_min_k && (long)((p.M + 255) / 256) * p.ctiles >= big_min_tiles) {
-            // 256-pixel tiles, 64-byte rows x 3 stages (2 workgroups per CU): long reductions with enough tiles to fill
-            // the chip -- 25 % fewer operand bytes per FLOP through the L2 -> LDS path that bounds the 128-pixel tile
+        p.uniform_taps = (cpt % 4 == 0) && (p.total_chunks % 4 == 0);
+        p.nkt = (p.total_chunks + 3) / 4;     // 64-byte K rows
+        if (dlds_cfg == 5 && CT == 128 && k_elems >= big_min_k && (long)((p.M + 255) / 256) * p.ctiles >= big_min_tiles) {
+            // 256-pixel tiles, 3 stages (2 workgroups per CU): long reductions with enough tiles to fill the chip --
+            // 25 % fewer operand bytes per FLOP through the L2 -> LDS path that bounds the 128-pixel tile
             if constexpr (CT == 128) {
-                p.nkt = (p.total_chunks + 3) / 4;
                 p.ptiles = (p.M + 255) / 256;
-                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                                   stream, p);
             }
-        } else if (dlds_cfg == 4 || dlds_cfg == 5) {   // 64-byte rows x 2 stages, registers capped for 4 workgroups per CU
-            p.nkt = (p.total_chunks + 3) / 4;
-            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4>), grid, dim3(256), 0, stream, p);
-        } else {
-            p.nkt = (p.total_chunks + 7) / 8;
-            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 3>), grid, dim3(256), 0, stream, p);
+        } else {   // 128-pixel tiles, 2 stages, registers capped for 4 workgroups per CU
+            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
         }
         VINCE_CHECK_LAUNCH();
         return VINCE_OK;
     }
-    // K tile = 128 bytes per row (8 chunks) when the reduction is long enough to pipeline, else 64 bytes
+    // register-staged fallback (tensors beyond the 31-bit buffer offsets of the direct-to-LDS path): K tile = 128 bytes
+    // per row (8 chunks) when the reduction is long enough to pipeline, else 64 bytes.  Generic epilogue.
     if (k_elems >= 1024) {
         p.nkt = (p.total_chunks + 7) / 8;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 8>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 8, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
     } else {
         p.nkt = (p.total_chunks + 3) / 4;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 4>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 4, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
     }
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
@@ -570,13 +563,14 @@ int launch(ConvParams& p, hipStream_t stream) {
 }  // namespace
 
 extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void* in, const void* w, void* out,
-                                const float* bias, double* stats, const uint8_t* acc_mask, const vince_bn_reduce* bnred,
-                                int flags, void* stream) {
+                                const vince_conv_epi* epi, void* stream) {
+    vince_conv_epi e;
+    if (epi) e = *epi; else memset(&e, 0, sizeof(e));
     VINCE_CHECK_ARG(dd && in && w && out, VINCE_E_ARG, "vince_conv_igemm: null pointer");
-    VINCE_CHECK_ARG(!acc_mask || (flags & VINCE_EPI_ACCUMULATE), VINCE_E_ARG, "vince_conv_igemm: acc_mask needs VINCE_EPI_ACCUMULATE");
-    VINCE_CHECK_ARG(!bnred || (bnred->y && bnred->mean && bnred->invstd && bnred->sums && !stats), VINCE_E_ARG,
+    VINCE_CHECK_ARG(!e.acc_mask || (e.flags & VINCE_EPI_ACCUMULATE), VINCE_E_ARG, "vince_conv_igemm: acc_mask needs VINCE_EPI_ACCUMULATE");
+    VINCE_CHECK_ARG(!e.bnred.y || (e.bnred.mean && e.bnred.invstd && e.bnred.sums && !e.stats), VINCE_E_ARG,
                     "vince_conv_igemm: bnred needs y, mean, invstd and sums, and excludes stats");
-    VINCE_CHECK_ARG(!bnred || (!bnred->mask_scale == !bnred->mask_shift), VINCE_E_ARG,
+    VINCE_CHECK_ARG(!e.bnred.mask_scale == !e.bnred.mask_shift, VINCE_E_ARG,
                     "vince_conv_igemm: bnred mask_scale and mask_shift come together");
     VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_igemm: bad dtype %d", dtype);
     const vince_conv_desc& d = *dd;
@@ -610,8 +604,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.tb_mul = (65536 + d.TB - 1) / d.TB;
     p.div_howo = make_fastdiv((uint32_t)(d.Ho * d.Wo));
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
-    p.in = in; p.w = w; p.out = out; p.bias = bias; p.stats = stats; p.acc_mask = acc_mask; p.flags = flags;
-    if (bnred) p.br = *bnred; else memset(&p.br, 0, sizeof(p.br));
+    p.in = in; p.w = w; p.out = out; p.e = e;
     static int ablate = getenv("VINCE_CONV_ABLATE") ? atoi(getenv("VINCE_CONV_ABLATE")) : 0;   // measurement aid only
     p.ablate = ablate;
     {
@@ -643,11 +636,17 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
         // algorithmic FLOPs: the stem's input channels are padded 3 -> CH; count the 3 real ones
         const double ci_alg = (d.Ci == CH && T > 1) ? 3.0 : (double)d.Ci;
         vince_profile_begin_launch((dtype == VINCE_F32 ? 0 : 2) + (narrow ? 0 : 1), 2.0 * p.M * d.Co * T * ci_alg, stream, &tok);
-        vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh * 10 + d.osh, flags);
+        vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh * 10 + d.osh, e.flags);
     }
     int rc;
-    if (dtype == VINCE_F32) rc = narrow ? launch<float, 64>(p, s) : launch<float, 128>(p, s);
-    else rc = narrow ? launch<bf16_t, 64>(p, s) : launch<bf16_t, 128>(p, s);
+    const bool bwd = (e.flags & VINCE_EPI_ACCUMULATE) || e.bnred.y;   // gradient epilogue instantiation
+    if (dtype == VINCE_F32) {
+        if (bwd) rc = narrow ? launch<float, 64, true>(p, s) : launch<float, 128, true>(p, s);
+        else rc = narrow ? launch<float, 64, false>(p, s) : launch<float, 128, false>(p, s);
+    } else {
+        if (bwd) rc = narrow ? launch<bf16_t, 64, true>(p, s) : launch<bf16_t, 128, true>(p, s);
+        else rc = narrow ? launch<bf16_t, 64, false>(p, s) : launch<bf16_t, 128, false>(p, s);
+    }
     if (tok) vince_profile_end_launch(tok, stream);
     return rc;
 }

@@ -331,8 +331,10 @@ struct Ctx {
 int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_off, float* const* bn_running,
                 int64_t* const* bn_nbt, int train_bn) {
     vince_conv_desc d = fwd_desc(c.t, cv);
-    RC(vince_conv_igemm(&d, c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), nullptr,
-                        train_bn ? c.stats(bn) : nullptr, nullptr, nullptr, 0, c.stream));
+    vince_conv_epi e;
+    memset(&e, 0, sizeof(e));
+    e.stats = train_bn ? c.stats(bn) : nullptr;
+    RC(vince_conv_igemm(&d, c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), &e, c.stream));
     const int64_t count = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
     RC(vince_bn_finalize(c.stats(bn), count, bn.C, c.params[bn.gamma], c.params[bn.beta], bn_running[2 * bn.index],
                          bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr, 0.1f, 1e-5f, train_bn,
@@ -347,9 +349,12 @@ int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, co
     const int classes = cv.stride * cv.stride;
     if (!accumulate && n < classes)   // some pixel classes receive no gradient (1x1 stride 2): zero them
         VINCE_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)c.t->cfg.N * cv.Hi * cv.Wi * cv.Ci * c.t->esize, (hipStream_t)c.stream));
-    for (int i = 0; i < n; ++i)
-        RC(vince_conv_igemm(&ds[i], c.dtype, dy, at((void*)c.wcache, cv.wt), dx, nullptr, nullptr, acc_mask, bnred,
-                            accumulate ? VINCE_EPI_ACCUMULATE : 0, c.stream));
+    vince_conv_epi e;
+    memset(&e, 0, sizeof(e));
+    e.flags = accumulate ? VINCE_EPI_ACCUMULATE : 0;
+    e.acc_mask = acc_mask;
+    if (bnred) e.bnred = *bnred;
+    for (int i = 0; i < n; ++i) RC(vince_conv_igemm(&ds[i], c.dtype, dy, at((void*)c.wcache, cv.wt), dx, &e, c.stream));
     return VINCE_OK;
 }
 

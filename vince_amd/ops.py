@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BnReduce, ConvDesc, InfoNCEDesc, VINCE_BF16, VINCE_F32, check, lib
+from ._lib import BnReduce, ConvDesc, ConvEpi, InfoNCEDesc, VINCE_BF16, VINCE_F32, check, lib
 
 EPI_ACCUMULATE, EPI_RELU = _lib.EPI_ACCUMULATE, _lib.EPI_RELU
 STATS_REPLICAS = 16   # VINCE_STATS_REPLICAS in include/vince_hip.h
@@ -89,9 +89,17 @@ def bn_reduce_arg(y, mean, invstd, sums, mask_bits=None, mask_scale=None, mask_s
 
 
 def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None):
+    """vince_conv_igemm with the epilogue options of vince_conv_epi."""
     require_gpu(x, w, out, bias, stats, acc_mask)
-    check(lib().vince_conv_igemm(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(stats),
-                                 _ptr(acc_mask), None if bnred is None else ctypes.byref(bnred), flags, stream_ptr()))
+    e = ConvEpi()
+    e.flags = flags
+    e.bias = None if bias is None else bias.data_ptr()
+    e.stats = None if stats is None else stats.data_ptr()
+    e.acc_mask = None if acc_mask is None else acc_mask.data_ptr()
+    if bnred is not None:
+        e.bnred = bnred
+    check(lib().vince_conv_igemm(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(w), _ptr(out), ctypes.byref(e),
+                                 stream_ptr()))
     return out
 
 
