@@ -36,8 +36,10 @@ import torch  # noqa: E402
 STEP_GFLOP_PER_SAMPLE = {"ResNet50": 32.766, "ResNet18": 14.512}     # key fwd + query fwd + query bwd + similarity
 FWD_GFLOP_PER_FRAME = {"ResNet50": 8.2000, "ResNet18": 3.6282}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}                          # MI355X_MICROARCH.md dense MFMA peaks
-KERNEL_TAGS = ["conv_igemm<f32,64>", "conv_igemm<f32,128>", "conv_igemm<bf16,64>", "conv_igemm<bf16,128>",
-               "conv_wgrad<f32>", "conv_wgrad<bf16>"]
+# one tag per kernel symbol (as rocprofv3 lists them): conv_igemm_dlds_kernel<T, CT, 4, STAGES, MINW, PTL, BWD>
+KERNEL_TAGS = ["conv_igemm<%s,%s,%s>" % (t, shape, e) for t in ("f32", "bf16")
+               for shape in ("64ch x 128px", "128ch x 128px", "128ch x 256px") for e in ("fwd", "bwd")] + \
+              ["conv_wgrad<f32>", "conv_wgrad<bf16>"]
 
 
 class PooledFrames:
@@ -205,7 +207,8 @@ def main():
                                  "ms_per_step": round(ms[i] / opt.profile_steps, 3),
                                  "tflops": round(fl[i] / (ms[i] * 1e-3) / 1e12, 1)}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
-        dom_conv = "conv_igemm<%s,128>" % ("bf16" if opt.dtype == "bf16" else "f32")
+        convs = [k for k in kernels if k.startswith("conv_igemm")]
+        dom_conv = max(convs, key=lambda k: kernels[k]["ms_per_step"]) if convs else None
         if dom_conv in kernels:
             k = kernels[dom_conv]
             # HBM bytes per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note in
@@ -215,7 +218,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_conv_igemm.json")) as fh:
                     pm = json.load(fh)
-                traffic = {"bytes_per_launch": pm["bytes_per_launch"], "source": pm["source"]}
+                traffic = {"bytes_per_launch": pm["kernels"][dom_conv]["bytes_per_launch"], "source": pm["source"]}
             except Exception:
                 pass
             out["roofline"] = {"bound": "mfma", "kernel": dom_conv, "achieved": k["tflops"], "peak": PEAK_TFLOPS[opt.dtype],

@@ -1,5 +1,6 @@
 """Times a few representative ResNet-50 conv layers (B=256, bf16) through vince_conv_igemm; with statistics like the
 engine's forward.  Usage: conv_micro4.py [label]"""
+import os
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -11,10 +12,10 @@ SHAPES = [("l1 1x1 64->256", 56, 64, 256, 1), ("l1 3x3 64", 56, 64, 64, 3), ("l1
 N = 256
 res = []
 for name, hw, ci, co, k in SHAPES:
-    x = torch.randn(N, hw, hw, ci, device=dev).bfloat16()
+    x = torch.randn(N, hw, hw, ci, device=dev).clamp_(min=0).bfloat16()   # post-ReLU-like input
     w = (torch.randn(co, k * k, ci, device=dev) * 0.05).bfloat16()
     out = torch.empty(N, hw, hw, co, device=dev, dtype=torch.bfloat16)
-    stats = torch.zeros(ops.STATS_REPLICAS, co, 2, device=dev, dtype=torch.float64)
+    stats = None if os.environ.get("NOSTATS") else torch.zeros(ops.STATS_REPLICAS, co, 2, device=dev, dtype=torch.float64)
     d = ops.conv_desc(N, hw, hw, ci, co, k, 1, k // 2)
     for _ in range(3):
         ops.conv_igemm(d, x, w, out, stats=stats)

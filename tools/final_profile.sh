@@ -1,0 +1,17 @@
+#!/bin/bash
+# GPU box: the round's evidence set.  bench.py full line, rocprofv3 kernel stats of the same command, HBM traffic PMC passes.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/final; rm -rf $O; mkdir -p $O
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 20 python tools/bench_brief.py $O/bench.json bench
+timeout 600 rocprofv3 --kernel-trace -d $O/kt -o kt -- python bench.py --no-extras > $O/kt.log 2>&1
+DB=$(find $O/kt -name '*.db' | head -1); timeout 60 python tools/rocpd_stats.py $DB 45 > $O/kernel_stats.txt 2>&1; rm -rf $O/kt
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --steps 2 --warmup 1 --no-extras > $O/pmc_$C.log 2>&1
+done
+F=$(find $O/pmc_FETCH_SIZE -name '*.db' | head -1); W=$(find $O/pmc_WRITE_SIZE -name '*.db' | head -1)
+timeout 60 python tools/rocpd_pmc.py $F 14 > $O/pmc_fetch_size.txt 2>&1
+timeout 60 python tools/rocpd_pmc.py $W 14 > $O/pmc_write_size.txt 2>&1
+timeout 60 python tools/pmc_summary.py $F $W $O/pmc_conv_igemm.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B); bench.py --steps 2 --warmup 1 --no-extras" > $O/pmc_summary.txt 2>&1
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+cat $O/pmc_summary.txt | head -12

@@ -1,0 +1,59 @@
+"""Combine the FETCH_SIZE and WRITE_SIZE rocprofv3 PMC passes (two rocpd databases) into per-kernel HBM bytes per
+launch, keyed by bench.py's kernel tags.  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 bytes,
+MI355X_MICROARCH.md HBM section); both counters are in KB.  Usage: pmc_summary.py fetch.db write.db out.json "source" """
+import json
+import re
+import sqlite3
+import sys
+
+
+def tag_of(name):
+    m = re.search(r"conv_igemm_dlds_kernelI([tf])Li(\d+)ELi\d+ELi\d+ELi\d+ELi(\d+)ELb([01])E", name)
+    if not m:
+        m2 = re.search(r"conv_igemm_dlds_kernel<(unsigned short|float), (\d+), \d+, \d+, \d+, (\d+), (true|false)>", name)
+        if not m2:
+            if "conv_wgrad" in name:
+                return "conv_wgrad<%s>" % ("bf16" if ("It" in name or "unsigned short" in name) else "f32")
+            return None
+        t, ct, ptl, b = m2.group(1) == "unsigned short", int(m2.group(2)), int(m2.group(3)), m2.group(4) == "true"
+    else:
+        t, ct, ptl, b = m.group(1) == "t", int(m.group(2)), int(m.group(3)), m.group(4) == "1"
+    return "conv_igemm<%s,%dch x %dpx,%s>" % ("bf16" if t else "f32", ct, ptl, "bwd" if b else "fwd")
+
+
+def per_kernel(path):
+    c = sqlite3.connect(path)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    pe = [t for t in tabs if t.startswith("rocpd_pmc_event")][0]
+    scols = [r[1] for r in c.execute("pragma table_info(%s)" % ks)]
+    namecol = "kernel_name" if "kernel_name" in scols else "display_name"
+    q = ("select s.%s, count(*), sum(e.value) from %s e join %s d on e.event_id = d.event_id "
+         "join %s s on d.kernel_id = s.id group by s.%s" % (namecol, pe, kd, ks, namecol))
+    out = {}
+    for name, n, tot in c.execute(q):
+        t = tag_of(name)
+        if t:
+            a = out.setdefault(t, [0, 0.0])
+            a[0] += n
+            a[1] += tot
+    return out
+
+
+def main(fetch_db, write_db, out_json, source):
+    f, w = per_kernel(fetch_db), per_kernel(write_db)
+    kernels = {}
+    for t in sorted(set(f) & set(w)):
+        n = f[t][0]
+        fetch_b, write_b = 2.0 * f[t][1] * 1024.0 / n, w[t][1] * 1024.0 / w[t][0]
+        kernels[t] = {"launches": n, "fetch_bytes_per_launch": int(fetch_b), "write_bytes_per_launch": int(write_b),
+                      "bytes_per_launch": int(fetch_b + write_b)}
+    json.dump({"kernels": kernels, "source": source}, open(out_json, "w"), indent=1)
+    for t, v in kernels.items():
+        print("%-40s launches %5d  fetch %8.1f MB  write %8.1f MB  total %8.1f MB / launch"
+              % (t, v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])

@@ -23,6 +23,7 @@ void vince_set_error(const char* fmt, ...);
 bool vince_profile_enabled();
 void vince_profile_begin_launch(int tag, double work, void* stream, void** token);
 void vince_profile_end_launch(void* token, void* stream);
+void vince_profile_set_tag(void* token, int tag);
 void vince_profile_set_dims(void* token, int a, int b, int c, int d, int e, int f);
 
 #define VINCE_CHECK_ARG(cond, code, ...)   \

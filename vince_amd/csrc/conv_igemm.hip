@@ -29,6 +29,7 @@ namespace {
 struct ConvParams {
     vince_conv_desc d;
     int log2_cpt, cpt_mask, total_chunks, nkt, M, ptiles, ctiles, uniform_taps, ablate;
+    int variant;   // host side: which kernel the launcher picked (0 = 128-pixel tile, 1 = 256-pixel tile, 2 = register-staged)
     uint32_t tb_mul;
     FastDiv div_howo, div_wo;
     const void* in;
@@ -238,7 +239,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) s += red[((w * CPR + ck) * CH + e) * 2 + which];
-            if (c0 + ch < d.Co)
+            if (c0 + ch < d.Co && !(p.ablate & 8))   // ablate 8: measurement aid, drops the atomics only
                 unsafeAtomicAdd(red_out + ((size_t)(tile % VINCE_STATS_REPLICAS) * d.Co + (c0 + ch)) * 2 + which, (double)s);
         }
     }
@@ -538,6 +539,7 @@ int launch(ConvParams& p, hipStream_t stream) {
             // 25 % fewer operand bytes per FLOP through the L2 -> LDS path that bounds the 128-pixel tile
             if constexpr (CT == 128) {
                 p.ptiles = (p.M + 255) / 256;
+                p.variant = 1;
                 hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
                                    stream, p);
             }
@@ -549,6 +551,7 @@ int launch(ConvParams& p, hipStream_t stream) {
     }
     // register-staged fallback (tensors beyond the 31-bit buffer offsets of the direct-to-LDS path): K tile = 128 bytes
     // per row (8 chunks) when the reduction is long enough to pipeline, else 64 bytes.  Generic epilogue.
+    p.variant = 2;
     if (k_elems >= 1024) {
         p.nkt = (p.total_chunks + 7) / 8;
         hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 8, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
@@ -605,6 +608,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.div_howo = make_fastdiv((uint32_t)(d.Ho * d.Wo));
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.w = w; p.out = out; p.e = e;
+    p.variant = 0;
     static int ablate = getenv("VINCE_CONV_ABLATE") ? atoi(getenv("VINCE_CONV_ABLATE")) : 0;   // measurement aid only
     p.ablate = ablate;
     {
@@ -635,7 +639,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     if (vince_profile_enabled()) {
         // algorithmic FLOPs: the stem's input channels are padded 3 -> CH; count the 3 real ones
         const double ci_alg = (d.Ci == CH && T > 1) ? 3.0 : (double)d.Ci;
-        vince_profile_begin_launch((dtype == VINCE_F32 ? 0 : 2) + (narrow ? 0 : 1), 2.0 * p.M * d.Co * T * ci_alg, stream, &tok);
+        vince_profile_begin_launch(0, 2.0 * p.M * d.Co * T * ci_alg, stream, &tok);
         vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh * 10 + d.osh, e.flags);
     }
     int rc;
@@ -647,6 +651,12 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
         if (bwd) rc = narrow ? launch<bf16_t, 64, true>(p, s) : launch<bf16_t, 128, true>(p, s);
         else rc = narrow ? launch<bf16_t, 64, false>(p, s) : launch<bf16_t, 128, false>(p, s);
     }
-    if (tok) vince_profile_end_launch(tok, stream);
+    if (tok) {
+        // one tag per kernel symbol: [dtype][64ch | 128ch | 128ch x 256px][fwd | bwd epilogue]; the register-staged
+        // fallback (never taken at the benchmark sizes) is counted with the 128-pixel tile of its shape
+        const int shape = narrow ? 0 : (p.variant == 1 ? 2 : 1);
+        vince_profile_set_tag(tok, (dtype == VINCE_F32 ? 0 : 6) + shape * 2 + (bwd ? 1 : 0));
+        vince_profile_end_launch(tok, stream);
+    }
     return rc;
 }

@@ -37,6 +37,8 @@ void vince_profile_set_dims(void* token, int a, int b, int c, int d, int e, int 
     p[0] = a; p[1] = b; p[2] = c; p[3] = d; p[4] = e; p[5] = f;
 }
 
+void vince_profile_set_tag(void* token, int tag) { g_prof[(size_t)(uintptr_t)token - 1].tag = tag; }
+
 void vince_profile_begin_launch(int tag, double work, void* stream, void** token) {
     ProfRec r;
     r.tag = tag; r.work = work;
