@@ -360,7 +360,7 @@ def test_bucketed_allreduce_machinery_single_rank():
     assert not r0 and r1
     # (two steps only: fp32 atomics make weight gradients order-dependent in the last bits and a freshly initialised
     # encoder amplifies that chaotically from the third step on)
-    np.testing.assert_allclose(l1, l0, rtol=1e-5)
+    np.testing.assert_allclose(l1, l0, rtol=1e-4, atol=1e-7)
     assert rel(p1.cpu(), p0.cpu()) < 2e-3
 
 

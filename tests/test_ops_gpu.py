@@ -176,9 +176,10 @@ def test_conv_dgrad_wgrad(cfg, dtype):
         assert_close(dw, ref_dw, dtype, f32=1e-4, what="wgrad variant %d" % variant)
 
 
-def test_linear_fwd_bwd():
+@pytest.mark.parametrize("rows,cin,cout", [(37, 512, 64), (256, 2048, 2048), (256, 2048, 128), (64, 1000, 96)])
+def test_linear_fwd_bwd(rows, cin, cout):
+    # (256, 2048, *) are the ResNet-50 projection-MLP shapes: the launcher takes its split-K route for them
     ops = _ops()
-    rows, cin, cout = 37, 512, 64
     x = rnd(rows, cin, seed=9).requires_grad_(True)
     w = rnd(cout, cin, seed=10, scale=cin ** -0.5).requires_grad_(True)
     b = rnd(cout, seed=11).requires_grad_(True)

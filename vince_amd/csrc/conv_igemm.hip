@@ -29,6 +29,7 @@ namespace {
 struct ConvParams {
     vince_conv_desc d;
     int log2_cpt, cpt_mask, total_chunks, nkt, M, ptiles, ctiles, uniform_taps, ablate;
+    int kt_per_split;   // > 0: split-K (grid.y splits, fp32 atomics into a zeroed output; f32 only)
     int variant;   // host side: which kernel the launcher picked (0 = 128-pixel tile, 1 = 256-pixel tile, 2 = register-staged)
     uint32_t tb_mul;
     FastDiv div_howo, div_wo;
@@ -104,7 +105,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     const bool cvalid = cbase < d.Co;
     float bias_v[CH];
 #pragma unroll
-    for (int e = 0; e < CH; ++e) bias_v[e] = (p.e.bias && cvalid) ? p.e.bias[cbase + e] : 0.f;
+    for (int e = 0; e < CH; ++e) bias_v[e] = (p.e.bias && cvalid && blockIdx.y == 0) ? p.e.bias[cbase + e] : 0.f;
     float ssum[CH], ssq[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) ssum[e] = ssq[e] = 0.f;
@@ -187,7 +188,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
                 }
                 v = Chunk<T>::pack(f);
             }
-            *(uint4*)(out + off[u]) = v;
+            if constexpr (sizeof(T) == 4) {
+                if (p.kt_per_split > 0) {   // split-K partial: accumulate into the zeroed output
+                    float f[CH];
+                    Chunk<T>::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) unsafeAtomicAdd((float*)out + off[u] + e, f[e]);
+                } else {
+                    *(uint4*)(out + off[u]) = v;
+                }
+            } else {
+                *(uint4*)(out + off[u]) = v;
+            }
             if (p.e.stats) {
                 float f[CH];
                 Chunk<T>::unpack(v, f);
@@ -477,15 +489,18 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
+    // split-K (tiny-M GEMMs: the projection MLP): this workgroup reduces K tiles [kt0, kt1) only
+    const int kt0 = p.kt_per_split > 0 ? (int)blockIdx.y * p.kt_per_split : 0;
+    const int kt1 = p.kt_per_split > 0 ? min(p.nkt, kt0 + p.kt_per_split) : p.nkt;
     // prologue: STAGES-1 tiles in flight (tiles past the end are issued as all-zero fills so the counts stay uniform)
 #pragma unroll
-    for (int st = 0; st < STAGES - 1; ++st) issue_tile(st, st);
+    for (int st = 0; st < STAGES - 1; ++st) issue_tile(kt0 + st, st);
     wait_vmcnt<(STAGES - 2) * PER_STAGE>();
     __syncthreads();
     const int sw = ((lane & 31) >> SWSH) & SWMASK, khalf = lane >> 5;
     const int row_off = (lane & 31) * KB;
     int buf = 0, nbuf = STAGES - 1;
-    for (int kt = 0; kt < p.nkt; ++kt) {
+    for (int kt = kt0; kt < kt1; ++kt) {
         if (!(p.ablate & 1)) issue_tile(kt + STAGES - 1, nbuf);
         const unsigned char* xs = smem + buf * S::STAGE + (wp * (PTL / 2)) * KB + row_off;
         const unsigned char* ws = smem + buf * S::STAGE + S::XB + (wc * (CT / 2)) * KB + row_off;
@@ -522,6 +537,13 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     conv_epilogue<T, CT, S::CRS, BWD, PTL, (MINW >= 4 ? 2 : 4)>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
+__global__ void relu_inplace_kernel(float* x, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = ((float4*)x)[i];
+        ((float4*)x)[i] = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    }
+}
+
 template <typename T, int CT, bool BWD>
 int launch(ConvParams& p, hipStream_t stream) {
     static int dlds_min_k = getenv("VINCE_DLDS_MIN_K") ? atoi(getenv("VINCE_DLDS_MIN_K")) : 0;
@@ -544,7 +566,31 @@ int launch(ConvParams& p, hipStream_t stream) {
                                    stream, p);
             }
         } else {   // 128-pixel tiles, 2 stages, registers capped for 4 workgroups per CU
-            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+            // Tiny-M fp32 GEMMs (the projection MLP, 256 rows: 2 pixel tiles) would leave most CUs idle: split the
+            // reduction over grid.y, partial sums meet in a zeroed output through fp32 atomics, ReLU runs afterwards.
+            int splits = 1;
+            const long tiles = (long)p.ptiles * p.ctiles;
+            static const bool splitk_env = !(getenv("VINCE_SPLITK") && atoi(getenv("VINCE_SPLITK")) == 0);
+            if (sizeof(T) == 4 && splitk_env && !BWD && !p.e.stats && tiles < 128 && p.nkt >= 16 &&
+                p.d.osh == 1 && p.d.osw == 1 && p.d.OH == p.d.Ho && p.d.OW == p.d.Wo) {
+                static const long target = getenv("VINCE_SPLITK_WGS") ? atol(getenv("VINCE_SPLITK_WGS")) : 256;   // (env: measurement aid) more splits cost more in atomics than they buy
+                splits = (int)min((long)(p.nkt / 8), (target + tiles - 1) / tiles);
+                if (splits < 2) splits = 1;
+            }
+            if (splits > 1) {
+                const int relu = p.e.flags & VINCE_EPI_RELU;
+                p.e.flags &= ~VINCE_EPI_RELU;
+                p.kt_per_split = (p.nkt + splits - 1) / splits;
+                splits = (p.nkt + p.kt_per_split - 1) / p.kt_per_split;
+                const size_t n = (size_t)p.M * p.d.Co;
+                if (int zrc = vince_zero_async(p.out, n * sizeof(float), stream)) return zrc;
+                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, BWD>), dim3(p.ptiles * p.ctiles, splits), dim3(256), 0,
+                                   stream, p);
+                if (relu) hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)min((size_t)1024, (n / 4 + 255) / 256)), dim3(256), 0,
+                                             stream, (float*)p.out, n / 4);
+            } else {
+                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+            }
         }
         VINCE_CHECK_LAUNCH();
         return VINCE_OK;
@@ -609,6 +655,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.w = w; p.out = out; p.e = e;
     p.variant = 0;
+    p.kt_per_split = 0;
     static int ablate = getenv("VINCE_CONV_ABLATE") ? atoi(getenv("VINCE_CONV_ABLATE")) : 0;   // measurement aid only
     p.ablate = ablate;
     {

@@ -360,3 +360,19 @@ extern "C" int vince_sgd_flat(float* param, const float* grad, float* buf, int64
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
+
+namespace {
+__global__ __launch_bounds__(256) void zero_kernel(uint4* p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+}  // namespace
+
+int vince_zero_async(void* ptr, size_t bytes, void* stream) {
+    VINCE_CHECK_ARG(ptr && ((uintptr_t)ptr & 15) == 0 && (bytes & 15) == 0, VINCE_E_ALIGN, "vince_zero_async: 16-byte granularity");
+    if (bytes == 0) return VINCE_OK;
+    const size_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4*)ptr, n16);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}

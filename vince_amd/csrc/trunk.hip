@@ -348,7 +348,7 @@ int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, co
     const int n = dgrad_descs(c.t, cv, ds);
     const int classes = cv.stride * cv.stride;
     if (!accumulate && n < classes)   // some pixel classes receive no gradient (1x1 stride 2): zero them
-        VINCE_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)c.t->cfg.N * cv.Hi * cv.Wi * cv.Ci * c.t->esize, (hipStream_t)c.stream));
+        RC(vince_zero_async(dx, (size_t)c.t->cfg.N * cv.Hi * cv.Wi * cv.Ci * c.t->esize, c.stream));
     vince_conv_epi e;
     memset(&e, 0, sizeof(e));
     e.flags = accumulate ? VINCE_EPI_ACCUMULATE : 0;
@@ -436,7 +436,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     Ctx c{t, params, wcache, workspace, stream, t->cfg.dtype};
     const int N = t->cfg.N;
     if (train_bn)
-        VINCE_CHECK_HIP(hipMemsetAsync(at(workspace, t->off_stats), 0, t->n_stats_doubles * sizeof(double), (hipStream_t)stream));
+        RC(vince_zero_async(at(workspace, t->off_stats), t->n_stats_doubles * sizeof(double), stream));
     if (jig_h > 0) {
         VINCE_CHECK_ARG(N % 9 == 0, VINCE_E_SHAPE, "vince_trunk_forward: jigsaw needs N multiple of 9");
         RC(vince_jigsaw_nchw_to_nhwc(c.dtype, input, at(workspace, t->off_x0), N / 9, 3, jig_h, jig_w, t->cfg.H, t->cfg.W,
@@ -482,7 +482,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     VINCE_CHECK_ARG(t && params && wcache && workspace && dpooled && grads, VINCE_E_ARG, "vince_trunk_backward: null pointer");
     Ctx c{t, params, wcache, workspace, stream, t->cfg.dtype};
     const int N = t->cfg.N;
-    VINCE_CHECK_HIP(hipMemsetAsync(at(workspace, t->off_sums), 0, t->n_stats_doubles * sizeof(double), (hipStream_t)stream));
+    RC(vince_zero_async(at(workspace, t->off_sums), t->n_stats_doubles * sizeof(double), stream));
     // Weight gradients run on a side stream: wgrad(layer) only needs dY(layer) and the saved activation, and nothing but
     // the optimiser needs its result, so it overlaps the BatchNorm-backward / dgrad chain of the layers below (compute-
     // bound MFMA work next to HBM-bound streams).  dY lives in a 3-slot ring; a slot is rewritten only after the wgrad
