@@ -78,11 +78,40 @@ __global__ __launch_bounds__(256) void prepare_weight_kernel(const float* __rest
 // All conv layers of a trunk in one launch: blockIdx.y = layer (descriptor table in device memory), blockIdx.x strides
 // over that layer's elements.
 template <typename T>
-__global__ __launch_bounds__(256) void prepare_weights_batched_kernel(const vince_prep_entry* __restrict__ table) {
+__global__ __launch_bounds__(256) void prepare_weights_batched_kernel(const vince_prep_entry* __restrict__ table, int tiled) {
     const vince_prep_entry e = table[blockIdx.y];
     const float* __restrict__ w = (const float*)e.w;
     T* __restrict__ wk = (T*)e.wk;
     T* __restrict__ wt = (T*)e.wt;
+    if (tiled && wt && e.Ci % 64 == 0 && e.Co % 64 == 0 && e.Cip == e.Ci) {
+        // 64 x 64 (co x ci) tiles through LDS: the [Co][T][Ci] copy and its [Ci][T][Co] transpose are both written in
+        // whole rows (element-wise transposed stores cost ~5x their bytes in partial-line HBM writes)
+        __shared__ float tile[64][65];
+        const int tci = e.Ci / 64, tco = e.Co / 64;
+        const int ntiles = tco * e.T * tci;
+        const int col = threadIdx.x & 63, rq = threadIdx.x >> 6;
+        for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+            const int ci0 = (tl % tci) * 64;
+            const int t = (tl / tci) % e.T;
+            const int co0 = (tl / (tci * e.T)) * 64;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int row = i * 4 + rq;
+                const size_t off = ((size_t)(co0 + row) * e.T + t) * e.Ci + ci0 + col;
+                const float v = w[off];
+                wk[off] = cvt_from_f32<T>(v);
+                tile[row][col] = v;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int row = i * 4 + rq;   // ci within the tile
+                wt[((size_t)(ci0 + row) * e.T + t) * e.Co + co0 + col] = cvt_from_f32<T>(tile[col][row]);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int64_t total = (int64_t)e.Co * e.T * e.Cip;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int ci = (int)(idx % e.Cip);
@@ -259,11 +288,12 @@ extern "C" int vince_prepare_weight(int dtype, const float* w, void* wk, void* w
 extern "C" int vince_prepare_weights_batched(int dtype, const vince_prep_entry* table_dev, int32_t n, void* stream) {
     DTYPE_OK("vince_prepare_weights_batched");
     VINCE_CHECK_ARG(table_dev && n > 0, VINCE_E_ARG, "vince_prepare_weights_batched: bad arguments");
+    static const int tiled = !(getenv("VINCE_PREP_TILED") && atoi(getenv("VINCE_PREP_TILED")) == 0);   // measurement aid
     const dim3 grid(512, n);   // blocks beyond a small layer's element count fall through the grid-stride loop at once
     if (dtype == VINCE_F32)
-        hipLaunchKernelGGL(prepare_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
+        hipLaunchKernelGGL(prepare_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, table_dev, tiled);
     else
-        hipLaunchKernelGGL(prepare_weights_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
+        hipLaunchKernelGGL(prepare_weights_batched_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, table_dev, tiled);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
