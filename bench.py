@@ -219,6 +219,12 @@ def main():
                 with open(os.path.join(ROOT, "profiles", "pmc_conv_igemm.json")) as fh:
                     pm = json.load(fh)
                 traffic = {"bytes_per_launch": pm["kernels"][dom_conv]["bytes_per_launch"], "source": pm["source"]}
+                if pm.get("step"):
+                    # whole-step HBM view: the step as a whole is bandwidth-bound
+                    out["step_hbm"] = {"bytes_per_step": pm["step"]["bytes"], "unit": "GB/s", "peak": 8000.0,
+                                       "achieved": round(pm["step"]["bytes"] / (out["ms_per_step"] * 1e-3) / 1e9, 1),
+                                       "frac": round(pm["step"]["bytes"] / (out["ms_per_step"] * 1e-3) / 8e12, 4),
+                                       "source": pm["source"]}
             except Exception:
                 pass
             out["roofline"] = {"bound": "mfma", "kernel": dom_conv, "achieved": k["tflops"], "peak": PEAK_TFLOPS[opt.dtype],

@@ -41,15 +41,42 @@ def per_kernel(path):
     return out
 
 
+def step_total(path):
+    """Counter total (KB) over the dispatches of the last complete training step (between the first sgd_kernel launch
+    of two consecutive steps)."""
+    c = sqlite3.connect(path)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    pe = [t for t in tabs if t.startswith("rocpd_pmc_event")][0]
+    scols = [r[1] for r in c.execute("pragma table_info(%s)" % ks)]
+    namecol = "kernel_name" if "kernel_name" in scols else "display_name"
+    rows = list(c.execute("select s.%s, d.start, e.value from %s e join %s d on e.event_id = d.event_id join %s s "
+                          "on d.kernel_id = s.id order by d.start" % (namecol, pe, kd, ks)))
+    marks = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
+    firsts = [m for j, m in enumerate(marks) if j == 0 or rows[m][1] - rows[marks[j - 1]][1] > 5e6]
+    if len(firsts) < 2:
+        return None
+    lo, hi = firsts[-2], firsts[-1]
+    return sum(r[2] for r in rows[lo:hi])
+
+
 def main(fetch_db, write_db, out_json, source):
     f, w = per_kernel(fetch_db), per_kernel(write_db)
+    sf, sw = step_total(fetch_db), step_total(write_db)
     kernels = {}
     for t in sorted(set(f) & set(w)):
         n = f[t][0]
         fetch_b, write_b = 2.0 * f[t][1] * 1024.0 / n, w[t][1] * 1024.0 / w[t][0]
         kernels[t] = {"launches": n, "fetch_bytes_per_launch": int(fetch_b), "write_bytes_per_launch": int(write_b),
                       "bytes_per_launch": int(fetch_b + write_b)}
-    json.dump({"kernels": kernels, "source": source}, open(out_json, "w"), indent=1)
+    step = None
+    if sf is not None and sw is not None:
+        step = {"fetch_bytes": int(2.0 * sf * 1024.0), "write_bytes": int(sw * 1024.0),
+                "bytes": int(2.0 * sf * 1024.0 + sw * 1024.0)}
+        print("whole training step: fetch %.2f GB  write %.2f GB  total %.2f GB" % (step["fetch_bytes"] / 1e9,
+              step["write_bytes"] / 1e9, step["bytes"] / 1e9))
+    json.dump({"kernels": kernels, "step": step, "source": source}, open(out_json, "w"), indent=1)
     for t, v in kernels.items():
         print("%-40s launches %5d  fetch %8.1f MB  write %8.1f MB  total %8.1f MB / launch"
               % (t, v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["bytes_per_launch"] / 1e6))
