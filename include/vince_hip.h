@@ -70,6 +70,13 @@ typedef struct vince_conv_desc {
     int32_t wt0, wta, wtb, WT;  /* weight tap index; weights are [Co][WT][Ci] */
     int32_t OH, OW;             /* output tensor [N][OH][OW][Co] */
     int32_t osh, osw, oh0, ow0; /* grid -> output pixel */
+    int32_t Cs, Kw;             /* packed row taps, 0 / 0 = off.  Cs (< Ci) = element stride between input pixels and
+                                 * Kw = kernel width: tap a reads the Ci contiguous elements (Ci / Cs pixels of one
+                                 * input row) that start at pixel (ho*sh + dh0 + a*dhs, wo*sw + dw0); TB must be 1.
+                                 * Weight element k of a tap is (kw = k / Cs, c = k % Cs) and must be zero where
+                                 * kw >= Kw or c is a padding channel.  This is how the 7x7 stem (resnet.py:170) runs
+                                 * with K = 7 x 32 instead of 49 taps x 8 padded channels: the input is stored
+                                 * [N][H][Wp][4] with zero margins (vince_input_nchw_to_rows). */
 } vince_conv_desc;
 
 /* Per-channel BatchNorm reductions are accumulated with fp64 atomics into VINCE_STATS_REPLICAS interleaved copies
@@ -177,6 +184,12 @@ int vince_input_nchw_to_nhwc(int dtype, const float* in, const int64_t* perm, vo
 /* jigsaw tiling (vince_model.py:144-155): float NCHW [N][C][H][W] -> dtype NHWC [9N][th][tw][Cp], zero pad */
 int vince_jigsaw_nchw_to_nhwc(int dtype, const float* in, void* out, int32_t N, int32_t C, int32_t H, int32_t W,
                               int32_t th, int32_t tw, int32_t Cp, void* stream);
+/* The packed-row-tap input layout of the stem (vince_conv_desc.Cs): dtype [N][H][Wp][4], image column w at index
+ * w + left, channel 3 and the columns outside [left, left + W) zero.  Same `perm` / jigsaw semantics as above. */
+int vince_input_nchw_to_rows(int dtype, const float* in, const int64_t* perm, void* out, int32_t N, int32_t C,
+                             int32_t H, int32_t W, int32_t Wp, int32_t left, void* stream);
+int vince_jigsaw_nchw_to_rows(int dtype, const float* in, void* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                              int32_t th, int32_t tw, int32_t Wp, int32_t left, void* stream);
 /* fp32 master weights [Co][T][Ci] -> compute copy [Co][T][Cip] (dtype) and, if wt != NULL, the dgrad copy
  * [Ci][T][Co] (dtype). */
 int vince_prepare_weight(int dtype, const float* w, void* wk, void* wt, int32_t Co, int32_t T, int32_t Ci,
@@ -187,6 +200,8 @@ typedef struct vince_prep_entry {
     void* wk;      /* dtype [Co][T][Cip] */
     void* wt;      /* dtype [Ci][T][Co] or NULL */
     int32_t Co, T, Ci, Cip;
+    int32_t Cs, Kw; /* packed row taps (0 / 0 = off): w is float [Co][T][Kw][Ci], wk element k of tap t is
+                     * (kw = k / Cs, c = k % Cs) -> w[co][t][kw][c], zero where kw >= Kw or c >= Ci */
 } vince_prep_entry;
 int vince_prepare_weights_batched(int dtype, const vince_prep_entry* table_dev, int32_t n, void* stream);
 

@@ -119,6 +119,39 @@ def test_conv_stem(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hw", [(32, 32), (45, 51), (224, 224)])
+def test_conv_stem_packed_rows(dtype, hw):
+    """The engine's stem: 7 packed row taps over the [N][H][Wp][4] layout == conv2d(7x7, stride 2, pad 3), fwd + wgrad."""
+    ops = _ops()
+    H, W = hw
+    N = 2
+    x = q(rnd(N, 3, H, W, seed=3), dtype)
+    w = q(rnd(64, 3, 7, 7, seed=4, scale=(2.0 / 147) ** 0.5), dtype).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 3)
+    dy = q(rnd(*y.shape, seed=5), dtype)
+    y.backward(dy)
+    xin = ops.input_nchw_to_rows(x.to(DEV), dtype)
+    Wp = ops.stem_row_width(W)
+    assert xin.shape == (N, H, Wp, 4)
+    torch.testing.assert_close(xin[:, :, 3:3 + W, :3].float().cpu(), x.permute(0, 2, 3, 1), rtol=0, atol=0)
+    assert float(xin[:, :, :3].abs().max()) == 0.0 and float(xin[:, :, 3 + W:].abs().max()) == 0.0
+    assert float(xin[..., 3].abs().max()) == 0.0
+    # packed weights [Co][kh][kw*4 + c], zero at kw = 7 and c = 3
+    wp = torch.zeros(64, 7, 8, 4)
+    wp[:, :, :7, :3] = w.detach().permute(0, 2, 3, 1)
+    wk = wp.reshape(64, 7, 32).to(DEV).to(dtype).contiguous()
+    d = ops.stem_desc(N, H, W)
+    out = torch.empty(N, d.Ho, d.Wo, 64, device=DEV, dtype=dtype)
+    stats = torch.zeros(ops.STATS_REPLICAS, 64, 2, device=DEV, dtype=torch.float64)
+    ops.conv_igemm(d, xin, wk, out, stats=stats)
+    assert_close(from_nhwc(out), y.detach(), dtype, what="packed stem conv")
+    dw = torch.zeros(64, 49, 3, device=DEV)
+    ops.conv_wgrad(d, xin, to_nhwc(dy, dtype), dw, ci_dw=3)
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(64, 49, 3)
+    assert_close(dw, ref_dw, dtype, f32=1e-4, what="packed stem wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", CONVS)
 def test_conv_dgrad_wgrad(cfg, dtype):
     ops = _ops()
@@ -331,6 +364,13 @@ def test_jigsaw_and_layouts():
         out = ops.jigsaw_nchw_to_nhwc(x.to(DEV), torch.float32)
         assert list(out.shape[:3]) == [18, ref.shape[2], ref.shape[3]]
         torch.testing.assert_close(from_nhwc(out)[:, :3], ref, rtol=0, atol=0)
+        for dt in DTYPES:   # the packed stem layout of the same tiles: [9N][th][Wp][4], zero margins
+            rows = ops.jigsaw_nchw_to_rows(x.to(DEV), dt)
+            tw = ref.shape[3]
+            assert rows.shape == (18, ref.shape[2], ops.stem_row_width(tw), 4)
+            torch.testing.assert_close(rows[:, :, 3:3 + tw, :3].float().cpu().permute(0, 3, 1, 2), q(ref, dt), rtol=0, atol=0)
+            assert float(rows[:, :, :3].abs().max()) == 0.0 and float(rows[:, :, 3 + tw:].abs().max()) == 0.0
+            assert float(rows[..., 3].abs().max()) == 0.0
     x = rnd(3, 3, 10, 12, seed=36)
     perm = torch.tensor([2, 0, 1])
     out = ops.input_nchw_to_nhwc(x.to(DEV), torch.float32, perm=perm.to(DEV))

@@ -15,7 +15,7 @@ c_void_p, c_int, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int32) for n in (
         "N", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "sh", "sw", "TA", "TB", "dh0", "dhs", "dw0", "dws",
-        "wt0", "wta", "wtb", "WT", "OH", "OW", "osh", "osw", "oh0", "ow0")]
+        "wt0", "wta", "wtb", "WT", "OH", "OW", "osh", "osw", "oh0", "ow0", "Cs", "Kw")]
 
 
 class BnReduce(ctypes.Structure):
@@ -63,6 +63,10 @@ PROTOTYPES = {
                                          c_void_p]),
     "vince_jigsaw_nchw_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_void_p]),
+    "vince_input_nchw_to_rows": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         c_int32, c_void_p]),
+    "vince_jigsaw_nchw_to_rows": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                          c_int32, c_int32, c_void_p]),
     "vince_prepare_weight": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "vince_prepare_weights_batched": (c_int, [c_int, c_void_p, c_int32, c_void_p]),
     "vince_nhwc_to_nchw_f32": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

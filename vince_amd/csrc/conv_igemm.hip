@@ -29,6 +29,7 @@ namespace {
 struct ConvParams {
     vince_conv_desc d;
     int log2_cpt, cpt_mask, total_chunks, nkt, M, ptiles, ctiles, uniform_taps, ablate;
+    int cs;             // element stride between input pixels (= Ci unless the descriptor packs row taps)
     int kt_per_split;   // > 0: split-K (grid.y splits, fp32 atomics into a zeroed output; f32 only)
     int variant;   // host side: which kernel the launcher picked (0 = 128-pixel tile, 1 = 256-pixel tile, 2 = register-staged)
     uint32_t tb_mul;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             const int hi = hb[e] + dh, wi = wb[e] + dw;
             const bool ok = rv[e] && qv && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *(const uint4*)(in + (nb[e] + (size_t)hi * d.Wi + wi) * d.Ci + (size_t)cc * CH);
+            if (ok) v = *(const uint4*)(in + (nb[e] + (size_t)hi * d.Wi + wi) * p.cs + (size_t)cc * CH);
             xr[e] = v;
         }
 #pragma unroll
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
         for (int e = 0; e < XROWS; ++e) {
             const int hi = hb[e] + dh, wi = wb[e] + dw;
             const bool ok = rv[e] && qv && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
-            offx[e] = ok ? ((nb[e] + (uint32_t)(hi * d.Wi + wi)) * (uint32_t)d.Ci + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
+            offx[e] = ok ? ((nb[e] + (uint32_t)(hi * d.Wi + wi)) * (uint32_t)p.cs + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
         }
 #pragma unroll
         for (int e = 0; e < WROWS; ++e) {
@@ -627,6 +628,15 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     VINCE_CHECK_ARG(d.N > 0 && d.Hi > 0 && d.Wi > 0 && d.Ho > 0 && d.Wo > 0 && d.Co > 0 && d.Ci > 0, VINCE_E_SHAPE,
                     "vince_conv_igemm: non-positive dimension");
     VINCE_CHECK_ARG(d.Ci % CH == 0, VINCE_E_SHAPE, "vince_conv_igemm: Ci=%d not a multiple of %d", d.Ci, CH);
+    if (d.Cs > 0) {   // packed row taps: every tap start must stay 16-byte aligned and inside its input row
+        const int eb = dtype == VINCE_F32 ? 4 : 2;
+        VINCE_CHECK_ARG(d.TB == 1 && d.Cs < d.Ci && d.Ci % d.Cs == 0 && d.Kw > 0 && d.Kw <= d.Ci / d.Cs, VINCE_E_SHAPE,
+                        "vince_conv_igemm: packed row taps need TB=1, Cs | Ci, 0 < Kw <= Ci/Cs");
+        VINCE_CHECK_ARG((d.Cs * eb) % 8 == 0 && (d.sw * d.Cs * eb) % 16 == 0 && (d.dw0 * d.Cs * eb) % 16 == 0 &&
+                        (d.Wi * d.Cs * eb) % 16 == 0, VINCE_E_ALIGN, "vince_conv_igemm: packed row taps must start 16-byte aligned");
+        VINCE_CHECK_ARG(d.dw0 >= 0 && (d.Wo - 1) * d.sw + d.dw0 + d.Ci / d.Cs <= d.Wi, VINCE_E_SHAPE,
+                        "vince_conv_igemm: packed row taps must stay inside the (padded) input row");
+    }
     VINCE_CHECK_ARG(d.Co % CH == 0, VINCE_E_SHAPE, "vince_conv_igemm: Co=%d not a multiple of %d", d.Co, CH);
     VINCE_CHECK_ARG(d.TA >= 1 && d.TB >= 1 && d.TB <= 8 && d.TA * d.TB <= 64, VINCE_E_SHAPE,
                     "vince_conv_igemm: tap grid %dx%d unsupported", d.TA, d.TB);
@@ -655,12 +665,13 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.w = w; p.out = out; p.e = e;
     p.variant = 0;
+    p.cs = d.Cs > 0 ? d.Cs : d.Ci;
     p.kt_per_split = 0;
     static int ablate = getenv("VINCE_CONV_ABLATE") ? atoi(getenv("VINCE_CONV_ABLATE")) : 0;   // measurement aid only
     p.ablate = ablate;
     {
         const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;
-        const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * d.Ci * esz, wb = (unsigned long long)d.Co * d.WT * d.Ci * esz;
+        const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * p.cs * esz, wb = (unsigned long long)d.Co * d.WT * d.Ci * esz;
         p.in_bytes = ib < 0x7ff00000ull ? (uint32_t)ib : 0;   // the direct-to-LDS path addresses with 31-bit offsets
         p.w_bytes = wb < 0x7ff00000ull ? (uint32_t)wb : 0;
     }
@@ -685,7 +696,8 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     void* tok = nullptr;
     if (vince_profile_enabled()) {
         // algorithmic FLOPs: the stem's input channels are padded 3 -> CH; count the 3 real ones
-        const double ci_alg = (d.Ci == CH && T > 1) ? 3.0 : (double)d.Ci;
+        // (the stem: 3 real channels behind the padding, and Kw real pixels per packed row tap)
+        const double ci_alg = d.Cs > 0 ? 3.0 * d.Kw : ((d.Ci == CH && T > 1) ? 3.0 : (double)d.Ci);
         vince_profile_begin_launch(0, 2.0 * p.M * d.Co * T * ci_alg, stream, &tok);
         vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh * 10 + d.osh, e.flags);
     }

@@ -27,6 +27,7 @@ struct WgradParams {
     float* dw;
     uint32_t in_bytes, dy_bytes;   // descriptor ranges for the direct-to-LDS variant (0 = tensor too large)
     int linear_x;                  // 1x1 / stride 1 / no padding: the input pixel IS the output pixel
+    int cs;                        // element stride between input pixels (= Ci unless the descriptor packs row taps)
 };
 
 constexpr int KP = 64;  // pixels per K tile
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 const uint32_t wo = rem - ho * p.div_wo.d;
                 const int hi = (int)(ho * d.sh) + dh, wi = (int)(wo * d.sw) + dw_;
                 if ((unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi)
-                    v = *(const uint4*)(in + (((size_t)n * d.Hi + hi) * d.Wi + wi) * d.Ci + (size_t)cc * CH);
+                    v = *(const uint4*)(in + (((size_t)n * d.Hi + hi) * d.Wi + wi) * p.cs + (size_t)cc * CH);
             }
             xr[e] = v;
         }
@@ -199,15 +200,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         const int n = n0 + wn * (NT / 2) + i * 32 + (lane & 31);
         const int tp = (T_ == 1) ? 0 : (n >> p.log2_ci);
         const int ci = (T_ == 1) ? n : (n & ((1 << p.log2_ci) - 1));
-        if (tp >= T_ || ci >= p.Ci_dw || (T_ == 1 && n >= d.Ci)) continue;
+        if (tp >= T_ || (T_ == 1 && n >= d.Ci)) continue;
         const int a = (int)(((uint32_t)tp * p.tb_mul) >> 16), b = tp - a * d.TB;
-        const int widx = d.wt0 + a * d.wta + b * d.wtb;
+        int widx = d.wt0 + a * d.wta + b * d.wtb, wtn = d.WT, cdst = ci;
+        if (d.Cs > 0) {   // packed row taps: element ci of tap a is (kw, c); dw is [Co][TA][Kw][Ci_dw]
+            const int kw = ci / d.Cs;
+            cdst = ci - kw * d.Cs;
+            if (kw >= d.Kw) continue;
+            widx = widx * d.Kw + kw;
+            wtn = d.WT * d.Kw;
+        }
+        if (cdst >= p.Ci_dw) continue;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = c0 + wc * (CT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < d.Co) unsafeAtomicAdd(p.dw + ((size_t)co * d.WT + widx) * p.Ci_dw + ci, acc[j][i][r]);
+                if (co < d.Co) unsafeAtomicAdd(p.dw + ((size_t)co * wtn + widx) * p.Ci_dw + cdst, acc[j][i][r]);
             }
         }
     }
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
                     const uint32_t wo = rem - ho * p.div_wo.d;
                     const int hi = (int)(ho * d.sh) + dh, wi = (int)(wo * d.sw) + dw_;
                     if ((unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi)
-                        off = ((n * (uint32_t)d.Hi + hi) * (uint32_t)d.Wi + wi) * (uint32_t)d.Ci * (uint32_t)sizeof(T) + xcol_off;
+                        off = ((n * (uint32_t)d.Hi + hi) * (uint32_t)d.Wi + wi) * (uint32_t)p.cs * (uint32_t)sizeof(T) + xcol_off;
                 }
             }
             lds_dma16(xs + e * 4096, off, rsrc_x);
@@ -378,15 +387,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
         const int n = n0 + wn * (NT / 2) + i * 32 + (lane & 31);
         const int tp = (T_ == 1) ? 0 : (n >> p.log2_ci);
         const int ci = (T_ == 1) ? n : (n & ((1 << p.log2_ci) - 1));
-        if (tp >= T_ || ci >= p.Ci_dw || (T_ == 1 && n >= d.Ci)) continue;
+        if (tp >= T_ || (T_ == 1 && n >= d.Ci)) continue;
         const int a = (int)(((uint32_t)tp * p.tb_mul) >> 16), b = tp - a * d.TB;
-        const int widx = d.wt0 + a * d.wta + b * d.wtb;
+        int widx = d.wt0 + a * d.wta + b * d.wtb, wtn = d.WT, cdst = ci;
+        if (d.Cs > 0) {   // packed row taps: element ci of tap a is (kw, c); dw is [Co][TA][Kw][Ci_dw]
+            const int kw = ci / d.Cs;
+            cdst = ci - kw * d.Cs;
+            if (kw >= d.Kw) continue;
+            widx = widx * d.Kw + kw;
+            wtn = d.WT * d.Kw;
+        }
+        if (cdst >= p.Ci_dw) continue;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = c0 + wc * (CT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < d.Co) unsafeAtomicAdd(p.dw + ((size_t)co * d.WT + widx) * p.Ci_dw + ci, acc[j][i][r]);
+                if (co < d.Co) unsafeAtomicAdd(p.dw + ((size_t)co * wtn + widx) * p.Ci_dw + cdst, acc[j][i][r]);
             }
         }
     }
@@ -448,7 +465,16 @@ extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void
                     "vince_conv_wgrad: non-positive dimension");
     VINCE_CHECK_ARG(d.Ci % CH == 0 && d.Co % CH == 0, VINCE_E_SHAPE, "vince_conv_wgrad: Ci=%d / Co=%d not multiples of %d",
                     d.Ci, d.Co, CH);
-    VINCE_CHECK_ARG(Ci_dw >= 1 && Ci_dw <= d.Ci, VINCE_E_SHAPE, "vince_conv_wgrad: Ci_dw=%d out of range", Ci_dw);
+    VINCE_CHECK_ARG(Ci_dw >= 1 && Ci_dw <= (d.Cs > 0 ? d.Cs : d.Ci), VINCE_E_SHAPE, "vince_conv_wgrad: Ci_dw=%d out of range", Ci_dw);
+    if (d.Cs > 0) {
+        const int eb = dtype == VINCE_F32 ? 4 : 2;
+        VINCE_CHECK_ARG(d.TB == 1 && d.Cs < d.Ci && d.Ci % d.Cs == 0 && d.Kw > 0 && d.Kw <= d.Ci / d.Cs, VINCE_E_SHAPE,
+                        "vince_conv_wgrad: packed row taps need TB=1, Cs | Ci, 0 < Kw <= Ci/Cs");
+        VINCE_CHECK_ARG((d.Cs * eb) % 8 == 0 && (d.sw * d.Cs * eb) % 16 == 0 && (d.dw0 * d.Cs * eb) % 16 == 0 &&
+                        (d.Wi * d.Cs * eb) % 16 == 0, VINCE_E_ALIGN, "vince_conv_wgrad: packed row taps must start 16-byte aligned");
+        VINCE_CHECK_ARG(d.dw0 >= 0 && (d.Wo - 1) * d.sw + d.dw0 + d.Ci / d.Cs <= d.Wi, VINCE_E_SHAPE,
+                        "vince_conv_wgrad: packed row taps must stay inside the (padded) input row");
+    }
     VINCE_CHECK_ARG(d.TA >= 1 && d.TB >= 1 && d.TB <= 8 && d.TA * d.TB <= 64, VINCE_E_SHAPE,
                     "vince_conv_wgrad: tap grid %dx%d unsupported", d.TA, d.TB);
     VINCE_CHECK_ARG((long long)d.N * d.Ho * d.Wo < (1ll << 31), VINCE_E_SHAPE, "vince_conv_wgrad: too many pixels");
@@ -474,9 +500,10 @@ extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void
     p.div_howo = make_fastdiv((uint32_t)(d.Ho * d.Wo));
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.dy = dy; p.dw = dw; p.Ci_dw = Ci_dw; p.variant = variant;
+    p.cs = d.Cs > 0 ? d.Cs : d.Ci;
     {
         const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;
-        const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * d.Ci * esz, yb = (unsigned long long)p.M * d.Co * esz;
+        const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * p.cs * esz, yb = (unsigned long long)p.M * d.Co * esz;
         p.in_bytes = ib < 0x7ff00000ull ? (uint32_t)ib : 0;
         p.dy_bytes = yb < 0x7ff00000ull ? (uint32_t)yb : 0;
         p.linear_x = (T == 1 && d.sh == 1 && d.sw == 1 && d.dh0 == 0 && d.dw0 == 0 && d.Hi == d.Ho && d.Wi == d.Wo) ? 1 : 0;
@@ -485,7 +512,7 @@ extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void
     void* tok = nullptr;
     if (vince_profile_enabled())
     {
-        vince_profile_begin_launch(dtype == VINCE_F32 ? 12 : 13, 2.0 * p.M * d.Co * T * (double)Ci_dw, stream, &tok);
+        vince_profile_begin_launch(dtype == VINCE_F32 ? 12 : 13, 2.0 * p.M * d.Co * T * (double)Ci_dw * (d.Cs > 0 ? d.Kw : 1), stream, &tok);
         vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh, 0);
     }
     const int rc = dtype == VINCE_F32 ? dispatch<float>(p, s) : dispatch<bf16_t>(p, s);

@@ -52,6 +52,56 @@ __global__ __launch_bounds__(256) void jigsaw_to_nhwc_kernel(const float* __rest
     }
 }
 
+// Packed-row-tap layouts (4 channels per pixel, zero margins): one thread per output pixel incl. the margins.
+template <typename T>
+__device__ __forceinline__ void store_px4(T* out, size_t pix, const float (&f)[4]) {
+    if constexpr (sizeof(T) == 4) {
+        *(float4*)((float*)out + pix * 4) = make_float4(f[0], f[1], f[2], f[3]);
+    } else {
+        *(uint2*)((bf16_t*)out + pix * 4) = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void input_to_rows_kernel(const float* __restrict__ in, const int64_t* __restrict__ perm,
+                                                            T* __restrict__ out, int N, int C, int H, int W, int Wp, int left) {
+    const int64_t total = (int64_t)N * H * Wp;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int wp = (int)(idx % Wp);
+        const int64_t r = idx / Wp;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        const int w = wp - left;
+        const bool inside = w >= 0 && w < W;
+        const int64_t src_n = perm ? perm[n] : n;
+        float f[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) f[c] = (c < C && inside) ? in[(((size_t)src_n * C + c) * H + h) * W + w] : 0.f;
+        store_px4<T>(out, (size_t)idx, f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void jigsaw_to_rows_kernel(const float* __restrict__ in, T* __restrict__ out, int N, int C,
+                                                             int H, int W, int th, int tw, int Wp, int left) {
+    const int64_t total = (int64_t)N * 9 * th * Wp;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int wp = (int)(idx % Wp);
+        int64_t r = idx / Wp;
+        const int y = (int)(r % th);
+        r /= th;
+        const int tile = (int)(r % 9);
+        const int n = (int)(r / 9);
+        const int x = wp - left;
+        const int sy = (tile / 3) * th + y, sx = (tile % 3) * tw + x;
+        const bool inside = x >= 0 && x < tw && sy < H && sx < W;   // F.pad zero padding (vince_model.py:146) + margins
+        float f[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) f[c] = (c < C && inside) ? in[(((size_t)n * C + c) * H + sy) * W + sx] : 0.f;
+        store_px4<T>(out, (size_t)idx, f);
+    }
+}
+
 template <typename T> __device__ inline T cvt_from_f32(float f);
 template <> __device__ inline float cvt_from_f32<float>(float f) { return f; }
 template <> __device__ inline bf16_t cvt_from_f32<bf16_t>(float f) { return f32_to_bf16(f); }
@@ -83,6 +133,16 @@ __global__ __launch_bounds__(256) void prepare_weights_batched_kernel(const vinc
     const float* __restrict__ w = (const float*)e.w;
     T* __restrict__ wk = (T*)e.wk;
     T* __restrict__ wt = (T*)e.wt;
+    if (e.Cs > 0) {   // packed row taps (the stem): wk[co][t][k] = w[co][t][k / Cs][k % Cs]
+        const int64_t total = (int64_t)e.Co * e.T * e.Cip;
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+            const int k = (int)(idx % e.Cip);
+            const int64_t r = idx / e.Cip;   // co * T + t
+            const int kw = k / e.Cs, c = k - kw * e.Cs;
+            wk[idx] = cvt_from_f32<T>((kw < e.Kw && c < e.Ci) ? w[((size_t)r * e.Kw + kw) * e.Ci + c] : 0.f);
+        }
+        return;
+    }
     if (tiled && wt && e.Ci % 64 == 0 && e.Co % 64 == 0 && e.Cip == e.Ci) {
         // 64 x 64 (co x ci) tiles through LDS: the [Co][T][Ci] copy and its [Ci][T][Co] transpose are both written in
         // whole rows (element-wise transposed stores cost ~5x their bytes in partial-line HBM writes)
@@ -403,6 +463,39 @@ int vince_zero_async(void* ptr, size_t bytes, void* stream) {
     const size_t n16 = bytes / 16;
     const unsigned grid = (unsigned)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
     hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4*)ptr, n16);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_input_nchw_to_rows(int dtype, const float* in, const int64_t* perm, void* out, int32_t N, int32_t C,
+                                        int32_t H, int32_t W, int32_t Wp, int32_t left, void* stream) {
+    DTYPE_OK("vince_input_nchw_to_rows");
+    VINCE_CHECK_ARG(in && out && N > 0 && C >= 1 && C <= 4 && H > 0 && W > 0 && left >= 0 && Wp >= W + left, VINCE_E_ARG,
+                    "vince_input_nchw_to_rows: bad arguments");
+    const int64_t total = (int64_t)N * H * Wp;
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(input_to_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, perm,
+                           (float*)out, N, C, H, W, Wp, left);
+    else
+        hipLaunchKernelGGL(input_to_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, perm,
+                           (bf16_t*)out, N, C, H, W, Wp, left);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_jigsaw_nchw_to_rows(int dtype, const float* in, void* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                                         int32_t th, int32_t tw, int32_t Wp, int32_t left, void* stream) {
+    DTYPE_OK("vince_jigsaw_nchw_to_rows");
+    VINCE_CHECK_ARG(in && out && N > 0 && C >= 1 && C <= 4 && H > 0 && W > 0 && th > 0 && tw > 0 && left >= 0 &&
+                    Wp >= tw + left, VINCE_E_ARG, "vince_jigsaw_nchw_to_rows: bad arguments");
+    VINCE_CHECK_ARG(3 * th >= H && 3 * tw >= W, VINCE_E_SHAPE, "vince_jigsaw_nchw_to_rows: 3x3 tiles do not cover the image");
+    const int64_t total = (int64_t)N * 9 * th * Wp;
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(jigsaw_to_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                           (float*)out, N, C, H, W, th, tw, Wp, left);
+    else
+        hipLaunchKernelGGL(jigsaw_to_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                           (bf16_t*)out, N, C, H, W, th, tw, Wp, left);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

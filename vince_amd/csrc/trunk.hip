@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <array>
 #include <string>
 #include <vector>
@@ -53,6 +54,7 @@ struct vince_trunk {
     ConvL stem;
     BnL stem_bn;
     int sH, sW, pH, pW;   // stem conv output, pool output
+    int sWp;              // padded row length of the packed stem input
     int outC, outH, outW;
     int nparams, nbn;
     std::vector<std::string> pnames;
@@ -98,7 +100,9 @@ struct Planner {
         t->pbn.push_back(-1);
         t->pshape.push_back({Co, Ci, k, k});
         c.wk = wc;
-        wc = align_up(wc + (size_t)Co * k * k * c.Cip * t->esize);
+        // (the 3-channel stem keeps room for either formulation: 49 taps x padded channels, or 7 packed row taps x 32)
+        const size_t wk_elems = Ci < t->CH ? std::max((size_t)Co * k * k * c.Cip, (size_t)Co * k * 32) : (size_t)Co * k * k * c.Cip;
+        wc = align_up(wc + wk_elems * t->esize);
         if (want_wt) {
             c.wt = wc;
             wc = align_up(wc + (size_t)Ci * k * k * Co * t->esize);
@@ -141,6 +145,31 @@ vince_conv_desc fwd_desc(const vince_trunk* t, const ConvL& c) {
     d.dh0 = d.dw0 = -c.pad; d.dhs = d.dws = 1;
     d.wt0 = 0; d.wta = c.k; d.wtb = 1; d.WT = c.k * c.k;
     d.OH = c.Ho; d.OW = c.Wo; d.osh = d.osw = 1; d.oh0 = d.ow0 = 0;
+    d.Cs = d.Kw = 0;
+    return d;
+}
+
+// The 7x7/s2/p3 stem as 7 packed row taps (vince_conv_desc.Cs): the input is stored [N][H][sWp][4] with 3 zero columns on
+// the left, so tap kh of output column wo is the 8 consecutive pixels (32 elements, 16-byte aligned) starting at padded
+// column 2*wo -- K = 7 x 32 instead of 49 taps x 8 padded channels, one 64-byte (bf16) LDS-DMA row per tap.
+constexpr int STEM_CS = 4, STEM_K = 32, STEM_LEFT = 3;
+bool stem_packed() {
+    static const bool on = !(getenv("VINCE_STEM_PACKED") && atoi(getenv("VINCE_STEM_PACKED")) == 0);
+    return on;
+}
+vince_conv_desc fwd_desc(const vince_trunk* t, const ConvL& c);
+vince_conv_desc stem_desc(const vince_trunk* t) {
+    const ConvL& c = t->stem;
+    if (!stem_packed()) return fwd_desc(t, c);
+    vince_conv_desc d;
+    d.N = t->cfg.N; d.Hi = c.Hi; d.Wi = t->sWp; d.Ci = STEM_K;
+    d.Ho = c.Ho; d.Wo = c.Wo; d.Co = c.Co;
+    d.sh = d.sw = 2;
+    d.TA = 7; d.TB = 1;
+    d.dh0 = -3; d.dhs = 1; d.dw0 = 0; d.dws = 0;
+    d.wt0 = 0; d.wta = 1; d.wtb = 0; d.WT = 7;
+    d.OH = c.Ho; d.OW = c.Wo; d.osh = d.osw = 1; d.oh0 = d.ow0 = 0;
+    d.Cs = STEM_CS; d.Kw = 7;
     return d;
 }
 
@@ -163,6 +192,7 @@ int dgrad_descs(const vince_trunk* t, const ConvL& c, vince_conv_desc out[4]) {
             d.dw0 = (pw + p - s0) / s; d.dws = -1;
             d.wt0 = r0 * k + s0; d.wta = s * k; d.wtb = s; d.WT = k * k;
             d.OH = c.Hi; d.OW = c.Wi; d.osh = d.osw = s; d.oh0 = ph; d.ow0 = pw;
+            d.Cs = d.Kw = 0;
             out[n++] = d;
         }
     return n;
@@ -185,8 +215,10 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     t->max_act = 0;
     Planner P{t};
     const int N = cfg->N;
-    t->off_x0 = P.alloc_act((size_t)N * cfg->H * cfg->W * t->Cp);
     t->stem = P.conv("conv1", 3, 64, 7, 2, 3, cfg->H, cfg->W, false);
+    t->sWp = (2 * t->stem.Wo + 6 + 1) & ~1;   // last tap row ends at padded column 2*(Wo-1) + 8; even for 16-byte rows
+    // (room for either stem formulation: VINCE_STEM_PACKED=0 selects the 49-tap one, a measurement / cross-check aid)
+    t->off_x0 = P.alloc_act(std::max((size_t)N * cfg->H * t->sWp * STEM_CS, (size_t)N * cfg->H * cfg->W * t->Cp));
     t->stem_bn = P.bn("bn1", 64);
     t->sH = t->stem.Ho; t->sW = t->stem.Wo;
     t->pH = (t->sH + 2 - 3) / 2 + 1; t->pW = (t->sW + 2 - 3) / 2 + 1;
@@ -309,11 +341,6 @@ extern "C" const void* vince_trunk_spatial_ptr(vince_trunk_t t, const void* work
 
 namespace {
 
-int prep_one(vince_trunk* t, const ConvL& c, const float* const* params, void* wcache, void* stream) {
-    return vince_prepare_weight(t->cfg.dtype, params[c.param], at(wcache, c.wk), c.wt == NONE ? nullptr : at(wcache, c.wt),
-                                c.Co, c.k * c.k, c.Ci, c.Cip, stream);
-}
-
 struct Ctx {
     vince_trunk* t;
     const float* const* params;
@@ -329,8 +356,8 @@ struct Ctx {
 #define RC(expr) do { int _rc = (expr); if (_rc != VINCE_OK) return _rc; } while (0)
 
 int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_off, float* const* bn_running,
-                int64_t* const* bn_nbt, int train_bn) {
-    vince_conv_desc d = fwd_desc(c.t, cv);
+                int64_t* const* bn_nbt, int train_bn, const vince_conv_desc* desc = nullptr) {
+    vince_conv_desc d = desc ? *desc : fwd_desc(c.t, cv);
     vince_conv_epi e;
     memset(&e, 0, sizeof(e));
     e.stats = train_bn ? c.stats(bn) : nullptr;
@@ -403,10 +430,18 @@ extern "C" int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* 
         e.w = params[c.param];
         e.wk = at(wcache, c.wk);
         e.wt = c.wt == NONE ? nullptr : at(wcache, c.wt);
-        e.Co = c.Co; e.T = c.k * c.k; e.Ci = c.Ci; e.Cip = c.Cip;
+        e.Co = c.Co; e.T = c.k * c.k; e.Ci = c.Ci; e.Cip = c.Cip; e.Cs = e.Kw = 0;
         tab.push_back(e);
     };
-    add(t->stem);
+    {   // stem: packed row taps
+        vince_prep_entry e;
+        e.w = params[t->stem.param];
+        e.wk = at(wcache, t->stem.wk);
+        e.wt = nullptr;
+        e.Co = t->stem.Co; e.T = 7; e.Ci = 3; e.Cip = STEM_K; e.Cs = STEM_CS; e.Kw = 7;
+        if (!stem_packed()) { e.T = 49; e.Cip = t->stem.Cip; e.Cs = e.Kw = 0; }
+        tab.push_back(e);
+    }
     for (const Blk& b : t->blocks) {
         for (int ci = 0; ci < b.nconv; ++ci) add(b.c[ci]);
         if (b.has_ds) add(b.cd);
@@ -437,15 +472,23 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     const int N = t->cfg.N;
     if (train_bn)
         RC(vince_zero_async(at(workspace, t->off_stats), t->n_stats_doubles * sizeof(double), stream));
-    if (jig_h > 0) {
+    if (!stem_packed()) {
+        if (jig_h > 0)
+            RC(vince_jigsaw_nchw_to_nhwc(c.dtype, input, at(workspace, t->off_x0), N / 9, 3, jig_h, jig_w, t->cfg.H, t->cfg.W,
+                                         t->Cp, stream));
+        else
+            RC(vince_input_nchw_to_nhwc(c.dtype, input, perm, at(workspace, t->off_x0), N, 3, t->cfg.H, t->cfg.W, t->Cp, stream));
+    } else if (jig_h > 0) {
         VINCE_CHECK_ARG(N % 9 == 0, VINCE_E_SHAPE, "vince_trunk_forward: jigsaw needs N multiple of 9");
-        RC(vince_jigsaw_nchw_to_nhwc(c.dtype, input, at(workspace, t->off_x0), N / 9, 3, jig_h, jig_w, t->cfg.H, t->cfg.W,
-                                     t->Cp, stream));
+        RC(vince_jigsaw_nchw_to_rows(c.dtype, input, at(workspace, t->off_x0), N / 9, 3, jig_h, jig_w, t->cfg.H, t->cfg.W,
+                                     t->sWp, STEM_LEFT, stream));
     } else {
-        RC(vince_input_nchw_to_nhwc(c.dtype, input, perm, at(workspace, t->off_x0), N, 3, t->cfg.H, t->cfg.W, t->Cp, stream));
+        RC(vince_input_nchw_to_rows(c.dtype, input, perm, at(workspace, t->off_x0), N, 3, t->cfg.H, t->cfg.W, t->sWp, STEM_LEFT,
+                                    stream));
     }
+    const vince_conv_desc sd = stem_desc(t);
     // stem: conv 7x7/s2 -> BN -> ReLU -> maxpool 3x3/s2 (resnet.py:170-173); BN-apply + ReLU are fused into the pool
-    RC(conv_bn_fwd(c, t->stem, t->stem_bn, t->off_x0, t->off_ystem, bn_running, bn_nbt, train_bn));
+    RC(conv_bn_fwd(c, t->stem, t->stem_bn, t->off_x0, t->off_ystem, bn_running, bn_nbt, train_bn, &sd));
     RC(vince_stem_pool_fwd(c.dtype, at(workspace, t->off_ystem), c.consts(t->stem_bn, 0), c.consts(t->stem_bn, 1),
                            at(workspace, t->off_p0), (uint8_t*)at(workspace, t->off_amax), N, t->sH, t->sW, 64, stream));
     for (const Blk& b : t->blocks) {
@@ -591,7 +634,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     RC(vince_stem_pool_bwd(c.dtype, Z, (const uint8_t*)at(workspace, t->off_amax), DA, N, t->sH, t->sW, 64, stream));
     RC(next_dy());
     RC(bn_bwd(c, t->stem_bn, DA, nullptr, false, t->off_ystem, (int64_t)N * t->sH * t->sW, DY, nullptr, grads));
-    RC(wgrad_async(fwd_desc(t, t->stem), at(workspace, t->off_x0), grads[t->stem.param], 3));
+    RC(wgrad_async(stem_desc(t), at(workspace, t->off_x0), grads[t->stem.param], 3));
     if (overlap) {   // the caller's stream continues only after every weight gradient has landed
         VINCE_CHECK_HIP(hipEventRecord(t->ev_join, t->side));
         VINCE_CHECK_HIP(hipStreamWaitEvent(main_s, t->ev_join, 0));

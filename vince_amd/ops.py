@@ -53,6 +53,33 @@ def conv_desc(N, Hi, Wi, Ci, Co, k, stride, pad):
                     dw0=-pad, dws=1, wt0=0, wta=k, wtb=1, WT=k * k, OH=Ho, OW=Wo, osh=1, osw=1, oh0=0, ow0=0)
 
 
+STEM_CS, STEM_K, STEM_LEFT = 4, 32, 3   # csrc/trunk.hip stem_desc
+
+
+def stem_row_width(W):
+    """Padded row length of the packed-row-tap stem input for image width W (csrc/trunk.hip: sWp)."""
+    Wo = (W + 6 - 7) // 2 + 1
+    return (2 * Wo + 6 + 1) & ~1
+
+
+def stem_desc(N, H, W, Co=64):
+    """The 7x7 / stride 2 / pad 3 stem as 7 packed row taps over the [N][H][Wp][4] input layout (vince_conv_desc.Cs)."""
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    return ConvDesc(N=N, Hi=H, Wi=stem_row_width(W), Ci=STEM_K, Ho=Ho, Wo=Wo, Co=Co, sh=2, sw=2, TA=7, TB=1, dh0=-3, dhs=1,
+                    dw0=0, dws=0, wt0=0, wta=1, wtb=0, WT=7, OH=Ho, OW=Wo, osh=1, osw=1, oh0=0, ow0=0, Cs=STEM_CS, Kw=7)
+
+
+def input_nchw_to_rows(x, dtype, perm=None):
+    """float NCHW frames -> the packed stem layout [N][H][Wp][4] (zero margins, 3 columns on the left)."""
+    require_gpu(x, perm)
+    N, C, H, W = x.shape
+    Wp = stem_row_width(W)
+    out = torch.empty(N, H, Wp, STEM_CS, device=x.device, dtype=dtype)
+    check(lib().vince_input_nchw_to_rows(dtype_code(out), _ptr(x), _ptr(perm), _ptr(out), N, C, H, W, Wp, STEM_LEFT,
+                                         stream_ptr()))
+    return out
+
+
 def dgrad_descs(N, Hi, Wi, Ci, Co, k, stride, pad):
     """Input-gradient descriptors of the same conv: one per output-pixel parity class (csrc/trunk.hip dgrad_descs)."""
     Ho = (Hi + 2 * pad - k) // stride + 1
@@ -264,6 +291,21 @@ def jigsaw_nchw_to_nhwc(x, dtype):
     Cp = 4 if dtype == torch.float32 else 8
     out = torch.empty(N * 9, th, tw, Cp, device=x.device, dtype=dtype)
     check(lib().vince_jigsaw_nchw_to_nhwc(dtype_code(out), _ptr(x), _ptr(out), N, C, H, W, th, tw, Cp, stream_ptr()))
+    return out
+
+
+def jigsaw_nchw_to_rows(x, dtype):
+    """Jigsaw tiling (vince_model.py:144-155) straight into the packed stem layout [9N][th][Wp][4]."""
+    require_gpu(x)
+    N, C, H, W = x.shape
+    if H % 3 != 0 or W % 3 != 0:
+        Hp, Wq = H + 3 - H % 3, W + 3 - W % 3
+    else:
+        Hp, Wq = H, W
+    th, tw = Hp // 3, Wq // 3
+    Wp = stem_row_width(tw)
+    out = torch.empty(N * 9, th, Wp, STEM_CS, device=x.device, dtype=dtype)
+    check(lib().vince_jigsaw_nchw_to_rows(dtype_code(out), _ptr(x), _ptr(out), N, C, H, W, th, tw, Wp, STEM_LEFT, stream_ptr()))
     return out
 
 
