@@ -171,6 +171,16 @@ int vince_stem_pool_fwd(int dtype, const void* y, const float* scale, const floa
 /* g[n,h,w,c] = sum of dpool over the windows whose argmax is (h,w)  (zero where relu(bn(y)) == 0) */
 int vince_stem_pool_bwd(int dtype, const void* dpool, const uint8_t* argmax, void* g, int32_t N, int32_t H,
                         int32_t W, int32_t C, void* stream);
+/* Stem backward without the materialised pre-pool gradient g: the max-pool gather above fused into the BatchNorm
+ * backward of bn1 (resnet.py:171-173 under autograd).  _reduce accumulates (sum g, sum g*xhat) into sums[R][C][2]
+ * (zeroed by the caller); _apply folds the replicas, adds dgamma / dbeta and writes
+ * dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).  H, W: pre-pool size.  Results equal
+ * vince_stem_pool_bwd -> vince_bn_bwd_reduce / vince_bn_bwd_apply on the stored g. */
+int vince_stem_bwd_reduce(int dtype, const void* dpool, const uint8_t* argmax, const void* y, const float* mean,
+                          const float* invstd, double* sums, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int vince_stem_bwd_apply(int dtype, const void* dpool, const uint8_t* argmax, const void* y, const float* mean,
+                         const float* invstd, const float* gamma, double* sums, void* dy, float* dgamma, float* dbeta,
+                         int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int vince_avgpool_fwd(int dtype, const void* x, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
 int vince_avgpool_bwd(int dtype, const float* dout, void* dx, int32_t N, int32_t HW, int32_t C, void* stream);
 

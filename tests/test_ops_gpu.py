@@ -331,6 +331,17 @@ def test_stem_pool(dtype, hw):
         assert_close(from_nhwc(g), ref_g, dtype, what="stem pool bwd")
     else:  # bf16 rounding of the pre-pool activation can move an argmax between tied neighbours: compare totals
         assert abs(float(g.float().sum()) - float(ref_g.sum())) < 2e-2 * float(ref_g.abs().sum())
+    # fused stem backward (pool gather inside the bn1 backward) == stem_pool_bwd followed by the BatchNorm backward
+    yg = to_nhwc(y.detach(), dtype)
+    mean, invstd = (0.1 * rnd(C, seed=41)).to(DEV), (rnd(C, seed=42).abs() + 0.5).to(DEV)
+    gamma = (1 + 0.2 * rnd(C, seed=43)).to(DEV)
+    dg1, db1, dg2, db2 = (torch.zeros(C, device=DEV) for _ in range(4))
+    want, _ = ops.bn_bwd(g, None, yg, mean, invstd, gamma, dg1, db1)
+    got = ops.stem_bwd(to_nhwc(dp, dtype), amax, yg, mean, invstd, gamma, dg2, db2)
+    tol_ = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((got.float() - want.float()).abs().max()) <= tol_ * (float(want.float().abs().max()) + 1e-6)
+    torch.testing.assert_close(dg2, dg1, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db2, db1, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -57,6 +57,10 @@ PROTOTYPES = {
     "vince_stem_pool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
     "vince_stem_pool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "vince_stem_bwd_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                      c_int32, c_void_p]),
+    "vince_stem_bwd_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "vince_avgpool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "vince_avgpool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "vince_input_nchw_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

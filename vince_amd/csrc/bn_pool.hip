@@ -7,6 +7,8 @@
 // walks pixel rows, so a wavefront always touches whole contiguous row segments and the per-channel constants
 // (scale/shift/mean/invstd) live in registers for the whole walk.  Reductions go registers -> LDS -> one fp64
 // atomic per channel per workgroup.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -364,52 +366,161 @@ __global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const T* __restrict_
     }
 }
 
+// Gradient of the stem max-pool for the 2x2 block of pre-pool pixels (2a..2a+1, 2b..2b+1), channel chunk `col`: each
+// pixel receives dpool from the windows whose argmax it is.  The block touches exactly the 4 windows (a..a+1, b..b+1)
+// -- one window load per output pixel instead of the 2.25 a per-pixel gather needs.  acc[2*dh + dw] = pixel (2a+dh, 2b+dw).
+template <typename T>
+__device__ __forceinline__ void stem_pool_gather2x2(const T* __restrict__ dpool, const uint8_t* __restrict__ amax, int n,
+                                                    int a, int b, int col, int C, int Ho, int Wo,
+                                                    float (&acc)[4][Elem<T>::CH]) {
+    constexpr int CH = Elem<T>::CH;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[p][e] = 0.f;
+    // window (a+i, b+j) holds pixel (2a+dh, 2b+dw) at (kh, kw) = (dh + 1 - 2i, dw + 1 - 2j), valid when both are in 0..2
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (a + i >= Ho) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (b + j >= Wo) continue;
+            const size_t ooff = (((size_t)n * Ho + (a + i)) * Wo + (b + j)) * C + (size_t)col * CH;
+            float d[CH];
+            Chunk<T>::unpack(*(const uint4*)(dpool + ooff), d);
+            uint32_t codes[CH];
+            if constexpr (CH == 8) {
+                const uint2 m = *(const uint2*)(amax + ooff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { codes[e] = (m.x >> (8 * e)) & 0xff; codes[4 + e] = (m.y >> (8 * e)) & 0xff; }
+            } else {
+                const uint32_t m = *(const uint32_t*)(amax + ooff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) codes[e] = (m >> (8 * e)) & 0xff;
+            }
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh) {
+                const int kh = dh + 1 - 2 * i;
+                if (kh < 0 || kh > 2) continue;
+#pragma unroll
+                for (int dw = 0; dw < 2; ++dw) {
+                    const int kw = dw + 1 - 2 * j;
+                    if (kw < 0 || kw > 2) continue;
+                    const uint32_t code = (uint32_t)(kh * 3 + kw);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e)
+                        if (codes[e] == code) acc[dh * 2 + dw][e] += d[e];
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const T* __restrict__ dpool,
                                                             const uint8_t* __restrict__ amax, T* __restrict__ g,
                                                             int N, int H, int W, int C, int Ho, int Wo) {
     constexpr int CH = Elem<T>::CH;
-    const int cpr = C / CH;
-    const int64_t total = (int64_t)N * H * W * cpr;
+    const int cpr = C / CH, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    const int64_t total = (int64_t)N * H2 * W2 * cpr;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int col = (int)(idx % cpr);
-        int64_t pix = idx / cpr;
-        const int w_ = (int)(pix % W);
-        pix /= W;
-        const int h = (int)(pix % H);
-        const int n = (int)(pix / H);
-        float acc[CH];
+        int64_t blk = idx / cpr;
+        const int b = (int)(blk % W2);
+        blk /= W2;
+        const int a = (int)(blk % H2);
+        const int n = (int)(blk / H2);
+        float acc[4][CH];
+        stem_pool_gather2x2<T>(dpool, amax, n, a, b, col, C, Ho, Wo, acc);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) acc[e] = 0.f;
-        // windows (ho, wo) that contain (h, w): ho*2-1 <= h <= ho*2+1
-        const int ho_lo = h >> 1, ho_hi = (h + 1) >> 1;   // floor(h/2) .. floor((h+1)/2)
-        const int wo_lo = w_ >> 1, wo_hi = (w_ + 1) >> 1;
-        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-            if (ho >= Ho) continue;
-            const int kh = h - (ho * 2 - 1);
-            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-                if (wo >= Wo) continue;
-                const int kw = w_ - (wo * 2 - 1);
-                const int code = kh * 3 + kw;
-                const size_t ooff = (((size_t)n * Ho + ho) * Wo + wo) * C + (size_t)col * CH;
-                float d[CH];
-                Chunk<T>::unpack(*(const uint4*)(dpool + ooff), d);
-                if constexpr (CH == 8) {
-                    const uint2 a = *(const uint2*)(amax + ooff);
+        for (int p = 0; p < 4; ++p) {
+            const int h = 2 * a + (p >> 1), w_ = 2 * b + (p & 1);
+            if (h < H && w_ < W) *(uint4*)(g + (((size_t)n * H + h) * W + w_) * C + (size_t)col * CH) = Chunk<T>::pack(acc[p]);
+        }
+    }
+}
+
+// Stem backward without the materialised pre-pool gradient: max-pool backward (gather) fused into the BatchNorm backward.
+// APPLY = false: (sum g, sum g*xhat) into sums[R][C][2]; APPLY = true: dy = gamma*invstd*(g - mean_g - xhat*mean_gx).
+// g is rounded to T first, so the results equal stem_pool_bwd -> bn_bwd_reduce / bn_bwd_apply on the stored tensor.
+// Requires 256 % (C / CH) == 0 (a thread keeps its channel chunk across the grid-stride loop).
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ amax,
+                                                       const T* __restrict__ y, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       double* __restrict__ sums, double inv_count, T* __restrict__ dy, int N,
+                                                       int H, int W, int C, int Ho, int Wo) {
+    constexpr int CH = Elem<T>::CH;
+    __shared__ float red[256 * 2 * CH];
+    const int cpr = C / CH, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    const int col = threadIdx.x % cpr;
+    float mu[CH], is[CH], k1[CH], ma[CH], mb[CH], sg[CH], sgx[CH];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (((a.x >> (8 * e)) & 0xff) == (uint32_t)code) acc[e] += d[e];
-                        if (((a.y >> (8 * e)) & 0xff) == (uint32_t)code) acc[4 + e] += d[4 + e];
-                    }
-                } else {
-                    const uint32_t a = *(const uint32_t*)(amax + ooff);
+    for (int e = 0; e < CH; ++e) {
+        const int c = col * CH + e;
+        mu[e] = mean[c];
+        is[e] = invstd[c];
+        sg[e] = sgx[e] = 0.f;
+        if constexpr (APPLY) {
+            k1[e] = gamma[c] * is[e];
+            ma[e] = (float)(sums[2 * c] * inv_count);       // replica 0 holds the folded totals (bn_bwd_fold_kernel)
+            mb[e] = (float)(sums[2 * c + 1] * inv_count);
+        }
+    }
+    const int64_t total = (int64_t)N * H2 * W2 * cpr;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int64_t blk = idx / cpr;
+        const int b = (int)(blk % W2);
+        blk /= W2;
+        const int a = (int)(blk % H2);
+        const int n = (int)(blk / H2);
+        size_t off[4];
+        bool ok[4];
+        uint4 yv[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (((a >> (8 * e)) & 0xff) == (uint32_t)code) acc[e] += d[e];
+        for (int p = 0; p < 4; ++p) {
+            const int h = 2 * a + (p >> 1), w_ = 2 * b + (p & 1);
+            ok[p] = h < H && w_ < W;
+            off[p] = (((size_t)n * H + h) * W + w_) * C + (size_t)col * CH;
+            if (ok[p]) yv[p] = *(const uint4*)(y + off[p]);
+        }
+        float acc[4][CH];
+        stem_pool_gather2x2<T>(dpool, amax, n, a, b, col, C, Ho, Wo, acc);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!ok[p]) continue;
+            float g[CH], yy[CH];
+            Chunk<T>::unpack(Chunk<T>::pack(acc[p]), g);   // the rounding of the tensor the unfused path stores
+            Chunk<T>::unpack(yv[p], yy);
+            if constexpr (APPLY) {
+                float o[CH];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) o[e] = k1[e] * (g[e] - ma[e] - (yy[e] - mu[e]) * is[e] * mb[e]);
+                *(uint4*)(dy + off[p]) = Chunk<T>::pack(o);
+            } else {
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    sg[e] += g[e];
+                    sgx[e] += g[e] * (yy[e] - mu[e]) * is[e];
                 }
             }
         }
-        *(uint4*)(g + (((size_t)n * H + h) * W + w_) * C + (size_t)col * CH) = Chunk<T>::pack(acc);
+    }
+    if constexpr (!APPLY) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            red[threadIdx.x * 2 * CH + e] = sg[e];
+            red[threadIdx.x * 2 * CH + CH + e] = sgx[e];
+        }
+        __syncthreads();
+        const int rpp = 256 / cpr;
+        for (int t = threadIdx.x; t < cpr * 2 * CH; t += 256) {
+            const int c_ = t / (2 * CH), slot = t % (2 * CH);
+            float s = 0.f;
+            for (int rr = 0; rr < rpp; ++rr) s += red[(rr * cpr + c_) * 2 * CH + slot];
+            const int ch = c_ * CH + (slot % CH), which = slot / CH;
+            unsafeAtomicAdd(sums + ((size_t)(blockIdx.x % VINCE_STATS_REPLICAS) * C + ch) * 2 + which, (double)s);
+        }
     }
 }
 
@@ -565,13 +676,58 @@ extern "C" int vince_stem_pool_bwd(int dtype, const void* dpool, const uint8_t* 
     VINCE_CHECK_ARG(dpool && argmax && g && N > 0 && H > 0 && W > 0, VINCE_E_ARG, "vince_stem_pool_bwd: bad arguments");
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_stem_pool_bwd: C=%d not a multiple of %d", C, CH_OF(dtype));
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const int64_t total = (int64_t)N * H * W * (C / CH_OF(dtype));
+    const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / CH_OF(dtype));   // one thread per 2x2 pixel block
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(stem_pool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)dpool, argmax, (float*)g, N, H, W, C, Ho, Wo);
     else
         hipLaunchKernelGGL(stem_pool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)dpool, argmax, (bf16_t*)g, N, H, W, C, Ho, Wo);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_stem_bwd_reduce(int dtype, const void* dpool, const uint8_t* argmax, const void* y, const float* mean,
+                                     const float* invstd, double* sums, int32_t N, int32_t H, int32_t W, int32_t C,
+                                     void* stream) {
+    DTYPE_OK("vince_stem_bwd_reduce");
+    VINCE_CHECK_ARG(dpool && argmax && y && mean && invstd && sums && N > 0 && H > 0 && W > 0, VINCE_E_ARG,
+                    "vince_stem_bwd_reduce: bad arguments");
+    const int CH = CH_OF(dtype);
+    VINCE_CHECK_ARG(C % CH == 0 && 256 % (C / CH) == 0, VINCE_E_SHAPE, "vince_stem_bwd_reduce: C=%d unsupported", C);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / CH);
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL((stem_bwd_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dpool,
+                           argmax, (const float*)y, mean, invstd, nullptr, sums, 0.0, (float*)nullptr, N, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dpool,
+                           argmax, (const bf16_t*)y, mean, invstd, nullptr, sums, 0.0, (bf16_t*)nullptr, N, H, W, C, Ho, Wo);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_stem_bwd_apply(int dtype, const void* dpool, const uint8_t* argmax, const void* y, const float* mean,
+                                    const float* invstd, const float* gamma, double* sums, void* dy, float* dgamma,
+                                    float* dbeta, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    DTYPE_OK("vince_stem_bwd_apply");
+    VINCE_CHECK_ARG(dpool && argmax && y && mean && invstd && gamma && sums && dy && N > 0 && H > 0 && W > 0, VINCE_E_ARG,
+                    "vince_stem_bwd_apply: bad arguments");
+    const int CH = CH_OF(dtype);
+    VINCE_CHECK_ARG(C % CH == 0 && 256 % (C / CH) == 0, VINCE_E_SHAPE, "vince_stem_bwd_apply: C=%d unsupported", C);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / CH);
+    const double inv_count = 1.0 / ((double)N * H * W);
+    hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, dgamma, dbeta);
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL((stem_bwd_kernel<float, true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)dpool, argmax, (const float*)y, mean, invstd, gamma, sums, inv_count, (float*)dy, N, H, W,
+                           C, Ho, Wo);
+    else
+        hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)dpool, argmax, (const bf16_t*)y, mean, invstd, gamma, sums, inv_count, (bf16_t*)dy, N, H,
+                           W, C, Ho, Wo);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

@@ -631,9 +631,22 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             }
     }
     // stem: Z = gradient wrt the pooled stem output
-    RC(vince_stem_pool_bwd(c.dtype, Z, (const uint8_t*)at(workspace, t->off_amax), DA, N, t->sH, t->sW, 64, stream));
+    // (max-pool backward gathered on the fly inside the bn1 backward passes: the pre-pool gradient is never materialised)
     RC(next_dy());
-    RC(bn_bwd(c, t->stem_bn, DA, nullptr, false, t->off_ystem, (int64_t)N * t->sH * t->sW, DY, nullptr, grads));
+    {
+        const BnL& sb = t->stem_bn;
+        const uint8_t* amax = (const uint8_t*)at(workspace, t->off_amax);
+        const void* ys = at(workspace, t->off_ystem);
+        static const bool fused_stem = !(getenv("VINCE_FUSE_STEM_BWD") && atoi(getenv("VINCE_FUSE_STEM_BWD")) == 0);
+        if (fused_stem) {
+            RC(vince_stem_bwd_reduce(c.dtype, Z, amax, ys, c.consts(sb, 2), c.consts(sb, 3), c.sums(sb), N, t->sH, t->sW, 64, stream));
+            RC(vince_stem_bwd_apply(c.dtype, Z, amax, ys, c.consts(sb, 2), c.consts(sb, 3), params[sb.gamma], c.sums(sb), DY,
+                                    grads[sb.gamma], grads[sb.beta], N, t->sH, t->sW, 64, stream));
+        } else {
+            RC(vince_stem_pool_bwd(c.dtype, Z, amax, DA, N, t->sH, t->sW, 64, stream));
+            RC(bn_bwd(c, sb, DA, nullptr, false, t->off_ystem, (int64_t)N * t->sH * t->sW, DY, nullptr, grads));
+        }
+    }
     RC(wgrad_async(stem_desc(t), at(workspace, t->off_x0), grads[t->stem.param], 3));
     if (overlap) {   // the caller's stream continues only after every weight gradient has landed
         VINCE_CHECK_HIP(hipEventRecord(t->ev_join, t->side));

@@ -245,6 +245,19 @@ def stem_pool_fwd(y, scale, shift):
     return out, amax
 
 
+def stem_bwd(dpool, amax, y, mean, invstd, gamma, dgamma, dbeta):
+    """Fused stem backward (max-pool gather + bn1 backward): returns dy wrt the stem conv output y [N][H][W][C]."""
+    require_gpu(dpool, amax, y, mean, invstd, gamma, dgamma, dbeta)
+    N, H, W, C = y.shape
+    sums = torch.zeros(STATS_REPLICAS, C, 2, device=y.device, dtype=torch.float64)
+    dy = torch.empty_like(y)
+    check(lib().vince_stem_bwd_reduce(dtype_code(y), _ptr(dpool), _ptr(amax), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums),
+                                      N, H, W, C, stream_ptr()))
+    check(lib().vince_stem_bwd_apply(dtype_code(y), _ptr(dpool), _ptr(amax), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                     _ptr(sums), _ptr(dy), _ptr(dgamma), _ptr(dbeta), N, H, W, C, stream_ptr()))
+    return dy
+
+
 def stem_pool_bwd(dpool, amax, H, W):
     require_gpu(dpool, amax)
     N, _, _, C = dpool.shape
