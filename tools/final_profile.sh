@@ -13,7 +13,7 @@ F=$(find $O/pmc_FETCH_SIZE -name '*.db' | head -1); W=$(find $O/pmc_WRITE_SIZE -
 timeout 60 python tools/rocpd_pmc.py $F 14 > $O/pmc_fetch_size.txt 2>&1
 timeout 60 python tools/rocpd_pmc.py $W 14 > $O/pmc_write_size.txt 2>&1
 timeout 60 python tools/pmc_summary.py $F $W $O/pmc_conv_igemm.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B); bench.py --steps 2 --warmup 1 --no-extras" > $O/pmc_summary.txt 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o pmc -- python bench.py --steps 2 --warmup 1 --no-extras > $O/pmc_mfma.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -d $O/pmc_mfma -o pmc -- python bench.py --steps 2 --warmup 1 --no-extras > $O/pmc_mfma.log 2>&1
 M=$(find $O/pmc_mfma -name '*.db' | head -1); timeout 60 python tools/pmc_mfma.py $M > $O/pmc_mfma_util.txt 2>&1
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_mfma
 cat $O/pmc_summary.txt | head -12
