@@ -27,6 +27,7 @@ struct WgradParams {
     float* dw;
     uint32_t in_bytes, dy_bytes;   // descriptor ranges for the direct-to-LDS variant (0 = tensor too large)
     int linear_x;                  // 1x1 / stride 1 / no padding: the input pixel IS the output pixel
+    int xcd_group;                 // remap workgroups so that the tiles of one pixel range share an XCD
     int cs;                        // element stride between input pixels (= Ci unless the descriptor packs row taps)
 };
 
@@ -103,10 +104,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave & 1, wn = wave >> 1;
-    const int ctile = blockIdx.x % p.ctiles, ntile = blockIdx.x / p.ctiles;
+    // All (channel, tap) tiles of one pixel range read the same dY / X rows: keep them on ONE XCD (one L2) and adjacent
+    // in launch order.  The hardware deals workgroups to the 8 XCDs round-robin by linear id, so the linear id is
+    // remapped to "XCD x gets a contiguous run of (split, tile) pairs" (VINCE_WGRAD_XCD=0: plain order, measurement aid).
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_group) {
+        const uint32_t lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+        bx = lid % gridDim.x;
+        by = lid / gridDim.x;
+    }
+    const int ctile = bx % p.ctiles, ntile = bx / p.ctiles;
     const int c0 = ctile * CT, n0 = ntile * NT;
     const vince_conv_desc& d = p.d;
-    const int kt_begin = blockIdx.y * p.kt_per_split;
+    const int kt_begin = by * p.kt_per_split;
     const int kt_end = min(kt_begin + p.kt_per_split, p.nkt_total);
     if (kt_begin >= kt_end) return;
 
@@ -286,10 +296,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave & 1, wn = wave >> 1;
-    const int ctile = blockIdx.x % p.ctiles, ntile = blockIdx.x / p.ctiles;
+    // All (channel, tap) tiles of one pixel range read the same dY / X rows: keep them on ONE XCD (one L2) and adjacent
+    // in launch order.  The hardware deals workgroups to the 8 XCDs round-robin by linear id, so the linear id is
+    // remapped to "XCD x gets a contiguous run of (split, tile) pairs" (VINCE_WGRAD_XCD=0: plain order, measurement aid).
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_group) {
+        const uint32_t lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+        bx = lid % gridDim.x;
+        by = lid / gridDim.x;
+    }
+    const int ctile = bx % p.ctiles, ntile = bx / p.ctiles;
     const int c0 = ctile * CT, n0 = ntile * NT;
     const vince_conv_desc& d = p.d;
-    const int kt_begin = blockIdx.y * p.kt_per_split;
+    const int kt_begin = by * p.kt_per_split;
     const int kt_end = min(kt_begin + p.kt_per_split, p.nkt_total);
     if (kt_begin >= kt_end) return;
     const int nkt = kt_end - kt_begin;
@@ -447,6 +466,10 @@ int dispatch(WgradParams& p, hipStream_t stream) {
     if (splits < 1) splits = 1;
     p.kt_per_split = (p.nkt_total + splits - 1) / splits;
     splits = (p.nkt_total + p.kt_per_split - 1) / p.kt_per_split;
+    // XCD grouping pays most when many tiles share a pixel range (kernels timed alone: -15 % at 16-36 tiles, +12 % at 5
+    // tiles; in the overlapped step always-on measured best, so the threshold stays a measurement knob)
+    static const int xcd_min_tiles = getenv("VINCE_WGRAD_XCD_MIN_TILES") ? atoi(getenv("VINCE_WGRAD_XCD_MIN_TILES")) : 1;
+    p.xcd_group = p.xcd_group && tiles >= xcd_min_tiles;
     if (CT == 64 && NT == 64) return launch<T, 64, 64>(p, splits, stream);
     if (CT == 64) return launch<T, 64, 128>(p, splits, stream);
     if (NT == 64) return launch<T, 128, 64>(p, splits, stream);
@@ -501,6 +524,8 @@ extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.dy = dy; p.dw = dw; p.Ci_dw = Ci_dw; p.variant = variant;
     p.cs = d.Cs > 0 ? d.Cs : d.Ci;
+    static const int xcd_group = !(getenv("VINCE_WGRAD_XCD") && atoi(getenv("VINCE_WGRAD_XCD")) == 0);
+    p.xcd_group = xcd_group;
     {
         const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;
         const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * p.cs * esz, yb = (unsigned long long)p.M * d.Co * esz;
