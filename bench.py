@@ -35,6 +35,7 @@ import torch  # noqa: E402
 # algorithmic work per unit (hook-counted on the reference's resnet.py)
 STEP_GFLOP_PER_SAMPLE = {"ResNet50": 32.766, "ResNet18": 14.512}     # key fwd + query fwd + query bwd + similarity
 FWD_GFLOP_PER_FRAME = {"ResNet50": 8.2000, "ResNet18": 3.6282}
+TRUNK_GFLOP_PER_FRAME = {"ResNet50": 8.1743, "ResNet18": 3.6271}      # conv MACs x 2 per image
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}                          # MI355X_MICROARCH.md dense MFMA peaks
 # one tag per kernel symbol (as rocprofv3 lists them): conv_igemm_dlds_kernel<T, CT, 4, STAGES, MINW, PTL, BWD>
 KERNEL_TAGS = ["conv_igemm<%s,%s,%s>" % (t, shape, e) for t in ("f32", "bf16")
@@ -185,6 +186,27 @@ def main():
         fwd_tflops = FWD_GFLOP_PER_FRAME.get(opt.backbone, 0.0) * opt.batch / 1000.0 / tfwd
         out["fwd_infonce"] = {"frames_per_s_per_gpu": round(opt.batch / tfwd, 1), "ms": round(tfwd * 1000, 3),
                               "tflops": round(fwd_tflops, 1), "mfma_frac": round(fwd_tflops / PEAK_TFLOPS[opt.dtype], 4)}
+
+        # ---- inference: eval-mode extract_features, BatchNorms folded into the convolutions -----------------
+        solver.model.eval()
+
+        def infer_once():
+            with torch.no_grad():
+                return solver.model.extract_features(batch_fwd["data"])["extracted_features"]
+
+        for _ in range(3):
+            infer_once()
+        barrier()
+        ti0 = time.perf_counter()
+        for _ in range(nf):
+            infer_once()
+        barrier()
+        tinf = (time.perf_counter() - ti0) / nf
+        solver.model.train()
+        inf_tflops = TRUNK_GFLOP_PER_FRAME.get(opt.backbone, 0.0) * opt.batch / 1000.0 / tinf
+        out["inference_extract_features"] = {"frames_per_s_per_gpu": round(opt.batch / tinf, 1), "ms": round(tinf * 1000, 3),
+                                             "tflops": round(inf_tflops, 1),
+                                             "mfma_frac": round(inf_tflops / PEAK_TFLOPS[opt.dtype], 4)}
 
     if rank == 0 and world == 1 and not opt.no_extras:
         # ---- roofline leg: hipEvent pairs around every conv launch for a few extra steps -------------------------

@@ -209,6 +209,7 @@ typedef struct vince_prep_entry {
     const void* w; /* float [Co][T][Ci] */
     void* wk;      /* dtype [Co][T][Cip] */
     void* wt;      /* dtype [Ci][T][Co] or NULL */
+    const float* scale; /* optional float[Co]: the row of output channel co is multiplied by scale[co] (BatchNorm folding) */
     int32_t Co, T, Ci, Cip;
     int32_t Cs, Kw; /* packed row taps (0 / 0 = off): w is float [Co][T][Kw][Ci], wk element k of tap t is
                      * (kw = k / Cs, c = k % Cs) -> w[co][t][kw][c], zero where kw >= Kw or c >= Ci */
@@ -320,6 +321,17 @@ int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void*
                         int64_t* const* bn_nbt, const float* input, const int64_t* perm, int32_t jigsaw_src_h,
                         int32_t jigsaw_src_w, void* workspace, float* pooled, int32_t train_bn, void* stream);
 const void* vince_trunk_spatial_ptr(vince_trunk_t t, const void* workspace);
+
+/* Inference with the BatchNorms FOLDED into the convolutions (eval mode, running statistics; the end-task feature
+ * extraction of end_task_base_solver.py:199-212 / vince_model.py:97-117 `extract_features`): no BatchNorm pass at all.
+ * _prepare_weights_folded writes w * gamma/sqrt(var+eps) (compute dtype) and the per-channel bias beta - mean*scale into
+ * `wcache` (vince_trunk_weight_cache_bytes; a cache separate from the training one); call it whenever parameters or
+ * running statistics change.  _forward_folded then runs conv(+bias)(+ReLU) only, the residual join in the conv3
+ * epilogue; nothing is kept for a backward pass.  Outputs as vince_trunk_forward. */
+int vince_trunk_prepare_weights_folded(vince_trunk_t t, const float* const* params, float* const* bn_running, void* wcache,
+                                       void* stream);
+int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, const float* input, const int64_t* perm,
+                               int32_t jigsaw_src_h, int32_t jigsaw_src_w, void* workspace, float* pooled, void* stream);
 /* grads: float pointers parallel to params (accumulated into; zero them first).  dpooled: float[N][C].
  * Gradient buckets for data parallelism: after the backward of residual block event_blocks[e] (blocks are numbered in
  * forward order; backward visits them last to first) has been enqueued, hipEvent_t events[e] is recorded on `stream`;

@@ -63,6 +63,33 @@ def test_g3_trunk_head_fp32(arch, embed, hw, train):
 
 
 @pytest.mark.parametrize("arch,embed", [("ResNet18", 64), ("ResNet50", 128)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_eval_bn_folding_matches_unfolded(arch, embed, dtype, monkeypatch):
+    """the inference path folds every BatchNorm into its convolution (conv + bias [+ ReLU] [+ residual join
+    in the epilogue]); it must reproduce the eval-mode forward that runs the BatchNorm passes separately, including after
+    a train-mode forward has moved the running statistics (the folded cache has to notice)."""
+    from vince_amd.models import vince_model as vm
+    _, model = build(arch, embed, dtype, 12)
+    x = vo.structured_frames(4, 96, 96, seed=77).to(DEV)
+    tol_ = 2e-5 if dtype == "fp32" else 6e-2
+
+    def eval_out(fold):
+        monkeypatch.setattr(vm, "FOLD_BN", fold)
+        model.eval()
+        with torch.no_grad():
+            o = model.extract_features(x)
+        return {k: o[k].float().cpu() for k in ("extracted_features", "spatial_features")}
+
+    for _ in range(2):
+        a, b = eval_out(True), eval_out(False)
+        for k in a:
+            assert rel(a[k], b[k]) < tol_, (k, rel(a[k], b[k]))
+        model.train()
+        with torch.no_grad():
+            model.get_embeddings({"data": x})    # moves the running statistics
+
+
+@pytest.mark.parametrize("arch,embed", [("ResNet18", 64), ("ResNet50", 128)])
 def test_g3_trunk_head_bf16_reported(arch, embed, record_property):
     """bf16 trunk against the fp32 reference.  53 stacked bf16 layers cannot hold 1e-3 on raw embeddings in general
     (SURVEY.md 7.4-4); the miss is reported as a number, and bounded."""

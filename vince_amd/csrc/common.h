@@ -27,6 +27,7 @@ void vince_profile_set_tag(void* token, int tag);
 // Zero `bytes` (multiple of 16, 16-byte aligned pointer) on `stream` with a full-width grid; the runtime's fill kernel runs
 // a few-MB clear at a fraction of HBM speed.  Defined in misc.hip.
 int vince_zero_async(void* ptr, size_t bytes, void* stream);
+int vince_fill_f32_async(float* ptr, int n, float value, void* stream);   // small constant vectors (misc.hip)
 void vince_profile_set_dims(void* token, int a, int b, int c, int d, int e, int f);
 
 #define VINCE_CHECK_ARG(cond, code, ...)   \

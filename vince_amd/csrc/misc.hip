@@ -131,6 +131,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void prepare_weights_batched_kernel(const vince_prep_entry* __restrict__ table, int tiled) {
     const vince_prep_entry e = table[blockIdx.y];
     const float* __restrict__ w = (const float*)e.w;
+    const float* __restrict__ sc = e.scale;   // optional per-output-channel multiplier (BatchNorm folding)
     T* __restrict__ wk = (T*)e.wk;
     T* __restrict__ wt = (T*)e.wt;
     if (e.Cs > 0) {   // packed row taps (the stem): wk[co][t][k] = w[co][t][k / Cs][k % Cs]
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void prepare_weights_batched_kernel(const vinc
             const int k = (int)(idx % e.Cip);
             const int64_t r = idx / e.Cip;   // co * T + t
             const int kw = k / e.Cs, c = k - kw * e.Cs;
-            wk[idx] = cvt_from_f32<T>((kw < e.Kw && c < e.Ci) ? w[((size_t)r * e.Kw + kw) * e.Ci + c] : 0.f);
+            const float m = sc ? sc[r / e.T] : 1.f;
+            wk[idx] = cvt_from_f32<T>((kw < e.Kw && c < e.Ci) ? w[((size_t)r * e.Kw + kw) * e.Ci + c] * m : 0.f);
         }
         return;
     }
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void prepare_weights_batched_kernel(const vinc
             for (int i = 0; i < 16; ++i) {
                 const int row = i * 4 + rq;
                 const size_t off = ((size_t)(co0 + row) * e.T + t) * e.Ci + ci0 + col;
-                const float v = w[off];
+                const float v = w[off] * (sc ? sc[co0 + row] : 1.f);
                 wk[off] = cvt_from_f32<T>(v);
                 tile[row][col] = v;
             }
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void prepare_weights_batched_kernel(const vinc
         const int64_t r = idx / e.Cip;
         const int t = (int)(r % e.T);
         const int co = (int)(r / e.T);
-        const float v = ci < e.Ci ? w[((size_t)co * e.T + t) * e.Ci + ci] : 0.f;
+        const float v = ci < e.Ci ? w[((size_t)co * e.T + t) * e.Ci + ci] * (sc ? sc[co] : 1.f) : 0.f;
         const T o = cvt_from_f32<T>(v);
         wk[idx] = o;
         if (wt && ci < e.Ci) wt[((size_t)ci * e.T + t) * e.Co + co] = o;
@@ -496,6 +498,19 @@ extern "C" int vince_jigsaw_nchw_to_rows(int dtype, const float* in, void* out, 
     else
         hipLaunchKernelGGL(jigsaw_to_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
                            (bf16_t*)out, N, C, H, W, th, tw, Wp, left);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+namespace {
+__global__ void fill_f32_kernel(float* p, int n, float v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+}  // namespace
+
+int vince_fill_f32_async(float* ptr, int n, float value, void* stream) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ptr, n, value);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

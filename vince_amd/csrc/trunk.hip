@@ -64,8 +64,9 @@ struct vince_trunk {
     std::vector<int> bnC;
     size_t off_x0, off_ystem, off_amax, off_p0, off_stats, off_sums, off_consts, off_g[3], off_dy[3];
     size_t n_stats_doubles, n_consts_floats, max_act, ws_bytes, wc_bytes, off_prep_table;
-    std::vector<vince_prep_entry> prep_table;   // last uploaded batched weight-prep descriptors
-    void* prep_table_dev = nullptr;
+    std::vector<vince_prep_entry> prep_table[2];   // last uploaded batched weight-prep descriptors (training / folded)
+    void* prep_table_dev[2] = {nullptr, nullptr};
+    size_t off_fold;      // fold constants (scale, bias per BN channel + ones/zeros) inside a weight cache
     // weight-gradient side stream (created on first backward) + per-slot events of the dY ring
     hipStream_t side = nullptr;
     hipEvent_t ev_dy[3] = {nullptr, nullptr, nullptr}, ev_wg[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr;
@@ -289,7 +290,8 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     for (int i = 0; i < 3; ++i) { t->off_dy[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     t->ws_bytes = P.ws;
     t->off_prep_table = P.wc;
-    t->wc_bytes = align_up(P.wc + 128 * sizeof(vince_prep_entry));
+    t->off_fold = align_up(P.wc + 128 * sizeof(vince_prep_entry));
+    t->wc_bytes = align_up(t->off_fold + (2 * (P.nf / 4) + 128) * sizeof(float));
     *out = t;
     return VINCE_OK;
 }
@@ -421,15 +423,19 @@ vince_bn_reduce bn_reduce_of(Ctx& c, const BnL& bn, const uint8_t* bits, bool se
 
 }  // namespace
 
-extern "C" int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* params, void* wcache, void* stream) {
-    VINCE_CHECK_ARG(t && params && wcache, VINCE_E_ARG, "vince_trunk_prepare_weights: null pointer");
-    // one launch for all conv layers: the descriptor table is staged at the tail of the weight cache
+namespace {
+
+// Batched weight prep shared by the training cache (scale == nullptr) and the BatchNorm-folded inference cache
+// (fold_scale: float[sum of BN channels] in BN order, inside the cache).  `which` selects the cached descriptor table.
+int prepare_common(vince_trunk* t, const float* const* params, void* wcache, const float* fold_scale, int which, void* stream) {
     std::vector<vince_prep_entry> tab;
-    auto add = [&](const ConvL& c) {
+    auto scale_of = [&](const BnL& b) -> const float* { return fold_scale ? fold_scale + b.consts / 4 : nullptr; };
+    auto add = [&](const ConvL& c, const BnL& b) {
         vince_prep_entry e;
         e.w = params[c.param];
         e.wk = at(wcache, c.wk);
-        e.wt = c.wt == NONE ? nullptr : at(wcache, c.wt);
+        e.wt = (c.wt == NONE || fold_scale) ? nullptr : at(wcache, c.wt);   // inference needs no dgrad copy
+        e.scale = scale_of(b);
         e.Co = c.Co; e.T = c.k * c.k; e.Ci = c.Ci; e.Cip = c.Cip; e.Cs = e.Kw = 0;
         tab.push_back(e);
     };
@@ -438,27 +444,120 @@ extern "C" int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* 
         e.w = params[t->stem.param];
         e.wk = at(wcache, t->stem.wk);
         e.wt = nullptr;
+        e.scale = scale_of(t->stem_bn);
         e.Co = t->stem.Co; e.T = 7; e.Ci = 3; e.Cip = STEM_K; e.Cs = STEM_CS; e.Kw = 7;
         if (!stem_packed()) { e.T = 49; e.Cip = t->stem.Cip; e.Cs = e.Kw = 0; }
         tab.push_back(e);
     }
     for (const Blk& b : t->blocks) {
-        for (int ci = 0; ci < b.nconv; ++ci) add(b.c[ci]);
-        if (b.has_ds) add(b.cd);
+        for (int ci = 0; ci < b.nconv; ++ci) add(b.c[ci], b.b[ci]);
+        if (b.has_ds) add(b.cd, b.bd);
     }
     void* dev_table = at(wcache, t->off_prep_table);
     // the table only changes when the caller's buffers move: upload it then (a pageable H2D copy synchronises the host
     // with the stream, which must not happen every step)
-    const bool same = t->prep_table_dev == dev_table && t->prep_table.size() == tab.size() &&
-                      memcmp(t->prep_table.data(), tab.data(), tab.size() * sizeof(vince_prep_entry)) == 0;
+    std::vector<vince_prep_entry>& last = t->prep_table[which];
+    const bool same = t->prep_table_dev[which] == dev_table && last.size() == tab.size() &&
+                      memcmp(last.data(), tab.data(), tab.size() * sizeof(vince_prep_entry)) == 0;
     if (!same) {
         VINCE_CHECK_HIP(hipMemcpyAsync(dev_table, tab.data(), tab.size() * sizeof(vince_prep_entry), hipMemcpyHostToDevice,
                                        (hipStream_t)stream));
         VINCE_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-        t->prep_table = tab;
-        t->prep_table_dev = dev_table;
+        last = tab;
+        t->prep_table_dev[which] = dev_table;
     }
     return vince_prepare_weights_batched(t->cfg.dtype, (const vince_prep_entry*)dev_table, (int32_t)tab.size(), stream);
+}
+
+// fold constants inside a folded weight cache: scale[c] and bias[c] per BN channel (BN order, offset b.consts / 4), then
+// 64 ones and 64 zeros (the stem pool's identity affine)
+inline float* fold_scale(vince_trunk* t, void* wcache) { return (float*)at(wcache, t->off_fold); }
+inline float* fold_bias(vince_trunk* t, void* wcache) { return fold_scale(t, wcache) + t->n_consts_floats / 4; }
+inline float* fold_ones(vince_trunk* t, void* wcache) { return fold_bias(t, wcache) + t->n_consts_floats / 4; }
+
+}  // namespace
+
+extern "C" int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* params, void* wcache, void* stream) {
+    VINCE_CHECK_ARG(t && params && wcache, VINCE_E_ARG, "vince_trunk_prepare_weights: null pointer");
+    return prepare_common(t, params, wcache, nullptr, 0, stream);
+}
+
+extern "C" int vince_trunk_prepare_weights_folded(vince_trunk_t t, const float* const* params, float* const* bn_running,
+                                                  void* wcache, void* stream) {
+    VINCE_CHECK_ARG(t && params && bn_running && wcache, VINCE_E_ARG, "vince_trunk_prepare_weights_folded: null pointer");
+    float* sc = fold_scale(t, wcache);
+    float* bi = fold_bias(t, wcache);
+    auto fold = [&](const BnL& b) -> int {   // eval-mode finalize: scale = gamma / sqrt(var + eps), bias = beta - mean * scale
+        return vince_bn_finalize(nullptr, 1, b.C, params[b.gamma], params[b.beta], bn_running[2 * b.index],
+                                 bn_running[2 * b.index + 1], nullptr, 0.1f, 1e-5f, 0, sc + b.consts / 4, bi + b.consts / 4,
+                                 nullptr, nullptr, stream);
+    };
+    RC(fold(t->stem_bn));
+    for (const Blk& b : t->blocks) {
+        for (int ci = 0; ci < b.nconv; ++ci) RC(fold(b.b[ci]));
+        if (b.has_ds) RC(fold(b.bd));
+    }
+    RC(vince_fill_f32_async(fold_ones(t, wcache), 64, 1.f, stream));
+    RC(vince_fill_f32_async(fold_ones(t, wcache) + 64, 64, 0.f, stream));
+    return prepare_common(t, params, wcache, sc, 1, stream);
+}
+
+extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, const float* input, const int64_t* perm,
+                                          int32_t jig_h, int32_t jig_w, void* workspace, float* pooled, void* stream) {
+    VINCE_CHECK_ARG(t && wcache && input && workspace && pooled, VINCE_E_ARG, "vince_trunk_forward_folded: null pointer");
+    VINCE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, VINCE_E_ALIGN,
+                    "vince_trunk_forward_folded: workspace / weight cache must be 256-byte aligned");
+    const int N = t->cfg.N, dtype = t->cfg.dtype;
+    const float* bias = fold_bias(t, (void*)wcache);
+    const float* ones = fold_ones(t, (void*)wcache);
+    if (!stem_packed()) {
+        if (jig_h > 0)
+            RC(vince_jigsaw_nchw_to_nhwc(dtype, input, at(workspace, t->off_x0), N / 9, 3, jig_h, jig_w, t->cfg.H, t->cfg.W,
+                                         t->Cp, stream));
+        else
+            RC(vince_input_nchw_to_nhwc(dtype, input, perm, at(workspace, t->off_x0), N, 3, t->cfg.H, t->cfg.W, t->Cp, stream));
+    } else if (jig_h > 0) {
+        VINCE_CHECK_ARG(N % 9 == 0, VINCE_E_SHAPE, "vince_trunk_forward_folded: jigsaw needs N multiple of 9");
+        RC(vince_jigsaw_nchw_to_rows(dtype, input, at(workspace, t->off_x0), N / 9, 3, jig_h, jig_w, t->cfg.H, t->cfg.W,
+                                     t->sWp, STEM_LEFT, stream));
+    } else {
+        RC(vince_input_nchw_to_rows(dtype, input, perm, at(workspace, t->off_x0), N, 3, t->cfg.H, t->cfg.W, t->sWp, STEM_LEFT,
+                                    stream));
+    }
+    // conv + bias [+ ReLU] [+ residual join: out = relu(conv + bias + out)]
+    auto conv = [&](const vince_conv_desc& d, const ConvL& cv, const BnL& b, const void* in, void* out, int flags) -> int {
+        vince_conv_epi e;
+        memset(&e, 0, sizeof(e));
+        e.flags = flags;
+        e.bias = bias + b.consts / 4;
+        return vince_conv_igemm(&d, dtype, in, at((void*)wcache, cv.wk), out, &e, stream);
+    };
+    RC(conv(stem_desc(t), t->stem, t->stem_bn, at(workspace, t->off_x0), at(workspace, t->off_ystem), 0));
+    RC(vince_stem_pool_fwd(dtype, at(workspace, t->off_ystem), ones, ones + 64, at(workspace, t->off_p0),
+                           (uint8_t*)at(workspace, t->off_amax), N, t->sH, t->sW, 64, stream));
+    void* cur = at(workspace, t->off_p0);   // the running block output; identity blocks update it in place
+    for (size_t bi = 0; bi < t->blocks.size(); ++bi) {
+        const Blk& b = t->blocks[bi];
+        const void* in = cur;
+        for (int ci = 0; ci < b.nconv - 1; ++ci) {
+            RC(conv(fwd_desc(t, b.c[ci]), b.c[ci], b.b[ci], in, at(workspace, b.a[ci]), VINCE_EPI_RELU));
+            in = at(workspace, b.a[ci]);
+        }
+        const int L = b.nconv - 1;
+        void* out = cur;
+        if (b.has_ds) {   // the downsample branch (bias, no ReLU) lands in z, then conv_L joins onto it
+            out = at(workspace, b.z);
+            RC(conv(fwd_desc(t, b.cd), b.cd, b.bd, cur, out, 0));
+        } else if (bi + 1 == t->blocks.size()) {   // the trunk output is read at blocks.back().z
+            out = at(workspace, b.z);
+            VINCE_CHECK_HIP(hipMemcpyAsync(out, cur, (size_t)N * b.c[L].Ho * b.c[L].Wo * b.c[L].Co * t->esize,
+                                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        }
+        RC(conv(fwd_desc(t, b.c[L]), b.c[L], b.b[L], in, out, VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU));
+        cur = out;
+    }
+    RC(vince_avgpool_fwd(dtype, cur, pooled, N, t->outH * t->outW, t->outC, stream));
+    return VINCE_OK;
 }
 
 extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void* wcache, float* const* bn_running,

@@ -84,6 +84,19 @@ class Trunk:
             ctypes.c_void_p(data.data_ptr()), None if perm is None else ctypes.c_void_p(perm.data_ptr()), jh, jw,
             ctypes.c_void_p(workspace.data_ptr()), ctypes.c_void_p(pooled.data_ptr()), int(train_bn), ops.stream_ptr()))
 
+    def prepare_weights_folded(self, param_ptrs, bn_running_ptrs, wcache):
+        """BatchNorm-folded inference weights + biases into `wcache` (a cache separate from the training one)."""
+        check(lib().vince_trunk_prepare_weights_folded(self._h, param_ptrs, bn_running_ptrs,
+                                                       ctypes.c_void_p(wcache.data_ptr()), ops.stream_ptr()))
+
+    def forward_folded(self, wcache, data, workspace, pooled, perm=None, jigsaw_src=None):
+        """Eval-mode forward with folded BatchNorms: convolutions only, nothing kept for backward."""
+        jh, jw = (0, 0) if jigsaw_src is None else jigsaw_src
+        check(lib().vince_trunk_forward_folded(
+            self._h, ctypes.c_void_p(wcache.data_ptr()), ctypes.c_void_p(data.data_ptr()),
+            None if perm is None else ctypes.c_void_p(perm.data_ptr()), jh, jw, ctypes.c_void_p(workspace.data_ptr()),
+            ctypes.c_void_p(pooled.data_ptr()), ops.stream_ptr()))
+
     def backward(self, param_ptrs, wcache, workspace, dpooled, grad_ptrs, bucket_events=None):
         """bucket_events: optional [(block_index, torch.cuda.Event)] recorded as soon as that block's (and every later
         block's) parameter gradients are final."""

@@ -15,6 +15,7 @@ There is no CPU path: tensors must be on the GPU.
 """
 import copy
 import ctypes
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -26,6 +27,9 @@ from .. import constants, ops
 from ..engine import Trunk, nograd_workspace, pointer_table
 from ..utils import loss_util
 from .base_model import BaseModel
+
+# VINCE_FOLD_BN=0: eval-mode forwards keep the separate BatchNorm passes (cross-check aid)
+FOLD_BN = os.environ.get("VINCE_FOLD_BN", "1") != "0"
 
 _ALIGN = 64  # floats; every tensor in the flat buffers starts on a 256-byte boundary
 
@@ -158,6 +162,7 @@ class VinceModel(BaseModel):
         self._saved = None
         self._fwd_generation = 0
         self._param_version, self._wcache_version = 1, 0
+        self._bn_version, self._fold_version, self._wcache_folded = 0, None, None
         self._grad_zero_pending = True
         self._flat = self._flat_grad = None
         self._build_flat()
@@ -295,6 +300,15 @@ class VinceModel(BaseModel):
                         p.shape[1], p.shape[0])
             self._wcache_version = self._param_version
 
+    def _ensure_folded_weights(self, trunk):
+        """Inference cache: BatchNorms folded into the conv weights (eval mode only).  Rebuilt when parameters change
+        (_touch) or a train-mode forward has moved the running statistics."""
+        if self._wcache_folded is None:
+            self._wcache_folded = torch.empty(trunk.wc_bytes, dtype=torch.uint8, device=self._flat.device)
+        if self._fold_version != (self._param_version, self._bn_version):
+            trunk.prepare_weights_folded(self._param_ptrs, self._bn_running_ptrs, self._wcache_folded)
+            self._fold_version = (self._param_version, self._bn_version)
+
     def _encode(self, data, jigsaw, orders, with_head, save):
         """Returns (spatial, pooled, prenorm, embeddings).  data: float32 NCHW on the GPU."""
         self._require_gpu()
@@ -318,8 +332,15 @@ class VinceModel(BaseModel):
             ws = nograd_workspace(self._flat.device, trunk.ws_bytes)
         nt = trunk.N
         pooled = torch.empty(nt, self.output_channels, device=self._flat.device, dtype=torch.float32)
-        trunk.forward(self._param_ptrs, self._wcache, self._bn_running_ptrs, self._bn_nbt_ptrs, data, ws, pooled,
-                      train_bn=self.training, jigsaw_src=(h, w) if jigsaw else None)
+        if not self.training and not save and FOLD_BN:
+            # inference (extract_features for the end tasks, validation): BatchNorms folded into the convolutions
+            self._ensure_folded_weights(trunk)
+            trunk.forward_folded(self._wcache_folded, data, ws, pooled, jigsaw_src=(h, w) if jigsaw else None)
+        else:
+            trunk.forward(self._param_ptrs, self._wcache, self._bn_running_ptrs, self._bn_nbt_ptrs, data, ws, pooled,
+                          train_bn=self.training, jigsaw_src=(h, w) if jigsaw else None)
+            if self.training:
+                self._bn_version += 1   # running statistics moved
         spatial = trunk.spatial_view(ws).clone()
         pre = emb = None
         saved = dict(trunk=trunk, pooled=pooled, jigsaw=jigsaw)
