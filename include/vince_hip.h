@@ -114,6 +114,9 @@ typedef struct vince_conv_epi {
                                * bits written by vince_bn_apply); bit e gates element e, so the residual join
                                * out = dgrad + out * (z > 0) (autograd of resnet.py:132-133) happens in place */
     vince_bn_reduce bnred;    /* excludes stats */
+    int32_t replicas;         /* how many of the R replicas of `stats` / `bnred.sums` this launch spreads its atomics over
+                               * (0 = all VINCE_STATS_REPLICAS); few workgroups need few replicas, and a consumer that
+                               * folds them itself (vince_bn_train_apply, vince_bn_bwd_apply) then reads less */
 } vince_conv_epi;
 
 /* in/w/out have element type `dtype`.  epi may be NULL (plain store). */
@@ -139,6 +142,27 @@ int vince_bn_finalize(const double* stats, int64_t count, int32_t C, const float
                       float eps, int train, float* scale, float* shift, float* save_mean, float* save_invstd,
                       void* stream);
 
+/* vince_bn_finalize(train) + vince_bn_apply in ONE launch: every workgroup folds the statistic replicas of its own channels,
+ * row-block 0 publishes scale / shift / mean / invstd (read by the backward pass) and updates the running statistics. */
+typedef struct vince_bn_train {
+    const double* stats;          /* double[R][C][2], only the first `replicas` copies need to hold data (rest zero or unused) */
+    int32_t replicas;             /* copies to fold; 0 = VINCE_STATS_REPLICAS */
+    int64_t count;                /* elements per channel */
+    const float* gamma;
+    const float* beta;
+    float* running_mean;          /* optional pair */
+    float* running_var;
+    int64_t* num_batches_tracked; /* optional */
+    float momentum, eps;
+    float* scale;                 /* outputs, float[C] */
+    float* shift;
+    float* save_mean;             /* optional outputs */
+    float* save_invstd;
+} vince_bn_train;
+int vince_bn_train_apply(int dtype, const void* y, const vince_bn_train* bt, const void* identity, const float* id_scale,
+                         const float* id_shift, void* out, uint8_t* mask_out, int64_t rows, int32_t C, int relu,
+                         void* stream);
+
 /* out = [relu]( y*scale + shift + (identity ? (id_scale ? identity*id_scale + id_shift : identity) : 0) ).
  * mask_out (optional): one byte per 16-byte chunk of `out` (8 bf16 / 4 f32 channels), bit e = pre-ReLU value e > 0 --
  * the ReLU mask backward needs, at 1/16 of the bytes of re-reading the activation. */
@@ -149,18 +173,18 @@ int vince_bn_apply(int dtype, const void* y, const float* scale, const float* sh
 /* Backward pass 1: g = dz * relu_mask;  sums[c] += (sum g, sum g*xhat), xhat = (y - mean)*invstd.
  * relu_mask comes from (first non-NULL wins) mask_bits (bytes written by vince_bn_apply), mask_scale/mask_shift
  * (sign of y*scale+shift, recomputed from y: plain BN+ReLU), mask_src (sign of a materialised activation), else 1.
- * sums is double[R][C][2], zeroed by the caller. */
+ * sums is double[R][C][2], zeroed by the caller; atomics are spread over the first `replicas` copies (0 = all). */
 int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_src, const uint8_t* mask_bits, const float* mask_scale,
                         const float* mask_shift, const void* y, const float* mean, const float* invstd, double* sums,
-                        int64_t rows, int32_t C, void* stream);
+                        int64_t rows, int32_t C, int32_t replicas, void* stream);
 
 /* Backward pass 2: dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count); optional g_out = g (the
- * residual branch's gradient); dgamma += sum_gx, dbeta += sum_g (float[C]).  `sums` (the R replicas written by
- * vince_bn_bwd_reduce) is folded in place into replica 0 first, hence not const in effect. */
+ * residual branch's gradient); dgamma += sum_gx, dbeta += sum_g (float[C]).  The first `replicas` copies of `sums`
+ * (0 = all) are folded by every workgroup for its own channels; no separate fold launch. */
 int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_src, const uint8_t* mask_bits, const float* mask_scale,
                        const float* mask_shift, const void* y, const float* mean, const float* invstd, const float* gamma,
                        const double* sums, int64_t count, void* dy, void* g_out, float* dgamma, float* dbeta, int64_t rows,
-                       int32_t C, void* stream);
+                       int32_t C, int32_t replicas, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pooling (K6 MaxPool2d 3x3/s2/p1 resnet.py:173, fused with the stem's BN-apply + ReLU; K7 AdaptiveAvgPool2d

@@ -270,6 +270,25 @@ def test_bn_train_fwd_bwd(C, shape, dtype):
                          mask_bits=bits)
     assert torch.equal(dy2, dy) and torch.equal(g2, g)
     torch.testing.assert_close(dgam2, dgam, rtol=1e-6, atol=1e-6)
+    # finalize fused into the apply launch (vince_bn_train_apply): same outputs, constants, running statistics; only the
+    # replicas it is told to fold are read (the statistics sit in replica 3 -> needs replicas >= 4)
+    rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt2 = torch.zeros((), dtype=torch.int64, device=DEV)
+    zg3, bits3, sc3, sh3, mean3, inv3 = ops.bn_train_apply(yg, stats, N * H * W, gamma.detach().to(DEV), beta.detach().to(DEV),
+                                                            rm2, rv2, nbt2, identity=to_nhwc(idn.detach(), dtype),
+                                                            want_mask=True, replicas=4)
+    assert torch.equal(zg3, zg) and torch.equal(bits3, bits)
+    for got, want in zip((sc3, sh3, mean3, inv3), consts):
+        torch.testing.assert_close(got, want, rtol=0, atol=0)
+    torch.testing.assert_close(rm2, rmg, rtol=0, atol=0)
+    torch.testing.assert_close(rv2, rvg, rtol=0, atol=0)
+    assert int(nbt2) == 1
+    # replica-limited backward: sums produced with 2 replicas, folded with 2
+    dgam4, dbet4 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dy4, _ = ops.bn_bwd(to_nhwc(dz, dtype), None, yg, consts[2], consts[3], gamma.detach().to(DEV), dgam4, dbet4,
+                        mask_bits=bits, replicas=2)
+    assert float((dy4.float() - dy.float()).abs().max()) <= 1e-6 * (1 + float(dy.float().abs().max()))
+    torch.testing.assert_close(dgam4, dgam, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -24,7 +24,14 @@ class BnReduce(ctypes.Structure):
 
 class ConvEpi(ctypes.Structure):
     _fields_ = [("flags", c_int32), ("bias", c_void_p), ("stats", c_void_p), ("acc_mask", c_void_p),
-                ("bnred", BnReduce)]
+                ("bnred", BnReduce), ("replicas", c_int32)]
+
+
+class BnTrain(ctypes.Structure):
+    _fields_ = [("stats", c_void_p), ("replicas", c_int32), ("count", ctypes.c_int64), ("gamma", c_void_p), ("beta", c_void_p),
+                ("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p),
+                ("momentum", c_float), ("eps", c_float), ("scale", c_void_p), ("shift", c_void_p),
+                ("save_mean", c_void_p), ("save_invstd", c_void_p)]
 
 
 class InfoNCEDesc(ctypes.Structure):
@@ -49,11 +56,13 @@ PROTOTYPES = {
                                   c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vince_bn_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int64, c_int32, c_int, c_void_p]),
+    "vince_bn_train_apply": (c_int, [c_int, c_void_p, P(BnTrain), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                     c_int32, c_int, c_void_p]),
     "vince_bn_bwd_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_int64, c_int32, c_void_p]),
+                                    c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "vince_bn_bwd_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
-                                   c_void_p]),
+                                   c_int32, c_void_p]),
     "vince_stem_pool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
     "vince_stem_pool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

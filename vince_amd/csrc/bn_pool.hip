@@ -7,6 +7,8 @@
 // walks pixel rows, so a wavefront always touches whole contiguous row segments and the per-channel constants
 // (scale/shift/mean/invstd) live in registers for the whole walk.  Reductions go registers -> LDS -> one fp64
 // atomic per channel per workgroup.
+#include <string.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -112,15 +114,55 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                                                        const float* __restrict__ shift, const T* __restrict__ idn,
                                                        const float* __restrict__ ids, const float* __restrict__ idt,
                                                        T* __restrict__ out, uint8_t* __restrict__ mask_out, int64_t rows,
-                                                       int C, int relu, RowWalk w) {
+                                                       int C, int relu, RowWalk w, const vince_bn_train fin) {
     constexpr int CH = Elem<T>::CH;
+    __shared__ float cst[2][256 * CH];   // fused finalize: (scale, shift) of this block's channels
     const int col = blockIdx.x * w.tpc + (threadIdx.x % w.tpc);
+    if (fin.stats) {
+        // train-mode finalize fused in (vince_bn_train_apply): every workgroup folds the statistic replicas of ITS channels
+        // (a few KB from L2) instead of a separate launch per BatchNorm; row-block 0 also publishes the constants the
+        // backward pass needs and updates the running statistics, exactly once.
+        const int nch = w.tpc * CH, c_base = blockIdx.x * nch;
+        for (int cl = threadIdx.x; cl < nch; cl += 256) {
+            const int c = c_base + cl;
+            if (c >= C) continue;
+            double s1 = 0, s2 = 0;
+            for (int r = 0; r < fin.replicas; ++r) {
+                s1 += fin.stats[((size_t)r * C + c) * 2];
+                s2 += fin.stats[((size_t)r * C + c) * 2 + 1];
+            }
+            const double cnt = (double)fin.count;
+            const double m = s1 / cnt;
+            double var = s2 / cnt - m * m;
+            if (var < 0) var = 0;
+            const float mean = (float)m;
+            const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+            const float scv = fin.gamma[c] * invstd;
+            const float shv = fin.beta[c] - mean * scv;
+            cst[0][cl] = scv;
+            cst[1][cl] = shv;
+            if (blockIdx.y == 0) {
+                fin.scale[c] = scv;
+                fin.shift[c] = shv;
+                if (fin.save_mean) fin.save_mean[c] = mean;
+                if (fin.save_invstd) fin.save_invstd[c] = invstd;
+                if (fin.running_mean) {
+                    const double unbiased = cnt > 1 ? var * cnt / (cnt - 1) : var;
+                    fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * mean;
+                    fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
+                }
+                if (c == 0 && fin.num_batches_tracked) *fin.num_batches_tracked += 1;
+            }
+        }
+        __syncthreads();
+    }
     if (col >= w.cpr) return;
     float sc[CH], sh[CH], isc[CH], ish[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
-        sc[e] = scale[col * CH + e];
-        sh[e] = shift[col * CH + e];
+        const int cl = (threadIdx.x % w.tpc) * CH + e;
+        sc[e] = fin.stats ? cst[0][cl] : scale[col * CH + e];
+        sh[e] = fin.stats ? cst[1][cl] : shift[col * CH + e];
         isc[e] = ids ? ids[col * CH + e] : 1.f;
         ish[e] = ids ? idt[col * CH + e] : 0.f;
     }
@@ -173,7 +215,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const MaskArgs msk,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, double* sums,
-                                                            int64_t rows, int C, RowWalk w) {
+                                                            int64_t rows, int C, RowWalk w, int replicas) {
     constexpr int CH = Elem<T>::CH;
     __shared__ float red[256 * 2 * CH];
     const int tc = threadIdx.x % w.tpc, tr = threadIdx.x / w.tpc;
@@ -234,7 +276,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         float s = 0.f;
         for (int rr = 0; rr < w.rpp; ++rr) s += red[(rr * w.tpc + c_) * 2 * CH + slot];
         const int ch = gcol * CH + (slot % CH), which = slot / CH;
-        unsafeAtomicAdd(sums + ((size_t)(blockIdx.y % VINCE_STATS_REPLICAS) * C + ch) * 2 + which, (double)s);
+        unsafeAtomicAdd(sums + ((size_t)(blockIdx.y % replicas) * C + ch) * 2 + which, (double)s);
     }
 }
 
@@ -260,21 +302,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma,
                                                            const double* __restrict__ sums, double inv_count,
                                                            T* __restrict__ dy, T* __restrict__ gout, float* dgamma,
-                                                           float* dbeta, int64_t rows, int C, RowWalk w) {
+                                                           float* dbeta, int64_t rows, int C, RowWalk w, int replicas) {
     constexpr int CH = Elem<T>::CH;
+    // The replica fold of (sum g, sum g*xhat) is done here, per workgroup for ITS channels, instead of a separate launch
+    // per BatchNorm; row-block 0 adds dgamma / dbeta.
+    __shared__ float fold[2][256 * CH];
+    {
+        const int nch = w.tpc * CH, c_base = blockIdx.x * nch;
+        for (int cl = threadIdx.x; cl < nch; cl += 256) {
+            const int c = c_base + cl;
+            if (c >= C) continue;
+            double sg = 0, sgx = 0;
+            for (int r = 0; r < replicas; ++r) {
+                sg += sums[((size_t)r * C + c) * 2];
+                sgx += sums[((size_t)r * C + c) * 2 + 1];
+            }
+            fold[0][cl] = (float)(sg * inv_count);
+            fold[1][cl] = (float)(sgx * inv_count);
+            if (blockIdx.y == 0) {
+                if (dgamma) dgamma[c] += (float)sgx;
+                if (dbeta) dbeta[c] += (float)sg;
+            }
+        }
+        __syncthreads();
+    }
     const int col = blockIdx.x * w.tpc + (threadIdx.x % w.tpc);
     if (col >= w.cpr) return;
     float mu[CH], is[CH], k1[CH], ma[CH], mb[CH], msc[CH], msh[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
-        const int c = col * CH + e;
+        const int c = col * CH + e, cl = (threadIdx.x % w.tpc) * CH + e;
         msc[e] = msk.scale ? msk.scale[c] : 0.f;
         msh[e] = msk.scale ? msk.shift[c] : 0.f;
         mu[e] = mean[c];
         is[e] = invstd[c];
         k1[e] = gamma[c] * is[e];
-        ma[e] = (float)(sums[2 * c] * inv_count);       // replica 0 holds the folded totals (bn_bwd_fold_kernel)
-        mb[e] = (float)(sums[2 * c + 1] * inv_count);
+        ma[e] = fold[0][cl];
+        mb[e] = fold[1][cl];
     }
     const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + threadIdx.x / w.tpc;
     const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
@@ -598,31 +662,58 @@ extern "C" int vince_bn_apply(int dtype, const void* y, const float* scale, cons
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 4096);
     dim3 grid(w.colgroups, w.rowblocks);
+    vince_bn_train fin;
+    memset(&fin, 0, sizeof(fin));
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, scale, shift,
-                           (const float*)identity, id_scale, id_shift, (float*)out, mask_out, rows, C, relu, w);
+                           (const float*)identity, id_scale, id_shift, (float*)out, mask_out, rows, C, relu, w, fin);
     else
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, scale,
-                           shift, (const bf16_t*)identity, id_scale, id_shift, (bf16_t*)out, mask_out, rows, C, relu, w);
+                           shift, (const bf16_t*)identity, id_scale, id_shift, (bf16_t*)out, mask_out, rows, C, relu, w, fin);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_bn_train_apply(int dtype, const void* y, const vince_bn_train* bt, const void* identity,
+                                    const float* id_scale, const float* id_shift, void* out, uint8_t* mask_out, int64_t rows,
+                                    int32_t C, int relu, void* stream) {
+    DTYPE_OK("vince_bn_train_apply");
+    VINCE_CHECK_ARG(y && bt && out && rows > 0, VINCE_E_ARG, "vince_bn_train_apply: bad arguments");
+    VINCE_CHECK_ARG(bt->stats && bt->count > 0 && bt->gamma && bt->beta && bt->scale && bt->shift, VINCE_E_ARG,
+                    "vince_bn_train_apply: stats, count, gamma, beta, scale and shift are required");
+    VINCE_CHECK_ARG(!bt->running_mean == !bt->running_var, VINCE_E_ARG, "vince_bn_train_apply: running_mean and running_var come together");
+    VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_train_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
+    vince_bn_train fin = *bt;
+    if (fin.replicas <= 0 || fin.replicas > VINCE_STATS_REPLICAS) fin.replicas = VINCE_STATS_REPLICAS;
+    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 4096);
+    dim3 grid(w.colgroups, w.rowblocks);
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, nullptr, nullptr,
+                           (const float*)identity, id_scale, id_shift, (float*)out, mask_out, rows, C, relu, w, fin);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, nullptr,
+                           nullptr, (const bf16_t*)identity, id_scale, id_shift, (bf16_t*)out, mask_out, rows, C, relu, w, fin);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
 
 extern "C" int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_src, const uint8_t* mask_bits,
                                    const float* mask_scale, const float* mask_shift, const void* y, const float* mean,
-                                   const float* invstd, double* sums, int64_t rows, int32_t C, void* stream) {
+                                   const float* invstd, double* sums, int64_t rows, int32_t C, int32_t replicas,
+                                   void* stream) {
     const MaskArgs msk{mask_src, mask_bits, mask_scale, mask_shift};
     DTYPE_OK("vince_bn_bwd_reduce");
+    if (replicas <= 0 || replicas > VINCE_STATS_REPLICAS) replicas = VINCE_STATS_REPLICAS;
     VINCE_CHECK_ARG(dz && y && mean && invstd && sums && rows > 0, VINCE_E_ARG, "vince_bn_bwd_reduce: bad arguments");
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_bwd_reduce: C=%d not a multiple of %d", C, CH_OF(dtype));
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 2048);
     dim3 grid(w.colgroups, w.rowblocks);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
-                           msk, (const float*)y, mean, invstd, sums, rows, C, w);
+                           msk, (const float*)y, mean, invstd, sums, rows, C, w, replicas);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz,
-                           msk, (const bf16_t*)y, mean, invstd, sums, rows, C, w);
+                           msk, (const bf16_t*)y, mean, invstd, sums, rows, C, w, replicas);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
@@ -630,25 +721,25 @@ extern "C" int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_s
 extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_src, const uint8_t* mask_bits,
                                   const float* mask_scale, const float* mask_shift, const void* y, const float* mean,
                                   const float* invstd, const float* gamma, const double* sums, int64_t count, void* dy,
-                                  void* g_out, float* dgamma, float* dbeta, int64_t rows, int32_t C, void* stream) {
+                                  void* g_out, float* dgamma, float* dbeta, int64_t rows, int32_t C, int32_t replicas,
+                                  void* stream) {
     const MaskArgs msk{mask_src, mask_bits, mask_scale, mask_shift};
     DTYPE_OK("vince_bn_bwd_apply");
+    if (replicas <= 0 || replicas > VINCE_STATS_REPLICAS) replicas = VINCE_STATS_REPLICAS;
     VINCE_CHECK_ARG(dz && y && mean && invstd && gamma && sums && dy && rows > 0 && count > 0, VINCE_E_ARG,
                     "vince_bn_bwd_apply: bad arguments");
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_bwd_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 4096);
     dim3 grid(w.colgroups, w.rowblocks);
     const double inv_count = 1.0 / (double)count;
-    hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double*)sums, C, dgamma,
-                       dbeta);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
                            msk, (const float*)y, mean, invstd, gamma, sums, inv_count, (float*)dy,
-                           (float*)g_out, dgamma, dbeta, rows, C, w);
+                           (float*)g_out, dgamma, dbeta, rows, C, w, replicas);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz,
                            msk, (const bf16_t*)y, mean, invstd, gamma, sums, inv_count, (bf16_t*)dy,
-                           (bf16_t*)g_out, dgamma, dbeta, rows, C, w);
+                           (bf16_t*)g_out, dgamma, dbeta, rows, C, w, replicas);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

@@ -253,7 +253,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
 #pragma unroll
             for (int w = 0; w < 4; ++w) s += red[((w * CPR + ck) * CH + e) * 2 + which];
             if (c0 + ch < d.Co && !(p.ablate & 8))   // ablate 8: measurement aid, drops the atomics only
-                unsafeAtomicAdd(red_out + ((size_t)(tile % VINCE_STATS_REPLICAS) * d.Co + (c0 + ch)) * 2 + which, (double)s);
+                unsafeAtomicAdd(red_out + ((size_t)(tile % (uint32_t)p.e.replicas) * d.Co + (c0 + ch)) * 2 + which, (double)s);
         }
     }
 }
@@ -617,6 +617,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     vince_conv_epi e;
     if (epi) e = *epi; else memset(&e, 0, sizeof(e));
     VINCE_CHECK_ARG(dd && in && w && out, VINCE_E_ARG, "vince_conv_igemm: null pointer");
+    if (e.replicas <= 0 || e.replicas > VINCE_STATS_REPLICAS) e.replicas = VINCE_STATS_REPLICAS;
     VINCE_CHECK_ARG(!e.acc_mask || (e.flags & VINCE_EPI_ACCUMULATE), VINCE_E_ARG, "vince_conv_igemm: acc_mask needs VINCE_EPI_ACCUMULATE");
     VINCE_CHECK_ARG(!e.bnred.y || (e.bnred.mean && e.bnred.invstd && e.bnred.sums && !e.stats), VINCE_E_ARG,
                     "vince_conv_igemm: bnred needs y, mean, invstd and sums, and excludes stats");

@@ -30,6 +30,7 @@ struct ConvL {
 };
 struct BnL {
     int C, gamma, beta, index;   // param indices + bn index
+    int R;                       // statistic replicas the producers spread over (few workgroups -> few replicas)
     size_t stats, sums, consts;  // stats/sums: offset in doubles; consts: offset in floats
     std::string name;
 };
@@ -129,6 +130,7 @@ struct Planner {
         t->pkind.push_back(2);
         t->pbn.push_back(b.index);
         t->pshape.push_back({C, 0, 0, 0});
+        b.R = VINCE_STATS_REPLICAS;
         b.stats = nd; b.sums = nd;   // sums live in a parallel region of the same size
         nd += (size_t)2 * C * VINCE_STATS_REPLICAS;
         b.consts = nf;
@@ -148,6 +150,13 @@ vince_conv_desc fwd_desc(const vince_trunk* t, const ConvL& c) {
     d.OH = c.Ho; d.OW = c.Wo; d.osh = d.osw = 1; d.oh0 = d.ow0 = 0;
     d.Cs = d.Kw = 0;
     return d;
+}
+
+// Replicas of a BatchNorm's fp64 accumulators: enough to keep atomic contention per address low (workgroups of the
+// producing conv per replica <= ~512), few enough that the consumers folding them in their prologue read little.
+int replicas_for(int64_t rows) {
+    const int64_t tiles = (rows + 127) / 128;
+    return tiles >= 4096 ? 16 : tiles >= 1024 ? 4 : 1;
 }
 
 // The 7x7/s2/p3 stem as 7 packed row taps (vince_conv_desc.Cs): the input is stored [N][H][sWp][4] with 3 zero columns on
@@ -220,7 +229,7 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     t->sWp = (2 * t->stem.Wo + 6 + 1) & ~1;   // last tap row ends at padded column 2*(Wo-1) + 8; even for 16-byte rows
     // (room for either stem formulation: VINCE_STEM_PACKED=0 selects the 49-tap one, a measurement / cross-check aid)
     t->off_x0 = P.alloc_act(std::max((size_t)N * cfg->H * t->sWp * STEM_CS, (size_t)N * cfg->H * cfg->W * t->Cp));
-    t->stem_bn = P.bn("bn1", 64);
+    t->stem_bn = P.bn("bn1", 64);   // (R stays at the maximum: 25 088 workgroups feed it at 224 x 224)
     t->sH = t->stem.Ho; t->sW = t->stem.Wo;
     t->pH = (t->sH + 2 - 3) / 2 + 1; t->pW = (t->sW + 2 - 3) / 2 + 1;
     t->off_ystem = P.alloc_act((size_t)N * t->sH * t->sW * 64);
@@ -265,6 +274,8 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
                 b.bd = P.bn(pre + "downsample.1", outp);
             }
             const int Ho = b.c[b.nconv - 1].Ho, Wo = b.c[b.nconv - 1].Wo;
+            for (int ci = 0; ci < b.nconv; ++ci) b.b[ci].R = replicas_for((int64_t)N * b.c[ci].Ho * b.c[ci].Wo);
+            if (b.has_ds) b.bd.R = replicas_for((int64_t)N * Ho * Wo);
             for (int ci = 0; ci < b.nconv; ++ci) {
                 b.y[ci] = P.alloc_act((size_t)N * b.c[ci].Ho * b.c[ci].Wo * b.c[ci].Co);
                 if (ci < b.nconv - 1) b.a[ci] = P.alloc_act((size_t)N * b.c[ci].Ho * b.c[ci].Wo * b.c[ci].Co);
@@ -357,22 +368,62 @@ struct Ctx {
 
 #define RC(expr) do { int _rc = (expr); if (_rc != VINCE_OK) return _rc; } while (0)
 
+// conv (+ BatchNorm statistics in train mode).  finalize_now: also run the stand-alone finalize -- needed in eval mode and
+// where the consumer of scale / shift is not vince_bn_train_apply (the stem's pool, the downsample branch's identity
+// affine); everywhere else the finalize rides in the prologue of the apply pass (bn_apply_fwd below).
 int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_off, float* const* bn_running,
-                int64_t* const* bn_nbt, int train_bn, const vince_conv_desc* desc = nullptr) {
+                int64_t* const* bn_nbt, int train_bn, bool finalize_now, const vince_conv_desc* desc = nullptr) {
     vince_conv_desc d = desc ? *desc : fwd_desc(c.t, cv);
     vince_conv_epi e;
     memset(&e, 0, sizeof(e));
     e.stats = train_bn ? c.stats(bn) : nullptr;
+    e.replicas = bn.R;
     RC(vince_conv_igemm(&d, c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), &e, c.stream));
-    const int64_t count = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
-    RC(vince_bn_finalize(c.stats(bn), count, bn.C, c.params[bn.gamma], c.params[bn.beta], bn_running[2 * bn.index],
-                         bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr, 0.1f, 1e-5f, train_bn,
-                         c.consts(bn, 0), c.consts(bn, 1), c.consts(bn, 2), c.consts(bn, 3), c.stream));
+    if (finalize_now || !train_bn) {
+        const int64_t count = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
+        RC(vince_bn_finalize(c.stats(bn), count, bn.C, c.params[bn.gamma], c.params[bn.beta], bn_running[2 * bn.index],
+                             bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr, 0.1f, 1e-5f, train_bn,
+                             c.consts(bn, 0), c.consts(bn, 1), c.consts(bn, 2), c.consts(bn, 3), c.stream));
+    }
     return VINCE_OK;
 }
 
+// out = relu(bn(y) [+ identity affine]); in train mode the BatchNorm's finalize is fused into the same launch
+int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const void* idn, const float* ids, const float* idt,
+                 void* out, uint8_t* mask_out, float* const* bn_running, int64_t* const* bn_nbt, int train_bn) {
+    const int64_t rows = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
+    static const bool fuse_fin = !(getenv("VINCE_FUSE_FINALIZE") && atoi(getenv("VINCE_FUSE_FINALIZE")) == 0);
+    if (!train_bn)
+        return vince_bn_apply(c.dtype, at(c.ws, y_off), c.consts(bn, 0), c.consts(bn, 1), idn, ids, idt, out, mask_out, rows,
+                              cv.Co, 1, c.stream);
+    if (!fuse_fin) {   // measurement aid: the two launches of the unfused path
+        RC(vince_bn_finalize(c.stats(bn), rows, bn.C, c.params[bn.gamma], c.params[bn.beta], bn_running[2 * bn.index],
+                             bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr, 0.1f, 1e-5f, 1,
+                             c.consts(bn, 0), c.consts(bn, 1), c.consts(bn, 2), c.consts(bn, 3), c.stream));
+        return vince_bn_apply(c.dtype, at(c.ws, y_off), c.consts(bn, 0), c.consts(bn, 1), idn, ids, idt, out, mask_out, rows,
+                              cv.Co, 1, c.stream);
+    }
+    vince_bn_train bt;
+    memset(&bt, 0, sizeof(bt));
+    bt.stats = c.stats(bn);
+    bt.replicas = bn.R;
+    bt.count = rows;
+    bt.gamma = c.params[bn.gamma];
+    bt.beta = c.params[bn.beta];
+    bt.running_mean = bn_running[2 * bn.index];
+    bt.running_var = bn_running[2 * bn.index + 1];
+    bt.num_batches_tracked = bn_nbt ? bn_nbt[bn.index] : nullptr;
+    bt.momentum = 0.1f;
+    bt.eps = 1e-5f;
+    bt.scale = c.consts(bn, 0);
+    bt.shift = c.consts(bn, 1);
+    bt.save_mean = c.consts(bn, 2);
+    bt.save_invstd = c.consts(bn, 3);
+    return vince_bn_train_apply(c.dtype, at(c.ws, y_off), &bt, idn, ids, idt, out, mask_out, rows, cv.Co, 1, c.stream);
+}
+
 int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, const uint8_t* acc_mask = nullptr,
-          const vince_bn_reduce* bnred = nullptr) {
+          const vince_bn_reduce* bnred = nullptr, int replicas = 0) {
     vince_conv_desc ds[4];
     const int n = dgrad_descs(c.t, cv, ds);
     const int classes = cv.stride * cv.stride;
@@ -383,6 +434,7 @@ int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, co
     e.flags = accumulate ? VINCE_EPI_ACCUMULATE : 0;
     e.acc_mask = acc_mask;
     if (bnred) e.bnred = *bnred;
+    e.replicas = replicas;
     for (int i = 0; i < n; ++i) RC(vince_conv_igemm(&ds[i], c.dtype, dy, at((void*)c.wcache, cv.wt), dx, &e, c.stream));
     return VINCE_OK;
 }
@@ -402,10 +454,10 @@ int bn_bwd(Ctx& c, const BnL& bn, const void* dz, const uint8_t* bits, bool self
     const float* msh = self_mask ? c.consts(bn, 1) : nullptr;
     if (!reduced)
         RC(vince_bn_bwd_reduce(c.dtype, dz, nullptr, bits, msc, msh, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3),
-                               c.sums(bn), rows, bn.C, c.stream));
+                               c.sums(bn), rows, bn.C, bn.R, c.stream));
     RC(vince_bn_bwd_apply(c.dtype, dz, nullptr, bits, msc, msh, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3),
                           c.params[bn.gamma], c.sums(bn), rows, dy, g_out, grads[bn.gamma], grads[bn.beta], rows, bn.C,
-                          c.stream));
+                          bn.R, c.stream));
     return VINCE_OK;
 }
 
@@ -587,31 +639,28 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     }
     const vince_conv_desc sd = stem_desc(t);
     // stem: conv 7x7/s2 -> BN -> ReLU -> maxpool 3x3/s2 (resnet.py:170-173); BN-apply + ReLU are fused into the pool
-    RC(conv_bn_fwd(c, t->stem, t->stem_bn, t->off_x0, t->off_ystem, bn_running, bn_nbt, train_bn, &sd));
+    RC(conv_bn_fwd(c, t->stem, t->stem_bn, t->off_x0, t->off_ystem, bn_running, bn_nbt, train_bn, true, &sd));
     RC(vince_stem_pool_fwd(c.dtype, at(workspace, t->off_ystem), c.consts(t->stem_bn, 0), c.consts(t->stem_bn, 1),
                            at(workspace, t->off_p0), (uint8_t*)at(workspace, t->off_amax), N, t->sH, t->sW, 64, stream));
     for (const Blk& b : t->blocks) {
         size_t in = b.x_in;
         for (int ci = 0; ci < b.nconv; ++ci) {
-            RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn));
+            RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, false));
             if (ci < b.nconv - 1) {
-                const int64_t rows = (int64_t)N * b.c[ci].Ho * b.c[ci].Wo;
-                RC(vince_bn_apply(c.dtype, at(workspace, b.y[ci]), c.consts(b.b[ci], 0), c.consts(b.b[ci], 1), nullptr, nullptr,
-                                  nullptr, at(workspace, b.a[ci]), nullptr, rows, b.c[ci].Co, 1, stream));
+                RC(bn_apply_fwd(c, b.c[ci], b.b[ci], b.y[ci], nullptr, nullptr, nullptr, at(workspace, b.a[ci]), nullptr,
+                                bn_running, bn_nbt, train_bn));
                 in = b.a[ci];
             }
         }
-        const ConvL& last = b.c[b.nconv - 1];
-        const BnL& lbn = b.b[b.nconv - 1];
-        const int64_t rows = (int64_t)N * last.Ho * last.Wo;
-        if (b.has_ds) {
-            RC(conv_bn_fwd(c, b.cd, b.bd, b.x_in, b.yd, bn_running, bn_nbt, train_bn));
-            RC(vince_bn_apply(c.dtype, at(workspace, b.y[b.nconv - 1]), c.consts(lbn, 0), c.consts(lbn, 1), at(workspace, b.yd),
-                              c.consts(b.bd, 0), c.consts(b.bd, 1), at(workspace, b.z), (uint8_t*)at(workspace, b.zmask), rows,
-                              last.Co, 1, stream));
+        const int L = b.nconv - 1;
+        uint8_t* zmask = (uint8_t*)at(workspace, b.zmask);
+        if (b.has_ds) {   // the downsample BatchNorm enters the join as an affine of its conv output: finalised on its own
+            RC(conv_bn_fwd(c, b.cd, b.bd, b.x_in, b.yd, bn_running, bn_nbt, train_bn, true));
+            RC(bn_apply_fwd(c, b.c[L], b.b[L], b.y[L], at(workspace, b.yd), c.consts(b.bd, 0), c.consts(b.bd, 1),
+                            at(workspace, b.z), zmask, bn_running, bn_nbt, train_bn));
         } else {
-            RC(vince_bn_apply(c.dtype, at(workspace, b.y[b.nconv - 1]), c.consts(lbn, 0), c.consts(lbn, 1), at(workspace, b.x_in),
-                              nullptr, nullptr, at(workspace, b.z), (uint8_t*)at(workspace, b.zmask), rows, last.Co, 1, stream));
+            RC(bn_apply_fwd(c, b.c[L], b.b[L], b.y[L], at(workspace, b.x_in), nullptr, nullptr, at(workspace, b.z), zmask,
+                            bn_running, bn_nbt, train_bn));
         }
     }
     RC(vince_avgpool_fwd(c.dtype, at(workspace, t->blocks.back().z), pooled, N, t->outH * t->outW, t->outC, stream));
@@ -698,7 +747,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             RC(wgrad_layer(b.c[ci], in_act));
             if (ci > 0) {
                 vince_bn_reduce br = bn_reduce_of(c, b.b[ci - 1], nullptr, true, b.y[ci - 1]);
-                RC(dgrad(c, b.c[ci], DY, DA, false, nullptr, fuse_red ? &br : nullptr));
+                RC(dgrad(c, b.c[ci], DY, DA, false, nullptr, fuse_red ? &br : nullptr, b.b[ci - 1].R));
                 const int64_t rows = (int64_t)N * b.c[ci - 1].Ho * b.c[ci - 1].Wo;
                 RC(next_dy());
                 RC(bn_bwd(c, b.b[ci - 1], DA, nullptr, true, b.y[ci - 1], rows, DY, nullptr, grads, fuse_red));
@@ -706,12 +755,14 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                 // block-input gradient; it is the dz of the block below, whose last BatchNorm's reduction is fused here
                 vince_bn_reduce br;
                 const bool fuse = fuse_red && bi > 0;
+                int rr = 0;
                 if (fuse) {
                     const Blk& lo = t->blocks[bi - 1];
                     br = bn_reduce_of(c, lo.b[lo.nconv - 1], (const uint8_t*)at(workspace, lo.zmask), false, lo.y[lo.nconv - 1]);
+                    rr = lo.b[lo.nconv - 1].R;
                 }
-                if (b.has_ds) RC(dgrad(c, b.c[0], DY, DX, true, nullptr, fuse ? &br : nullptr));
-                else RC(dgrad(c, b.c[0], DY, Z, true, zbits, fuse ? &br : nullptr));   // Z <- dgrad + Z * (z > 0)
+                if (b.has_ds) RC(dgrad(c, b.c[0], DY, DX, true, nullptr, fuse ? &br : nullptr, rr));
+                else RC(dgrad(c, b.c[0], DY, Z, true, zbits, fuse ? &br : nullptr, rr));   // Z <- dgrad + Z * (z > 0)
                 last_reduced = fuse;
             }
         }

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BnReduce, ConvDesc, ConvEpi, InfoNCEDesc, VINCE_BF16, VINCE_F32, check, lib
+from ._lib import BnReduce, BnTrain, ConvDesc, ConvEpi, InfoNCEDesc, VINCE_BF16, VINCE_F32, check, lib
 
 EPI_ACCUMULATE, EPI_RELU = _lib.EPI_ACCUMULATE, _lib.EPI_RELU
 STATS_REPLICAS = 16   # VINCE_STATS_REPLICAS in include/vince_hip.h
@@ -115,7 +115,7 @@ def bn_reduce_arg(y, mean, invstd, sums, mask_bits=None, mask_scale=None, mask_s
     return r
 
 
-def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None):
+def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None, replicas=0):
     """vince_conv_igemm with the epilogue options of vince_conv_epi."""
     require_gpu(x, w, out, bias, stats, acc_mask)
     e = ConvEpi()
@@ -125,6 +125,7 @@ def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, b
     e.acc_mask = None if acc_mask is None else acc_mask.data_ptr()
     if bnred is not None:
         e.bnred = bnred
+    e.replicas = replicas
     check(lib().vince_conv_igemm(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(w), _ptr(out), ctypes.byref(e),
                                  stream_ptr()))
     return out
@@ -207,30 +208,54 @@ def bn_apply(y, scale, shift, identity=None, id_scale=None, id_shift=None, relu=
     return (out, mask) if want_mask else out
 
 
-def bn_bwd_reduce(dz, y, mean, invstd, mask_src=None, mask_bits=None, mask_scale=None, mask_shift=None):
+def bn_train_apply(y, stats, count, gamma, beta, running_mean=None, running_var=None, nbt=None, identity=None, id_scale=None,
+                   id_shift=None, relu=True, want_mask=False, replicas=0, momentum=0.1, eps=1e-5):
+    """Train-mode finalize + apply in one launch.  Returns (out, mask or None, scale, shift, mean, invstd)."""
+    require_gpu(y, stats, gamma, beta, running_mean, running_var, nbt, identity, id_scale, id_shift)
+    C = y.shape[-1]
+    ch = 4 if y.dtype == torch.float32 else 8
+    out = torch.empty_like(y)
+    mask = torch.empty(y.numel() // ch, device=y.device, dtype=torch.uint8) if want_mask else None
+    scale, shift, mean, invstd = (torch.empty(C, device=y.device) for _ in range(4))
+    bt = BnTrain()
+    bt.stats, bt.replicas, bt.count = stats.data_ptr(), replicas, count
+    bt.gamma, bt.beta = gamma.data_ptr(), beta.data_ptr()
+    bt.running_mean = None if running_mean is None else running_mean.data_ptr()
+    bt.running_var = None if running_var is None else running_var.data_ptr()
+    bt.num_batches_tracked = None if nbt is None else nbt.data_ptr()
+    bt.momentum, bt.eps = momentum, eps
+    bt.scale, bt.shift, bt.save_mean, bt.save_invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    check(lib().vince_bn_train_apply(dtype_code(y), _ptr(y), ctypes.byref(bt), _ptr(identity), _ptr(id_scale), _ptr(id_shift),
+                                     _ptr(out), _ptr(mask), y.numel() // C, C, int(relu), stream_ptr()))
+    return out, mask, scale, shift, mean, invstd
+
+
+def bn_bwd_reduce(dz, y, mean, invstd, mask_src=None, mask_bits=None, mask_scale=None, mask_shift=None, replicas=0):
     """(sum g, sum g*xhat) per channel, replicas folded: the stand-alone pass the fused dgrad epilogue replaces."""
     require_gpu(dz, y, mean, invstd, mask_src, mask_bits, mask_scale, mask_shift)
     C = y.shape[-1]
     rows = y.numel() // C
     sums = torch.zeros(STATS_REPLICAS, C, 2, device=y.device, dtype=torch.float64)
     check(lib().vince_bn_bwd_reduce(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(mask_bits), _ptr(mask_scale),
-                                    _ptr(mask_shift), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums), rows, C, stream_ptr()))
+                                    _ptr(mask_shift), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums), rows, C, replicas,
+                                    stream_ptr()))
     return sums.sum(0)
 
 
 def bn_bwd(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, want_g=False, mask_bits=None, mask_scale=None,
-           mask_shift=None):
+           mask_shift=None, replicas=0):
     require_gpu(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, mask_bits, mask_scale, mask_shift)
     C = y.shape[-1]
     rows = y.numel() // C
     sums = torch.zeros(STATS_REPLICAS, C, 2, device=y.device, dtype=torch.float64)
     check(lib().vince_bn_bwd_reduce(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(mask_bits), _ptr(mask_scale),
-                                    _ptr(mask_shift), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums), rows, C, stream_ptr()))
+                                    _ptr(mask_shift), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(sums), rows, C, replicas,
+                                    stream_ptr()))
     dy = torch.empty_like(y)
     g = torch.empty_like(y) if want_g else None
     check(lib().vince_bn_bwd_apply(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(mask_bits), _ptr(mask_scale),
                                    _ptr(mask_shift), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), rows,
-                                   _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), rows, C, stream_ptr()))
+                                   _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), rows, C, replicas, stream_ptr()))
     return dy, g
 
 
