@@ -721,6 +721,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     // BatchNorm-backward reductions ride in the epilogue of the dgrad that produces their input gradient
     // (VINCE_FUSE_BNRED=0 runs them as separate passes: measurement aid)
     static const bool fuse_red = !(getenv("VINCE_FUSE_BNRED") && atoi(getenv("VINCE_FUSE_BNRED")) == 0);
+    static const bool wgrad_late = getenv("VINCE_WGRAD_LATE") && atoi(getenv("VINCE_WGRAD_LATE")) != 0;
     bool last_reduced = false;   // was the last-BN reduction of the current block done by the block above it?
     for (int bi = (int)t->blocks.size() - 1; bi >= 0; --bi) {
         const Blk& b = t->blocks[bi];
@@ -744,10 +745,13 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         }
         for (int ci = L; ci >= 0; --ci) {
             const void* in_act = ci == 0 ? x_in : at(workspace, b.a[ci - 1]);
-            RC(wgrad_layer(b.c[ci], in_act));
+            // wgrad_late: the weight gradient of a layer starts after that layer's dgrad instead of next to it, i.e. it
+            // runs beside the (HBM-bound) BatchNorm backward of the layer below (VINCE_WGRAD_LATE, measurement knob)
+            if (!wgrad_late) RC(wgrad_layer(b.c[ci], in_act));
             if (ci > 0) {
                 vince_bn_reduce br = bn_reduce_of(c, b.b[ci - 1], nullptr, true, b.y[ci - 1]);
                 RC(dgrad(c, b.c[ci], DY, DA, false, nullptr, fuse_red ? &br : nullptr, b.b[ci - 1].R));
+                if (wgrad_late) RC(wgrad_layer(b.c[ci], in_act));
                 const int64_t rows = (int64_t)N * b.c[ci - 1].Ho * b.c[ci - 1].Wo;
                 RC(next_dy());
                 RC(bn_bwd(c, b.b[ci - 1], DA, nullptr, true, b.y[ci - 1], rows, DY, nullptr, grads, fuse_red));
@@ -763,6 +767,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                 }
                 if (b.has_ds) RC(dgrad(c, b.c[0], DY, DX, true, nullptr, fuse ? &br : nullptr, rr));
                 else RC(dgrad(c, b.c[0], DY, Z, true, zbits, fuse ? &br : nullptr, rr));   // Z <- dgrad + Z * (z > 0)
+                if (wgrad_late) RC(wgrad_layer(b.c[0], in_act));
                 last_reduced = fuse;
             }
         }
