@@ -108,6 +108,39 @@ def test_g3_trunk_head_bf16_reported(arch, embed, record_property):
     assert err < 0.2 and cos > 0.99
 
 
+def test_bf16_vs_fp32_at_a_training_batch(record_property):
+    """The benchmark configuration's precision, measured where BatchNorm has a realistic sample count: ResNet-50, 32 frames
+    of 224 x 224 (1 568 - 401 408 samples per channel), bf16 trunk against this build's fp32 trunk (itself within 5e-4 of
+    the reference goldens), same weights and inputs; InfoNCE loss against the same queue.  Reported, and bounded."""
+    from vince_amd.utils import loss_util
+    x = (vo.structured_frames(32, 224, 224, seed=901) + 0.25 * vo.gaussian_frames(32, 224, 224, 902)).to(DEV)
+    xk = (vo.structured_frames(32, 224, 224, seed=901) + 0.25 * vo.gaussian_frames(32, 224, 224, 903)).to(DEV)
+    queue = torch.nn.functional.normalize(torch.randn(4096, 128, generator=torch.Generator().manual_seed(9)), dim=1).to(DEV)
+    out = {}
+    for dt in ("fp32", "bf16"):
+        _, model = build("ResNet50", 128, dt, 11)
+        model.train(True)
+        with torch.no_grad():
+            q = model.get_embeddings({"data": x})["embeddings"]
+            k = model.get_embeddings({"data": xk})["embeddings"]
+            sims = torch.cat([(q * k).sum(1, keepdim=True), q @ queue.t()], 1)
+            mask = torch.zeros_like(sims, dtype=torch.bool)
+            mask[:, 0] = True
+            loss = loss_util.similarity_cross_entropy(sims.contiguous(), 0.2, sims.shape[0], 1, mask=mask)["dist"]
+        out[dt] = (q.cpu(), float(loss))
+        del model
+    err = rel(out["bf16"][0], out["fp32"][0])
+    cos = float((out["bf16"][0] * out["fp32"][0]).sum(1).min())
+    loss_rel = abs(out["bf16"][1] / out["fp32"][1] - 1.0)
+    record_property("bf16_vs_fp32_embedding_rel_err_b32", err)
+    record_property("bf16_vs_fp32_loss_rel_err_b32", loss_rel)
+    print("bf16 vs fp32, ResNet50 B=32: embedding max rel err %.3e, min cosine %.6f, InfoNCE loss rel err %.3e"
+          % (err, cos, loss_rel))
+    # measured on MI355X: embedding max rel err 1.2e-1 (random-init encoder: nearly collapsed embeddings, cosine 0.9946),
+    # InfoNCE loss rel err 2.2e-4 -- the loss meets the north-star 1e-3 bar in bf16, raw embedding elements do not
+    assert err < 0.25 and cos > 0.99 and loss_rel < 1e-3
+
+
 # ------------------------------------------------------------------------------------------ training step, teacher forced
 def oracle_trainer(mode, lr=0.03):
     return vo.OracleTrainer("ResNet18", 64, 512, 32, 0.07, lr, inter_batch=mode == "vince",
