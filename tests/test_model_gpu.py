@@ -373,9 +373,11 @@ def test_solver_c5_mode_jigsaw_multiframe_and_val():
     from vince_amd.data_source import SyntheticFrames
     from vince_amd.solvers.vince_solver import VinceSolver
     val = SyntheticFrames(16, 64, 64, 4, device=DEV, seed=77, iterations=2)
+    g = torch.Generator().manual_seed(3)
+    knn_set = {"data": torch.randint(0, 256, (48, 3, 64, 64), generator=g).float(), "labels": torch.randint(0, 10, (48,), generator=g)}
     args = make_args(backbone="ResNet18", batch_size=16, vince_queue_size=64, input_size=(64, 64), compute_dtype="bf16",
                      num_frames=4, inter_batch_comparison=True, self_batch_comparison=True, jigsaw=True,
-                     val_batch_source=[val])
+                     val_batch_source=[val], knn_dataset=knn_set)
     solver = VinceSolver(args)
     solver.reset_epoch()
     seen = set()
@@ -388,7 +390,33 @@ def test_solver_c5_mode_jigsaw_multiframe_and_val():
                                "nce_accuracy_self_mean", "nce_softmax_weight_self_mean", "cosine_self_sim"}
     out = solver.run_val()
     assert np.isfinite(out["nce_loss"]) and 0.0 <= out["nce_accuracy_mean"] <= 1.0
+    assert 0.0 <= out["epoch_knn_cifar"] <= 1.0                # the labelled-set k-NN score of vince_solver.py:651-679
     assert solver.model.training                                # run_val restores train mode
+
+
+def test_knn_eval_matches_kdtree():
+    """brute-force GEMM + top-k on the GPU against the reference's recipe (sklearn KDTree, k=11, drop the
+    self match, scipy mode) on clustered unit vectors."""
+    import scipy.stats
+    from sklearn.neighbors import KDTree
+    from vince_amd.utils.knn_eval import knn_accuracy, knn_indices
+    g = torch.Generator().manual_seed(11)
+    n, d, ncls = 3001, 64, 10
+    centers = torch.randn(ncls, d, generator=g)
+    labels = torch.randint(0, ncls, (n,), generator=g)
+    feats = torch.nn.functional.normalize(centers[labels] + 0.9 * torch.randn(n, d, generator=g), dim=1)
+    kdt = KDTree(feats.numpy().astype(np.float64), leaf_size=40, metric="euclidean")
+    ref_d, ref_i = kdt.query(feats.numpy().astype(np.float64), k=11)
+    ref_pred = scipy.stats.mode(labels.numpy()[ref_i[:, 1:]], axis=1, keepdims=True)[0].squeeze(1)
+    ref_acc = float(np.mean(ref_pred == labels.numpy()))
+    acc, preds, nbrs = knn_accuracy(feats.to(DEV), labels.to(DEV), k=10)
+    idx = knn_indices(feats.to(DEV), 11).cpu().numpy()
+    assert (idx[:, 0] == np.arange(n)).all()                   # the self match comes first, as KDTree returns it
+    # identical neighbour sets except where two distances tie to fp32 rounding at the k-th place
+    same = np.array([set(a) == set(b) for a, b in zip(idx, ref_i)])
+    assert same.mean() > 0.999
+    assert (preds.cpu().numpy() == ref_pred).mean() > 0.999
+    assert abs(acc - ref_acc) < 1e-3
 
 
 def test_bucketed_allreduce_machinery_single_rank():

@@ -302,6 +302,19 @@ class VinceSolver(BaseSolver):
         return loss_dict, metrics
 
     # ------------------------------------------------------------------------------------------ validation
+    def knn_eval(self, data, labels, k=10):
+        from .. import constants
+        from ..utils.knn_eval import knn_accuracy
+        device = self.model.device
+        mean = torch.from_numpy(constants.IMAGENET_MEAN).to(device).view(1, -1, 1, 1)
+        std = torch.from_numpy(constants.IMAGENET_STD).to(device).view(1, -1, 1, 1)
+        feats = []
+        with torch.no_grad():
+            for i in range(0, data.shape[0], self.args.batch_size):
+                x = (data[i:i + self.args.batch_size].to(device=device, dtype=torch.float32) - mean) / std
+                feats.append(self.model.get_embeddings({"data": x})["embeddings"])
+        return knn_accuracy(torch.cat(feats, 0), labels.to(device), k)[0]
+
     def run_val(self):
         """vince_solver.py:520-649 without the CIFAR kNN / image dumps: the QUERY encoder in eval mode (running BN
         statistics), the key encoder still in train mode, no backward, no enqueue, no EMA."""
@@ -333,9 +346,14 @@ class VinceSolver(BaseSolver):
                             loss_meters[k].update(float(v[0] * v[1]), batch["batch_size"])
                         for k, v in self.model.get_metrics(output).items():
                             metric_meters[k].update(float(v), batch["batch_size"])
-        self.model.train()
         out = {k: m.avg for k, m in loss_meters.items()}
         out.update({k: m.avg for k, m in metric_meters.items()})
+        knn_set = getattr(self.args, "knn_dataset", None)
+        if knn_set is not None:
+            # vince_solver.py:651-679: embed a labelled image set (CIFAR in the reference; `data` in 0..255 NCHW like
+            # cifar_dataset.data, `labels`) with the eval-mode encoder and score it with leave-one-out 10-NN
+            out["epoch_knn_cifar"] = self.knn_eval(knn_set["data"], knn_set["labels"])
+        self.model.train()
         if self.val_logger is not None:
             self.val_logger.dict_log({"losses/%s/%s" % (self.full_name, k): v for k, v in out.items()}, self.iteration)
         return out
