@@ -236,11 +236,12 @@ def main():
             # HBM bytes per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note in
             # MI355X_MICROARCH.md, + WRITE_SIZE), recorded by tools/rocpd_pmc.py into profiles/ -- bench.py cannot run
             # the counter passes itself
-            traffic = None
+            traffic = traffic_source = None
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_conv_igemm.json")) as fh:
                     pm = json.load(fh)
-                traffic = {"bytes_per_launch": pm["kernels"][dom_conv]["bytes_per_launch"], "source": pm["source"]}
+                traffic = pm["kernels"][dom_conv]["bytes_per_launch"]      # HBM bytes per launch of that kernel
+                traffic_source = pm["source"]
                 if pm.get("step"):
                     # whole-step HBM view: the step as a whole is bandwidth-bound
                     out["step_hbm"] = {"bytes_per_step": pm["step"]["bytes"], "unit": "GB/s", "peak": 8000.0,
@@ -251,6 +252,8 @@ def main():
                 pass
             out["roofline"] = {"bound": "mfma", "kernel": dom_conv, "achieved": k["tflops"], "peak": PEAK_TFLOPS[opt.dtype],
                                "unit": "TFLOP/s", "frac": round(k["tflops"] / PEAK_TFLOPS[opt.dtype], 4), "traffic": traffic,
+                               "traffic_unit": "bytes/launch", "traffic_source": traffic_source,
+                               "flops_per_launch": round(k["tflops"] * 1e12 * k["avg_us"] * 1e-6),
                                "avg_us": k["avg_us"], "launches_per_step": k["launches_per_step"],
                                "ms_per_step": k["ms_per_step"], "longest_kernel_family": dom}
         out["kernels"] = kernels
