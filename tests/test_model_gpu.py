@@ -427,14 +427,14 @@ def test_bucketed_allreduce_machinery_single_rank():
     from vince_amd.data_source import SyntheticFrames
     from vince_amd.solvers.vince_solver import VinceSolver
 
-    def run(force):
+    def run(force, shuffle_bn=False):
         torch.manual_seed(0)
         if force:
             os.environ["VINCE_FORCE_DP"] = "1"
         else:
             os.environ.pop("VINCE_FORCE_DP", None)
         args = make_args(backbone="ResNet18", batch_size=16, vince_queue_size=64, input_size=(64, 64), compute_dtype="fp32",
-                         batch_source=SyntheticFrames(16, 64, 64, 1, device=DEV, seed=5))
+                         batch_source=SyntheticFrames(16, 64, 64, 1, device=DEV, seed=5), dp_shuffle_bn=shuffle_bn)
         solver = VinceSolver(args)
         solver.model.load_state_dict(vo.seeded_state(vo.model_spec("ResNet18", 64), 2))
         solver.queue_model.queue_network.load_state_dict(vo.seeded_state(vo.model_spec("ResNet18", 64), 2))
@@ -450,6 +450,7 @@ def test_bucketed_allreduce_machinery_single_rank():
     try:
         l0, p0, r0 = run(False)
         l1, p1, r1 = run(True)
+        l2, p2, _ = run(True, shuffle_bn=True)
     finally:
         os.environ.pop("VINCE_FORCE_DP", None)
         dist.destroy_process_group()
@@ -458,6 +459,10 @@ def test_bucketed_allreduce_machinery_single_rank():
     # encoder amplifies that chaotically from the third step on)
     np.testing.assert_allclose(l1, l0, rtol=1e-4, atol=1e-7)
     assert rel(p1.cpu(), p0.cpu()) < 2e-3
+    # cross-rank shuffle-BN (dp_shuffle_bn): on one rank the key batch is only re-ordered, so the key BatchNorm statistics,
+    # the un-permuted keys and hence the losses are unchanged up to summation order
+    np.testing.assert_allclose(l2, l0, rtol=1e-3, atol=1e-6)
+    assert rel(p2.cpu(), p0.cpu()) < 5e-3
 
 
 def test_cpu_model_forward_raises():

@@ -56,6 +56,7 @@ class VinceSolver(BaseSolver):
         self.kill_thread = False
         self.drawn_this_epoch = False
         self.reducer = None
+        self._dp_step = 0
         self._key_stream = None
         self.overlap_key_encoder = bool(int(os.environ.get("VINCE_OVERLAP_KEY", "1")))
         super(VinceSolver, self).__init__(args, train_logger, val_logger)
@@ -193,6 +194,28 @@ class VinceSolver(BaseSolver):
             batches = self._next_batches()
         return batches
 
+    # ------------------------------------------------------------------------------------------ cross-rank shuffle-BN
+    def _encode_keys(self, image_batch_concat, jig_key):
+        """Key-encoder forward.  With `args.dp_shuffle_bn` (data parallel only) the key IMAGES are permuted across ranks
+        first, so the batch each rank's key BatchNorms see is a random mix of the global batch -- MoCo's shuffle-BN, which
+        the reference gets from permuting before the DataParallel scatter (vince_model.py:137-142).  Every rank then
+        all-gathers the keys, undoes the permutation and keeps the rows of its own queries; the full natural-order block is
+        reused for the enqueue.  Off by default: it costs an all_to_all of the key images per step."""
+        w, r = dp.world()
+        shuffle_dp = (getattr(self.args, "dp_shuffle_bn", False) and self.reducer is not None and not jig_key
+                      and len(image_batch_concat["batch_sizes"]) == 1)
+        if not shuffle_dp:
+            return self.queue_model(image_batch_concat, jigsaw=jig_key, shuffle=True), None
+        B = image_batch_concat["queue_data"].shape[0]
+        perm = dp.global_permutation(w * B, step=self._dp_step, seed=17)
+        self._dp_step += 1
+        mixed = dict(image_batch_concat)
+        mixed["queue_data"] = dp.exchange_rows(image_batch_concat["queue_data"], perm)
+        out = self.queue_model(mixed, jigsaw=False, shuffle=True)
+        natural = dp.unpermute_gathered(dp.gather_keys(out[0]["queue_embeddings"]), perm)
+        mine = {"queue_embeddings": natural[r * B:(r + 1) * B].contiguous()}
+        return [mine], natural
+
     # ------------------------------------------------------------------------------------------ the hot loop
     def run_train_iteration(self):
         total_t_start = time.time()
@@ -217,15 +240,17 @@ class VinceSolver(BaseSolver):
                 self._key_stream = torch.cuda.Stream()
             self._key_stream.wait_stream(main)
             with torch.cuda.stream(self._key_stream):
-                queue_batches = self.queue_model(image_batch_concat, jigsaw=jig_key, shuffle=True)
+                queue_batches, gathered_keys = self._encode_keys(image_batch_concat, jig_key)
             outputs = self.model.get_embeddings(image_batch_concat, jigsaw=jig_query, shuffle=True)
             main.wait_stream(self._key_stream)
             for qb in queue_batches:      # produced on the side stream, consumed (and later freed) on the main one
                 for v in qb.values():
                     if isinstance(v, torch.Tensor):
                         v.record_stream(main)
+            if gathered_keys is not None:
+                gathered_keys.record_stream(main)
         else:
-            queue_batches = self.queue_model(image_batch_concat, jigsaw=jig_key, shuffle=True)
+            queue_batches, gathered_keys = self._encode_keys(image_batch_concat, jig_key)
             outputs = self.model.get_embeddings(image_batch_concat, jigsaw=jig_query, shuffle=True)
 
         t_end = time.time()
@@ -269,7 +294,7 @@ class VinceSolver(BaseSolver):
         for image_batch, output in zip(image_batches, outputs):
             # update queue (after the optimizer step, before the EMA, vince_solver.py:497-499); with several ranks
             # every rank enqueues the same world*B block in rank order
-            keys = dp.gather_keys(output["queue_embeddings"])
+            keys = gathered_keys if gathered_keys is not None else dp.gather_keys(output["queue_embeddings"])
             self.vince_queue.enqueue(keys, image_batch.get("queue_data_cpu"), image_batch["data_source"])
         self.queue_model.vince_update(self.model)
 
