@@ -341,7 +341,11 @@ class VinceModel(BaseModel):
                           train_bn=self.training, jigsaw_src=(h, w) if jigsaw else None)
             if self.training:
                 self._bn_version += 1   # running statistics moved
-        spatial = trunk.spatial_view(ws).clone()
+        # `spatial_features` is a copy by default: the workspace it lives in is rewritten by the next forward.  A caller that
+        # never reads it past that point (the training loop) sets clone_spatial = False and gets the zero-copy view.
+        spatial = trunk.spatial_view(ws)
+        if getattr(self, "clone_spatial", True):
+            spatial = spatial.clone()
         pre = emb = None
         saved = dict(trunk=trunk, pooled=pooled, jigsaw=jigsaw)
         if with_head:

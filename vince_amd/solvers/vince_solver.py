@@ -111,6 +111,9 @@ class VinceSolver(BaseSolver):
             torch.distributed.broadcast(self.model._flat, src=0)
             self.model._touch()
         self.queue_model = VinceQueueModel(args, self.model)
+        # the training loop never reads spatial_features after the next forward: skip the per-forward copy (51 MB at R50/B=256)
+        self.model.clone_spatial = False
+        self.queue_model.queue_network.clone_spatial = False
         self.queue_model.to(device)
         self.vince_queue = StorageQueue(args.vince_queue_size, args.vince_embedding_size, device=device,
                                         keep_images=getattr(args, "keep_queue_images", False))
