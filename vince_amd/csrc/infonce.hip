@@ -180,44 +180,64 @@ __global__ __launch_bounds__(256) void infonce_fwd_partial(const InfoParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void infonce_merge(const InfoParams p, int P, float* row_max, float* neg_sum,
-                                                     float* dists, float* sweights, float* scalars) {
-    __shared__ float red[5][256];
+// One workgroup of 1024 threads: 4 lanes share a row and split its P partial (max, sum) pairs, so the dependent chain per
+// lane is P/4 long (P = 130 at B = 256, K = 65536).
+constexpr int MERGE_THREADS = 1024, MERGE_LPR = 4;   // lanes per row
+__global__ __launch_bounds__(MERGE_THREADS) void infonce_merge(const InfoParams p, int P, float* row_max, float* neg_sum,
+                                                               float* dists, float* sweights, float* scalars) {
+    __shared__ float red[5][MERGE_THREADS / MERGE_LPR];
     const int B = p.d.B, F = p.d.frames;
     const float invT = p.d.inv_temperature;
+    const int sub = threadIdx.x % MERGE_LPR, slot = threadIdx.x / MERGE_LPR;
+    constexpr int ROWS_PER_PASS = MERGE_THREADS / MERGE_LPR;
     float a_loss = 0.f, a_sw = 0.f, a_acc = 0.f, a_pos = 0.f, a_nm = 0.f;
-    for (int row = threadIdx.x; row < B; row += 256) {
+    for (int row0 = 0; row0 < B; row0 += ROWS_PER_PASS) {
+        const int row = row0 + slot;
+        const bool live = row < B;
         float M = NEG_BIG, nmx = NEG_BIG;
-        for (int j = 0; j < P; ++j) {
-            M = fmaxf(M, p.part[((size_t)0 * P + j) * B + row]);
-            nmx = fmaxf(nmx, p.part[((size_t)2 * P + j) * B + row]);
+        if (live)
+            for (int j = sub; j < P; j += MERGE_LPR) {
+                M = fmaxf(M, p.part[((size_t)0 * P + j) * B + row]);
+                nmx = fmaxf(nmx, p.part[((size_t)2 * P + j) * B + row]);
+            }
+#pragma unroll
+        for (int o = 1; o < MERGE_LPR; o <<= 1) {
+            M = fmaxf(M, __shfl_xor(M, o, 64));
+            nmx = fmaxf(nmx, __shfl_xor(nmx, o, 64));
         }
-        for (int f = 0; f < F; ++f) M = fmaxf(M, p.pos[(size_t)row * F + f] * invT);   // row max over ALL columns
+        if (live)
+            for (int f = 0; f < F; ++f) M = fmaxf(M, p.pos[(size_t)row * F + f] * invT);   // row max over ALL columns
         float S = 0.f;
-        for (int j = 0; j < P; ++j)
-            S += p.part[((size_t)1 * P + j) * B + row] * __expf(p.part[((size_t)0 * P + j) * B + row] - M);
-        row_max[row] = M;
-        neg_sum[row] = S;
-        for (int f = 0; f < F; ++f) {
-            const float raw = p.pos[(size_t)row * F + f];
-            const float sp = raw * invT - M;
-            const float ls = sp - logf(expf(sp) + S);
-            dists[(size_t)row * F + f] = -ls;
-            const float sw = expf(ls);
-            sweights[(size_t)row * F + f] = sw;
-            a_loss += -ls;
-            a_sw += sw;
-            a_acc += raw > nmx ? 1.f : 0.f;
-            a_pos += raw;
+        if (live)
+            for (int j = sub; j < P; j += MERGE_LPR)
+                S += p.part[((size_t)1 * P + j) * B + row] * __expf(p.part[((size_t)0 * P + j) * B + row] - M);
+#pragma unroll
+        for (int o = 1; o < MERGE_LPR; o <<= 1) S += __shfl_xor(S, o, 64);
+        if (live && sub == 0) {
+            row_max[row] = M;
+            neg_sum[row] = S;
+            for (int f = 0; f < F; ++f) {
+                const float raw = p.pos[(size_t)row * F + f];
+                const float sp = raw * invT - M;
+                const float ls = sp - logf(expf(sp) + S);
+                dists[(size_t)row * F + f] = -ls;
+                const float sw = expf(ls);
+                sweights[(size_t)row * F + f] = sw;
+                a_loss += -ls;
+                a_sw += sw;
+                a_acc += raw > nmx ? 1.f : 0.f;
+                a_pos += raw;
+            }
+            a_nm += nmx;
         }
-        a_nm += nmx;
     }
-    red[0][threadIdx.x] = a_loss; red[1][threadIdx.x] = a_sw; red[2][threadIdx.x] = a_acc;
-    red[3][threadIdx.x] = a_pos; red[4][threadIdx.x] = a_nm;
+    if (sub == 0) {
+        red[0][slot] = a_loss; red[1][slot] = a_sw; red[2][slot] = a_acc; red[3][slot] = a_pos; red[4][slot] = a_nm;
+    }
     __syncthreads();
     if (threadIdx.x < 5) {
         double t = 0;
-        for (int i = 0; i < 256; ++i) t += red[threadIdx.x][i];
+        for (int i = 0; i < ROWS_PER_PASS; ++i) t += red[threadIdx.x][i];
         const double denom = threadIdx.x == 4 ? (double)B : (double)B * F;
         scalars[threadIdx.x] = (float)(t / denom);
     }
@@ -446,7 +466,7 @@ extern "C" int vince_infonce_fwd(const vince_infonce_desc* d, const float* q, co
     if (d->D == 64) hipLaunchKernelGGL(infonce_fwd_partial<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(infonce_fwd_partial<128>, grid, dim3(256), 0, (hipStream_t)stream, p);
     VINCE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(infonce_merge, dim3(1), dim3(256), 0, (hipStream_t)stream, p, P, row_max, neg_sum, dists,
+    hipLaunchKernelGGL(infonce_merge, dim3(1), dim3(MERGE_THREADS), 0, (hipStream_t)stream, p, P, row_max, neg_sum, dists,
                        softmax_weights, scalars);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;

@@ -236,13 +236,22 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
         dx[i] = act[i] > 0.f ? dout[i] : 0.f;
 }
 
+// out[c] += sum over rows of x[r][c] (bias gradients of the projection MLP: 256 x 2048).  64 columns x 4 row lanes per
+// workgroup, grid.y row chunks; partial sums meet in `out` through fp32 atomics.
+constexpr int COLSUM_CHUNKS = 8;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
                                                      int cols) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int per = (rows + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[(size_t)r * cols + c];
-    out[c] += s;
+    if (c < cols)
+        for (int r = r0 + ty; r < r1; r += 4) s += x[(size_t)r * cols + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < cols) unsafeAtomicAdd(out + c, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ k, const float* __restrict__ q, int64_t n, float m,
@@ -399,7 +408,7 @@ extern "C" int vince_relu_bwd(const float* dout, const float* act, float* dx, in
 
 extern "C" int vince_colsum(const float* x, float* out, int32_t rows, int32_t cols, void* stream) {
     VINCE_CHECK_ARG(x && out && rows > 0 && cols > 0, VINCE_E_ARG, "vince_colsum: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, rows, cols);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, COLSUM_CHUNKS), dim3(256), 0, (hipStream_t)stream, x, out, rows, cols);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
