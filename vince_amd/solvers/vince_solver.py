@@ -273,8 +273,13 @@ class VinceSolver(BaseSolver):
             loss_list.append({key: val[0] * val[1] for key, val in loss_dict.items()})
             metrics_list.append(metrics)
 
-        loss_dict = {k: v.mean() for k, v in stack_dicts_in_list(loss_list).items()}
-        metrics = {k: v.mean() for k, v in stack_dicts_in_list(metrics_list).items()}
+        if len(loss_list) == 1:
+            # one batch type (the usual case): the mean over a stack of one is the value itself -- skip the ~10 tiny
+            # stack / mean launches that would sit between the loss and the backward pass
+            loss_dict, metrics = loss_list[0], metrics_list[0]
+        else:
+            loss_dict = {k: v.mean() for k, v in stack_dicts_in_list(loss_list).items()}
+            metrics = {k: v.mean() for k, v in stack_dicts_in_list(metrics_list).items()}
 
         updated_loss_meters = set()
         total_loss = 0
