@@ -39,7 +39,7 @@ TRUNK_GFLOP_PER_FRAME = {"ResNet50": 8.1743, "ResNet18": 3.6271}      # conv MAC
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}                          # MI355X_MICROARCH.md dense MFMA peaks
 # one tag per kernel symbol (as rocprofv3 lists them): conv_igemm_dlds_kernel<T, CT, 4, STAGES, MINW, PTL, BWD>
 KERNEL_TAGS = ["conv_igemm<%s,%s,%s>" % (t, shape, e) for t in ("f32", "bf16")
-               for shape in ("64ch x 128px", "128ch x 128px", "128ch x 256px") for e in ("fwd", "bwd")] + \
+               for shape in ("64ch x 128px", "64ch x 256px", "128ch x 128px", "128ch x 256px") for e in ("fwd", "bwd")] + \
               ["conv_wgrad<f32>", "conv_wgrad<bf16>"]
 
 

@@ -12,7 +12,7 @@ for r in rows:
     a[0] += 1
     a[1] += float(r["us"])
     a[2] += float(r["tflops"]) * float(r["us"])
-names = ["ig %s/%s%s" % (t, sh, e) for t in ("f32", "bf16") for sh in ("64", "128", "128x256") for e in ("", " bwd")] + ["wg f32", "wg bf16"]
+names = ["ig %s/%s%s" % (t, sh, e) for t in ("f32", "bf16") for sh in ("64", "64x256", "128", "128x256") for e in ("", " bwd")] + ["wg f32", "wg bf16"]
 print("%-20s %9s %6s %6s %4s %4s %3s %6s %9s %8s %8s" % ("kernel", "M", "Co", "K", "taps", "s/os", "fl", "n/step", "us/launch", "ms/step", "TF/s"))
 tot = 0
 for k, (n, us, w) in sorted(agg.items(), key=lambda kv: -kv[1][1]):

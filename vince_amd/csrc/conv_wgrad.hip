@@ -537,7 +537,7 @@ extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void
     void* tok = nullptr;
     if (vince_profile_enabled())
     {
-        vince_profile_begin_launch(dtype == VINCE_F32 ? 12 : 13, 2.0 * p.M * d.Co * T * (double)Ci_dw * (d.Cs > 0 ? d.Kw : 1), stream, &tok);
+        vince_profile_begin_launch(dtype == VINCE_F32 ? 16 : 17, 2.0 * p.M * d.Co * T * (double)Ci_dw * (d.Cs > 0 ? d.Kw : 1), stream, &tok);
         vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh, 0);
     }
     const int rc = dtype == VINCE_F32 ? dispatch<float>(p, s) : dispatch<bf16_t>(p, s);
