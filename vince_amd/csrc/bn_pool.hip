@@ -7,6 +7,7 @@
 // walks pixel rows, so a wavefront always touches whole contiguous row segments and the per-channel constants
 // (scale/shift/mean/invstd) live in registers for the whole walk.  Reductions go registers -> LDS -> one fp64
 // atomic per channel per workgroup.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -628,6 +629,12 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     }
 }
 
+// workgroups per element-wise BatchNorm launch (VINCE_BN_BLOCKS: measurement knob)
+inline int bn_target_blocks() {
+    static const int n = getenv("VINCE_BN_BLOCKS") ? atoi(getenv("VINCE_BN_BLOCKS")) : 2048;   // swept 1024..16384: 1536-2048 best
+    return n;
+}
+
 inline int grid_for(int64_t total_threads) {
     int64_t b = (total_threads + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
@@ -660,7 +667,7 @@ extern "C" int vince_bn_apply(int dtype, const void* y, const float* scale, cons
     DTYPE_OK("vince_bn_apply");
     VINCE_CHECK_ARG(y && scale && shift && out && rows > 0, VINCE_E_ARG, "vince_bn_apply: bad arguments");
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
-    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 4096);
+    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_target_blocks());
     dim3 grid(w.colgroups, w.rowblocks);
     vince_bn_train fin;
     memset(&fin, 0, sizeof(fin));
@@ -685,7 +692,7 @@ extern "C" int vince_bn_train_apply(int dtype, const void* y, const vince_bn_tra
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_train_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
     vince_bn_train fin = *bt;
     if (fin.replicas <= 0 || fin.replicas > VINCE_STATS_REPLICAS) fin.replicas = VINCE_STATS_REPLICAS;
-    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 4096);
+    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_target_blocks());
     dim3 grid(w.colgroups, w.rowblocks);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, nullptr, nullptr,
@@ -729,7 +736,7 @@ extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_sr
     VINCE_CHECK_ARG(dz && y && mean && invstd && gamma && sums && dy && rows > 0 && count > 0, VINCE_E_ARG,
                     "vince_bn_bwd_apply: bad arguments");
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_bwd_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
-    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 4096);
+    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_target_blocks());
     dim3 grid(w.colgroups, w.rowblocks);
     const double inv_count = 1.0 / (double)count;
     if (dtype == VINCE_F32)
