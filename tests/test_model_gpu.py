@@ -465,6 +465,25 @@ def test_bucketed_allreduce_machinery_single_rank():
     assert rel(p2.cpu(), p0.cpu()) < 5e-3
 
 
+def test_two_ranks_on_one_gpu_stay_identical():
+    """The multi-rank path on GPU hardware: two data-parallel ranks of the full solver share this one GPU through the
+    gloo backend (NCCL refuses two ranks per device) -- parameter / queue broadcast, bucketed gradient all-reduce behind
+    the engine's bucket events, key all-gather, replicated enqueue; the script asserts that both replicas end with
+    bit-identical parameters and queues (tools/dp2_one_gpu.py)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "dp2_one_gpu.py")]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
 def test_cpu_model_forward_raises():
     from vince_amd.config import make_args
     from vince_amd.models.vince_model import VinceModel
