@@ -98,10 +98,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # VINCE_BENCH_ONE_GPU=1 (debug aid): run all ranks on device 0 through gloo to exercise the multi-rank path of this
+    # script on a single-GPU box (NCCL refuses two ranks per device)
+    one_gpu = os.environ.get("VINCE_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if one_gpu else "nccl")
     assert world == opt.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (opt.gpus, world)
     device = torch.device("cuda", local)
 

@@ -312,7 +312,7 @@ class VinceSolver(BaseSolver):
         if self.logger_iteration % self.args.log_frequency == 0:
             # the only host synchronisation of the step: scalar read-back for the meters (the reference's
             # assert torch.isfinite(loss), vince_solver.py:446, synchronises every step)
-            vals = {k: float(v) for k, v in loss_dict.items()}
+            vals = {k: float(v.detach()) for k, v in loss_dict.items()}
             total = sum(vals.values())
             if not (total == total and abs(total) != float("inf")):
                 raise AssertionError("non-finite loss %r" % vals)
