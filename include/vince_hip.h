@@ -178,13 +178,24 @@ int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_src, const u
                         const float* mask_shift, const void* y, const float* mean, const float* invstd, double* sums,
                         int64_t rows, int32_t C, int32_t replicas, void* stream);
 
+/* Optional second reduction of vince_bn_bwd_apply: another BatchNorm that consumes the SAME masked gradient g (the
+ * downsample branch next to a block's last BatchNorm, resnet.py:128-133) gets its (sum g, sum g*xhat2) accumulated in the
+ * same pass, xhat2 = (y - mean)*invstd with that BatchNorm's own input and statistics. */
+typedef struct vince_bn_reduce2 {
+    const void* y;        /* NULL = off */
+    const float* mean;
+    const float* invstd;
+    double* sums;         /* double[R][C][2], zeroed by the caller */
+    int32_t replicas;     /* copies to spread the atomics over; 0 = VINCE_STATS_REPLICAS */
+} vince_bn_reduce2;
+
 /* Backward pass 2: dy = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count); optional g_out = g (the
  * residual branch's gradient); dgamma += sum_gx, dbeta += sum_g (float[C]).  The first `replicas` copies of `sums`
  * (0 = all) are folded by every workgroup for its own channels; no separate fold launch. */
 int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_src, const uint8_t* mask_bits, const float* mask_scale,
                        const float* mask_shift, const void* y, const float* mean, const float* invstd, const float* gamma,
                        const double* sums, int64_t count, void* dy, void* g_out, float* dgamma, float* dbeta, int64_t rows,
-                       int32_t C, int32_t replicas, void* stream);
+                       int32_t C, int32_t replicas, const vince_bn_reduce2* second, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pooling (K6 MaxPool2d 3x3/s2/p1 resnet.py:173, fused with the stem's BN-apply + ReLU; K7 AdaptiveAvgPool2d

@@ -62,7 +62,7 @@ PROTOTYPES = {
                                     c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "vince_bn_bwd_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
-                                   c_int32, c_void_p]),
+                                   c_int32, c_void_p, c_void_p]),
     "vince_stem_pool_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
     "vince_stem_pool_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma,
                                                            const double* __restrict__ sums, double inv_count,
                                                            T* __restrict__ dy, T* __restrict__ gout, float* dgamma,
-                                                           float* dbeta, int64_t rows, int C, RowWalk w, int replicas) {
+                                                           float* dbeta, int64_t rows, int C, RowWalk w, int replicas,
+                                                           const vince_bn_reduce2 r2) {
     constexpr int CH = Elem<T>::CH;
     // The replica fold of (sum g, sum g*xhat) is done here, per workgroup for ITS channels, instead of a separate launch
     // per BatchNorm; row-block 0 adds dgamma / dbeta.
@@ -328,47 +329,84 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         __syncthreads();
     }
     const int col = blockIdx.x * w.tpc + (threadIdx.x % w.tpc);
-    if (col >= w.cpr) return;
+    const bool cv = col < w.cpr;
+    const T* __restrict__ y2 = (const T*)r2.y;
+    if (!cv && !y2) return;
     float mu[CH], is[CH], k1[CH], ma[CH], mb[CH], msc[CH], msh[CH];
+    // second reduction (r2): the downsample BatchNorm of the same block consumes the SAME masked gradient g -- its
+    // (sum g, sum g*xhat) is accumulated here, on the g this pass has in registers, instead of a separate pass over dz
+    float mu2[CH], is2[CH], sg2[CH], sgx2[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
         const int c = col * CH + e, cl = (threadIdx.x % w.tpc) * CH + e;
-        msc[e] = msk.scale ? msk.scale[c] : 0.f;
-        msh[e] = msk.scale ? msk.shift[c] : 0.f;
-        mu[e] = mean[c];
-        is[e] = invstd[c];
-        k1[e] = gamma[c] * is[e];
+        msc[e] = (cv && msk.scale) ? msk.scale[c] : 0.f;
+        msh[e] = (cv && msk.scale) ? msk.shift[c] : 0.f;
+        mu[e] = cv ? mean[c] : 0.f;
+        is[e] = cv ? invstd[c] : 0.f;
+        k1[e] = cv ? gamma[c] * is[e] : 0.f;
         ma[e] = fold[0][cl];
         mb[e] = fold[1][cl];
+        mu2[e] = (cv && y2) ? r2.mean[c] : 0.f;
+        is2[e] = (cv && y2) ? r2.invstd[c] : 0.f;
+        sg2[e] = sgx2[e] = 0.f;
     }
     const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + threadIdx.x / w.tpc;
     const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
     constexpr int U = 4;
-    for (int64_t rb = r0; rb < r1; rb += (int64_t)U * w.rpp) {
-        uint4 dv[U], yv[U];
+    if (cv)
+        for (int64_t rb = r0; rb < r1; rb += (int64_t)U * w.rpp) {
+            uint4 dv[U], yv[U], y2v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t r = rb + (int64_t)u * w.rpp;
-            if (r < r1) {
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = rb + (int64_t)u * w.rpp;
+                if (r < r1) {
+                    const size_t off = (size_t)r * C + (size_t)col * CH;
+                    dv[u] = *(const uint4*)(dz + off);
+                    yv[u] = *(const uint4*)(y + off);
+                    if (y2) y2v[u] = *(const uint4*)(y2 + off);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = rb + (int64_t)u * w.rpp;
+                if (r >= r1) break;
                 const size_t off = (size_t)r * C + (size_t)col * CH;
-                dv[u] = *(const uint4*)(dz + off);
-                yv[u] = *(const uint4*)(y + off);
+                float g[CH], yy[CH];
+                Chunk<T>::unpack(dv[u], g);
+                Chunk<T>::unpack(yv[u], yy);
+                apply_mask<T, CH>(msk, off, (size_t)r * w.cpr + col, yy, msc, msh, g);
+                if (gout) *(uint4*)(gout + off) = Chunk<T>::pack(g);
+                float o[CH];
+#pragma unroll
+                for (int e = 0; e < CH; ++e) o[e] = k1[e] * (g[e] - ma[e] - (yy[e] - mu[e]) * is[e] * mb[e]);
+                *(uint4*)(dy + off) = Chunk<T>::pack(o);
+                if (y2) {
+                    float y2f[CH];
+                    Chunk<T>::unpack(y2v[u], y2f);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) {
+                        sg2[e] += g[e];
+                        sgx2[e] += g[e] * (y2f[e] - mu2[e]) * is2[e];
+                    }
+                }
             }
         }
+    if (y2) {   // uniform: registers -> LDS -> one fp64 atomic per channel per workgroup (as bn_bwd_reduce_kernel)
+        __shared__ float red2[256 * 2 * CH];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t r = rb + (int64_t)u * w.rpp;
-            if (r >= r1) break;
-            const size_t off = (size_t)r * C + (size_t)col * CH;
-            float g[CH], yy[CH];
-            Chunk<T>::unpack(dv[u], g);
-            Chunk<T>::unpack(yv[u], yy);
-            apply_mask<T, CH>(msk, off, (size_t)r * w.cpr + col, yy, msc, msh, g);
-            if (gout) *(uint4*)(gout + off) = Chunk<T>::pack(g);
-            float o[CH];
-#pragma unroll
-            for (int e = 0; e < CH; ++e) o[e] = k1[e] * (g[e] - ma[e] - (yy[e] - mu[e]) * is[e] * mb[e]);
-            *(uint4*)(dy + off) = Chunk<T>::pack(o);
+        for (int e = 0; e < CH; ++e) {
+            red2[threadIdx.x * 2 * CH + e] = sg2[e];
+            red2[threadIdx.x * 2 * CH + CH + e] = sgx2[e];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < w.tpc * 2 * CH; t += 256) {
+            const int c_ = t / (2 * CH), slot = t % (2 * CH);
+            const int gcol = blockIdx.x * w.tpc + c_;
+            if (gcol >= w.cpr) continue;
+            float s_ = 0.f;
+            for (int rr = 0; rr < w.rpp; ++rr) s_ += red2[(rr * w.tpc + c_) * 2 * CH + slot];
+            const int ch = gcol * CH + (slot % CH), which = slot / CH;
+            unsafeAtomicAdd(r2.sums + ((size_t)(blockIdx.y % r2.replicas) * C + ch) * 2 + which, (double)s_);
         }
     }
 }
@@ -729,9 +767,17 @@ extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_sr
                                   const float* mask_scale, const float* mask_shift, const void* y, const float* mean,
                                   const float* invstd, const float* gamma, const double* sums, int64_t count, void* dy,
                                   void* g_out, float* dgamma, float* dbeta, int64_t rows, int32_t C, int32_t replicas,
-                                  void* stream) {
+                                  const vince_bn_reduce2* second, void* stream) {
     const MaskArgs msk{mask_src, mask_bits, mask_scale, mask_shift};
     DTYPE_OK("vince_bn_bwd_apply");
+    vince_bn_reduce2 r2;
+    memset(&r2, 0, sizeof(r2));
+    if (second) {
+        VINCE_CHECK_ARG(second->y && second->mean && second->invstd && second->sums, VINCE_E_ARG,
+                        "vince_bn_bwd_apply: second reduction needs y, mean, invstd and sums");
+        r2 = *second;
+        if (r2.replicas <= 0 || r2.replicas > VINCE_STATS_REPLICAS) r2.replicas = VINCE_STATS_REPLICAS;
+    }
     if (replicas <= 0 || replicas > VINCE_STATS_REPLICAS) replicas = VINCE_STATS_REPLICAS;
     VINCE_CHECK_ARG(dz && y && mean && invstd && gamma && sums && dy && rows > 0 && count > 0, VINCE_E_ARG,
                     "vince_bn_bwd_apply: bad arguments");
@@ -742,11 +788,11 @@ extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_sr
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
                            msk, (const float*)y, mean, invstd, gamma, sums, inv_count, (float*)dy,
-                           (float*)g_out, dgamma, dbeta, rows, C, w, replicas);
+                           (float*)g_out, dgamma, dbeta, rows, C, w, replicas, r2);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz,
                            msk, (const bf16_t*)y, mean, invstd, gamma, sums, inv_count, (bf16_t*)dy,
-                           (bf16_t*)g_out, dgamma, dbeta, rows, C, w, replicas);
+                           (bf16_t*)g_out, dgamma, dbeta, rows, C, w, replicas, r2);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

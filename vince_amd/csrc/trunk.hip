@@ -449,7 +449,7 @@ int wgrad(Ctx& c, const ConvL& cv, const void* in, const void* dy, float* dw) {
 // of y*scale+shift is recomputed from y, which is read anyway), or none (no ReLU: the stem's pooled gradient).
 // `reduced`: the (sum g, sum g*xhat) pass already ran inside the epilogue of the dgrad that produced dz (bn_reduce_of).
 int bn_bwd(Ctx& c, const BnL& bn, const void* dz, const uint8_t* bits, bool self_mask, size_t y_off, int64_t rows, void* dy,
-           void* g_out, float* const* grads, bool reduced = false) {
+           void* g_out, float* const* grads, bool reduced = false, const vince_bn_reduce2* second = nullptr) {
     const float* msc = self_mask ? c.consts(bn, 0) : nullptr;
     const float* msh = self_mask ? c.consts(bn, 1) : nullptr;
     if (!reduced)
@@ -457,7 +457,7 @@ int bn_bwd(Ctx& c, const BnL& bn, const void* dz, const uint8_t* bits, bool self
                                c.sums(bn), rows, bn.C, bn.R, c.stream));
     RC(vince_bn_bwd_apply(c.dtype, dz, nullptr, bits, msc, msh, at(c.ws, y_off), c.consts(bn, 2), c.consts(bn, 3),
                           c.params[bn.gamma], c.sums(bn), rows, dy, g_out, grads[bn.gamma], grads[bn.beta], rows, bn.C,
-                          bn.R, c.stream));
+                          bn.R, second, c.stream));
     return VINCE_OK;
 }
 
@@ -732,12 +732,26 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         const void* x_in = at(workspace, b.x_in);
         // z = relu(bn_L(y_L) + identity): g = dz * (z > 0) is the gradient of both addends
         if (b.has_ds) {
+            // bn_L's backward apply also accumulates the downsample BatchNorm's reduction (same g, its own y): one pass
+            // over dz instead of two.  Its dY keeps ring slot A for the main chain below; the downsample branch (apply,
+            // wgrad, dgrad -> DX) runs in the next slot first.  (VINCE_FUSE_DS_REDUCE=0: separate reduce pass)
+            static const bool fuse_ds = !(getenv("VINCE_FUSE_DS_REDUCE") && atoi(getenv("VINCE_FUSE_DS_REDUCE")) == 0);
+            vince_bn_reduce2 r2;
+            r2.y = at(workspace, b.yd);
+            r2.mean = c.consts(b.bd, 2);
+            r2.invstd = c.consts(b.bd, 3);
+            r2.sums = c.sums(b.bd);
+            r2.replicas = b.bd.R;
             RC(next_dy());
-            RC(bn_bwd(c, b.bd, Z, zbits, false, b.yd, rows_out, DY, nullptr, grads));
+            RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, nullptr, grads, last_reduced, fuse_ds ? &r2 : nullptr));
+            void* const dy_main = DY;
+            const int slot_main = slot;
+            RC(next_dy());
+            RC(bn_bwd(c, b.bd, Z, zbits, false, b.yd, rows_out, DY, nullptr, grads, fuse_ds));
             RC(wgrad_layer(b.cd, x_in));
             RC(dgrad(c, b.cd, DY, DX, false));
-            RC(next_dy());
-            RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, nullptr, grads, last_reduced));
+            DY = dy_main;
+            slot = slot_main;
         } else {
             // identity branch: g = dz * (z > 0) is never materialised -- the block-input dgrad below joins it in place
             RC(next_dy());

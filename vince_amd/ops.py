@@ -243,7 +243,8 @@ def bn_bwd_reduce(dz, y, mean, invstd, mask_src=None, mask_bits=None, mask_scale
 
 
 def bn_bwd(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, want_g=False, mask_bits=None, mask_scale=None,
-           mask_shift=None, replicas=0):
+           mask_shift=None, replicas=0, second=None):
+    """second: optional ctypes pointer to a vince_bn_reduce2 (another BatchNorm reduced over the same masked gradient)."""
     require_gpu(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, mask_bits, mask_scale, mask_shift)
     C = y.shape[-1]
     rows = y.numel() // C
@@ -255,7 +256,7 @@ def bn_bwd(dz, mask_src, y, mean, invstd, gamma, dgamma, dbeta, want_g=False, ma
     g = torch.empty_like(y) if want_g else None
     check(lib().vince_bn_bwd_apply(dtype_code(y), _ptr(dz), _ptr(mask_src), _ptr(mask_bits), _ptr(mask_scale),
                                    _ptr(mask_shift), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums), rows,
-                                   _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), rows, C, replicas, stream_ptr()))
+                                   _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), rows, C, replicas, second, stream_ptr()))
     return dy, g
 
 
