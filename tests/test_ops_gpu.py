@@ -209,14 +209,11 @@ def test_conv_dgrad_wgrad(cfg, dtype):
         assert_close(dw, ref_dw, dtype, f32=1e-4, what="wgrad variant %d" % variant)
 
 
-def test_conv_suite_through_the_256_pixel_tiles():
-    """The 256-pixel tile kernels (128ch x 256px for K >= 1024, 64ch x 256px for the stem / layer1) are only selected at
-    benchmark-sized pixel counts; their selection thresholds are read from the environment once per process, so the conv
-    parity tests of this file are re-run in a child process that forces both onto every shape."""
+def _rerun_conv_tests(extra_env):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, VINCE_BIG_MIN_K="1", VINCE_BIG_MIN_TILES="1", VINCE_NARROW256_MIN_TILES="1")
+    env = dict(os.environ, **extra_env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops_gpu.py"), "-q", "-m", "gpu",
                         "-k", "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem", "-p", "no:cacheprovider"],
@@ -224,6 +221,19 @@ def test_conv_suite_through_the_256_pixel_tiles():
     tail = r.stdout[-1500:] + r.stderr[-1500:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+def test_conv_suite_through_the_register_staged_fallback():
+    """Tensors beyond the 31-bit buffer offsets of the direct-to-LDS kernels (> 2 GiB) take the register-staged conv and
+    wgrad kernels; no test tensor is that large, so the same parity tests are re-run with those kernels forced."""
+    _rerun_conv_tests({"VINCE_DLDS_MIN_K": "1000000000", "VINCE_WGRAD_DLDS": "0"})
+
+
+def test_conv_suite_through_the_256_pixel_tiles():
+    """The 256-pixel tile kernels (128ch x 256px for K >= 1024, 64ch x 256px for the stem / layer1) are only selected at
+    benchmark-sized pixel counts; their selection thresholds are read from the environment once per process, so the conv
+    parity tests of this file are re-run in a child process that forces both onto every shape."""
+    _rerun_conv_tests({"VINCE_BIG_MIN_K": "1", "VINCE_BIG_MIN_TILES": "1", "VINCE_NARROW256_MIN_TILES": "1"})
 
 
 @pytest.mark.parametrize("rows,cin,cout", [(37, 512, 64), (256, 2048, 2048), (256, 2048, 128), (64, 1000, 96)])
