@@ -235,6 +235,15 @@ int vince_input_nchw_to_rows(int dtype, const float* in, const int64_t* perm, vo
                              int32_t H, int32_t W, int32_t Wp, int32_t left, void* stream);
 int vince_jigsaw_nchw_to_rows(int dtype, const float* in, void* out, int32_t N, int32_t C, int32_t H, int32_t W,
                               int32_t th, int32_t tw, int32_t Wp, int32_t left, void* stream);
+/* GPU input stage (the deterministic part of utils/transforms.py:62-235): uint8 HWC frames
+ * [N][Hs][Ws][3] -> the packed stem layout in ONE pass: per-image crop window (crop_yx int32[N][2] = top-left corner of the
+ * H x W window, NULL = (0,0)), horizontal flip (flip uint8[N], NULL = none), batch gather (perm, as above) and the
+ * ToTensor + Normalize arithmetic ((u8 - mean255[c]) / std255[c], constants.py:28-29; mean255 / std255 are HOST float[3])
+ * -- a quarter of the bytes of float frames across PCIe and no separate normalisation pass.  crop windows must lie
+ * inside the source frame (the caller's responsibility, not checked on the device). */
+int vince_input_u8hwc_to_rows(int dtype, const uint8_t* in, const int64_t* perm, const int32_t* crop_yx, const uint8_t* flip,
+                              const float* mean255, const float* std255, void* out, int32_t N, int32_t Hs, int32_t Ws,
+                              int32_t H, int32_t W, int32_t Wp, int32_t left, void* stream);
 /* fp32 master weights [Co][T][Ci] -> compute copy [Co][T][Cip] (dtype) and, if wt != NULL, the dgrad copy
  * [Ci][T][Co] (dtype). */
 int vince_prepare_weight(int dtype, const float* w, void* wk, void* wt, int32_t Co, int32_t T, int32_t Ci,
@@ -356,6 +365,10 @@ int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void*
                         int64_t* const* bn_nbt, const float* input, const int64_t* perm, int32_t jigsaw_src_h,
                         int32_t jigsaw_src_w, void* workspace, float* pooled, int32_t train_bn, void* stream);
 const void* vince_trunk_spatial_ptr(vince_trunk_t t, const void* workspace);
+/* Where the stem input lives inside `workspace` and its row layout ([N][H][row_width][4], image column w at w + left).
+ * A caller may stage it itself -- e.g. straight from uint8 frames with vince_input_u8hwc_to_rows -- and then call
+ * vince_trunk_forward / _forward_folded with input == NULL. */
+void* vince_trunk_input_ptr(vince_trunk_t t, void* workspace, int32_t* row_width, int32_t* left);
 
 /* Inference with the BatchNorms FOLDED into the convolutions (eval mode, running statistics; the end-task feature
  * extraction of end_task_base_solver.py:199-212 / vince_model.py:97-117 `extract_features`): no BatchNorm pass at all.

@@ -465,6 +465,47 @@ def test_bucketed_allreduce_machinery_single_rank():
     assert rel(p2.cpu(), p0.cpu()) < 5e-3
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_uint8_input_stage_equals_float_frames(dtype):
+    """SURVEY 8(f)-3, deterministic part: raw uint8 HWC frames with per-frame crop windows and flips through the fused input
+    stage (crop + flip + ToTensor/Normalize + stem layout in one kernel) give bit-identical trunk features in eval mode --
+    and embeddings / parameter gradients equal up to the atomics' summation order -- to feeding the float NCHW tensor those operations
+    produce (same arithmetic, same kernels downstream)."""
+    from vince_amd.models.vince_model import U8Frames
+    _, model = build("ResNet18", 64, dtype, 31)
+    g = torch.Generator().manual_seed(8)
+    n, hs, ws, h, w = 6, 80, 96, 64, 64
+    frames = torch.randint(0, 256, (n, hs, ws, 3), generator=g, dtype=torch.uint8).to(DEV)
+    crop = torch.stack([torch.randint(0, hs - h + 1, (n,), generator=g), torch.randint(0, ws - w + 1, (n,), generator=g)], 1).to(DEV)
+    flip = (torch.rand(n, generator=g) < 0.5).to(DEV)
+    u8 = U8Frames(frames, (h, w), crop, flip)
+    ref = u8.float_reference()
+    model.eval()
+    with torch.no_grad():
+        a = model.get_embeddings({"data": u8})
+        b = model.get_embeddings({"data": ref})
+    # the trunk is deterministic in eval mode: identical input layout -> bit-identical pooled features; the projection head's
+    # split-K GEMM accumulates with fp32 atomics, so embeddings agree to rounding only
+    # (fp32: torch's GPU division and the kernel's correctly rounded one may differ in the last bit of an input value)
+    if dtype == "bf16":
+        assert torch.equal(a["extracted_features"], b["extracted_features"])
+    assert rel(a["extracted_features"].cpu(), b["extracted_features"].cpu()) < 1e-5
+    assert rel(a["embeddings"].cpu(), b["embeddings"].cpu()) < 1e-5
+    # the staged values themselves against a CPU evaluation of (u8 - mean) / std
+    cpu_ref = U8Frames(frames.cpu(), (h, w), crop.cpu(), flip.cpu()).float_reference()
+    assert rel(ref.cpu(), cpu_ref) < 1e-6
+    model.train()
+    outs = []
+    for data in (u8, ref):
+        model.zero_grad()
+        e = model.get_embeddings({"data": data})["embeddings"]
+        (e * torch.linspace(-1, 1, e.numel(), device=DEV).view_as(e)).sum().backward()
+        outs.append((e.detach().clone(), model._flat_grad.clone()))
+    # train mode: BatchNorm statistics and weight gradients accumulate with atomics -> equal up to summation order
+    assert rel(outs[0][0].cpu(), outs[1][0].cpu()) < (1e-5 if dtype == "fp32" else 2e-2)
+    assert rel(outs[0][1].cpu(), outs[1][1].cpu()) < (1e-3 if dtype == "fp32" else 5e-2)
+
+
 def test_two_ranks_on_one_gpu_stay_identical():
     """The multi-rank path on GPU hardware: two data-parallel ranks of the full solver share this one GPU through the
     gloo backend (NCCL refuses two ranks per device) -- parameter / queue broadcast, bucketed gradient all-reduce behind

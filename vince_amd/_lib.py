@@ -80,6 +80,8 @@ PROTOTYPES = {
                                          c_int32, c_void_p]),
     "vince_jigsaw_nchw_to_rows": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_int32, c_void_p]),
+    "vince_input_u8hwc_to_rows": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, P(c_float), P(c_float), c_void_p,
+                                          c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "vince_prepare_weight": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "vince_prepare_weights_batched": (c_int, [c_int, c_void_p, c_int32, c_void_p]),
     "vince_nhwc_to_nchw_f32": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
@@ -111,6 +113,7 @@ PROTOTYPES = {
     "vince_trunk_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                     c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_trunk_spatial_ptr": (c_void_p, [c_void_p, c_void_p]),
+    "vince_trunk_input_ptr": (c_void_p, [c_void_p, c_void_p, P(c_int32), P(c_int32)]),
     "vince_trunk_prepare_weights_folded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vince_trunk_forward_folded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                            c_void_p]),

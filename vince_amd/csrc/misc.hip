@@ -102,6 +102,33 @@ __global__ __launch_bounds__(256) void jigsaw_to_rows_kernel(const float* __rest
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void input_u8_to_rows_kernel(const uint8_t* __restrict__ in, const int64_t* __restrict__ perm,
+                                                               const int32_t* __restrict__ crop, const uint8_t* __restrict__ flip,
+                                                               float m0, float m1, float m2, float s0, float s1, float s2,
+                                                               T* __restrict__ out, int N, int Hs, int Ws, int H, int W,
+                                                               int Wp, int left) {
+    const int64_t total = (int64_t)N * H * Wp;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int wp = (int)(idx % Wp);
+        const int64_t r = idx / Wp;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        const int w = wp - left;
+        float f[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w >= 0 && w < W) {
+            const int64_t sn = perm ? perm[n] : n;
+            const int cy = crop ? crop[2 * sn] : 0, cx = crop ? crop[2 * sn + 1] : 0;
+            const int sw_ = (flip && flip[sn]) ? (W - 1 - w) : w;    // RandomHorizontalFlip acts on the cropped window
+            const uint8_t* px = in + (((size_t)sn * Hs + (cy + h)) * Ws + (cx + sw_)) * 3;
+            f[0] = __fdiv_rn((float)px[0] - m0, s0);   // correctly rounded, like a CPU (x - mean) / std
+            f[1] = __fdiv_rn((float)px[1] - m1, s1);
+            f[2] = __fdiv_rn((float)px[2] - m2, s2);
+        }
+        store_px4<T>(out, (size_t)idx, f);
+    }
+}
+
 template <typename T> __device__ inline T cvt_from_f32(float f);
 template <> __device__ inline float cvt_from_f32<float>(float f) { return f; }
 template <> __device__ inline bf16_t cvt_from_f32<bf16_t>(float f) { return f32_to_bf16(f); }
@@ -520,6 +547,26 @@ __global__ void fill_f32_kernel(float* p, int n, float v) {
 
 int vince_fill_f32_async(float* ptr, int n, float value, void* stream) {
     hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ptr, n, value);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_input_u8hwc_to_rows(int dtype, const uint8_t* in, const int64_t* perm, const int32_t* crop_yx,
+                                         const uint8_t* flip, const float* mean255, const float* std255, void* out, int32_t N,
+                                         int32_t Hs, int32_t Ws, int32_t H, int32_t W, int32_t Wp, int32_t left, void* stream) {
+    DTYPE_OK("vince_input_u8hwc_to_rows");
+    VINCE_CHECK_ARG(in && out && mean255 && std255 && N > 0 && H > 0 && W > 0 && Hs >= H && Ws >= W && left >= 0 &&
+                    Wp >= W + left, VINCE_E_ARG, "vince_input_u8hwc_to_rows: bad arguments");
+    // (mean255 / std255 are HOST pointers: three floats each, passed by value to the kernel)
+    const int64_t total = (int64_t)N * H * Wp;
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(input_u8_to_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, perm,
+                           crop_yx, flip, mean255[0], mean255[1], mean255[2], std255[0], std255[1], std255[2], (float*)out, N,
+                           Hs, Ws, H, W, Wp, left);
+    else
+        hipLaunchKernelGGL(input_u8_to_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, perm,
+                           crop_yx, flip, mean255[0], mean255[1], mean255[2], std255[0], std255[1], std255[2], (bf16_t*)out, N,
+                           Hs, Ws, H, W, Wp, left);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

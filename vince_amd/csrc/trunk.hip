@@ -347,6 +347,13 @@ extern "C" int vince_trunk_bn_info(vince_trunk_t t, int32_t bn_index, char* name
     return VINCE_OK;
 }
 
+extern "C" void* vince_trunk_input_ptr(vince_trunk_t t, void* workspace, int32_t* row_width, int32_t* left) {
+    if (!t || !workspace) return nullptr;
+    if (row_width) *row_width = t->sWp;
+    if (left) *left = STEM_LEFT;
+    return (unsigned char*)workspace + t->off_x0;
+}
+
 extern "C" const void* vince_trunk_spatial_ptr(vince_trunk_t t, const void* workspace) {
     if (!t || !workspace) return nullptr;
     return (const unsigned char*)workspace + t->blocks.back().z;
@@ -556,13 +563,15 @@ extern "C" int vince_trunk_prepare_weights_folded(vince_trunk_t t, const float* 
 
 extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, const float* input, const int64_t* perm,
                                           int32_t jig_h, int32_t jig_w, void* workspace, float* pooled, void* stream) {
-    VINCE_CHECK_ARG(t && wcache && input && workspace && pooled, VINCE_E_ARG, "vince_trunk_forward_folded: null pointer");
+    VINCE_CHECK_ARG(t && wcache && workspace && pooled, VINCE_E_ARG, "vince_trunk_forward_folded: null pointer");
     VINCE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, VINCE_E_ALIGN,
                     "vince_trunk_forward_folded: workspace / weight cache must be 256-byte aligned");
     const int N = t->cfg.N, dtype = t->cfg.dtype;
     const float* bias = fold_bias(t, (void*)wcache);
     const float* ones = fold_ones(t, (void*)wcache);
-    if (!stem_packed()) {
+    if (!input) {   // staged input, see vince_trunk_forward
+        VINCE_CHECK_ARG(stem_packed(), VINCE_E_UNSUPPORTED, "vince_trunk_forward_folded: staged input needs the packed stem layout");
+    } else if (!stem_packed()) {
         if (jig_h > 0)
             RC(vince_jigsaw_nchw_to_nhwc(dtype, input, at(workspace, t->off_x0), N / 9, 3, jig_h, jig_w, t->cfg.H, t->cfg.W,
                                          t->Cp, stream));
@@ -615,7 +624,7 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
 extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void* wcache, float* const* bn_running,
                                    int64_t* const* bn_nbt, const float* input, const int64_t* perm, int32_t jig_h,
                                    int32_t jig_w, void* workspace, float* pooled, int32_t train_bn, void* stream) {
-    VINCE_CHECK_ARG(t && params && wcache && bn_running && input && workspace && pooled, VINCE_E_ARG,
+    VINCE_CHECK_ARG(t && params && wcache && bn_running && workspace && pooled, VINCE_E_ARG,
                     "vince_trunk_forward: null pointer");
     VINCE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, VINCE_E_ALIGN,
                     "vince_trunk_forward: workspace / weight cache must be 256-byte aligned");
@@ -623,7 +632,11 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     const int N = t->cfg.N;
     if (train_bn)
         RC(vince_zero_async(at(workspace, t->off_stats), t->n_stats_doubles * sizeof(double), stream));
-    if (!stem_packed()) {
+    if (!input) {
+        // staged input: the caller has already written the stem layout at vince_trunk_input_ptr() (e.g. straight from
+        // uint8 frames with vince_input_u8hwc_to_rows)
+        VINCE_CHECK_ARG(stem_packed(), VINCE_E_UNSUPPORTED, "vince_trunk_forward: staged input needs the packed stem layout");
+    } else if (!stem_packed()) {
         if (jig_h > 0)
             RC(vince_jigsaw_nchw_to_nhwc(c.dtype, input, at(workspace, t->off_x0), N / 9, 3, jig_h, jig_w, t->cfg.H, t->cfg.W,
                                          t->Cp, stream));

@@ -81,8 +81,26 @@ class Trunk:
         jh, jw = (0, 0) if jigsaw_src is None else jigsaw_src
         check(lib().vince_trunk_forward(
             self._h, param_ptrs, ctypes.c_void_p(wcache.data_ptr()), bn_running_ptrs, bn_nbt_ptrs,
-            ctypes.c_void_p(data.data_ptr()), None if perm is None else ctypes.c_void_p(perm.data_ptr()), jh, jw,
+            None if data is None else ctypes.c_void_p(data.data_ptr()),      # None: the input was staged (stage_u8)
+            None if perm is None else ctypes.c_void_p(perm.data_ptr()), jh, jw,
             ctypes.c_void_p(workspace.data_ptr()), ctypes.c_void_p(pooled.data_ptr()), int(train_bn), ops.stream_ptr()))
+
+    def stage_u8(self, workspace, frames_u8, crop_yx=None, flip=None, perm=None, mean255=None, std255=None):
+        """GPU input stage: uint8 HWC frames [N][Hs][Ws][3] -> the stem layout inside `workspace` (crop window, flip, batch
+        gather and (u8 - mean) / std in one pass).  Follow with forward(..., data=None)."""
+        ops.require_gpu(frames_u8, crop_yx, flip, perm)
+        n, hs, ws, c = frames_u8.shape
+        if frames_u8.dtype != torch.uint8 or c != 3 or n != self.N or not frames_u8.is_contiguous():
+            raise ValueError("stage_u8: expected contiguous uint8 [%d, Hs, Ws, 3] frames, got %s %s"
+                             % (self.N, frames_u8.dtype, tuple(frames_u8.shape)))
+        wp, left = ctypes.c_int32(), ctypes.c_int32()
+        x0 = lib().vince_trunk_input_ptr(self._h, ctypes.c_void_p(workspace.data_ptr()), ctypes.byref(wp), ctypes.byref(left))
+        mean = (ctypes.c_float * 3)(*[float(v) for v in mean255])
+        std = (ctypes.c_float * 3)(*[float(v) for v in std255])
+        code = VINCE_F32 if self.dtype == torch.float32 else VINCE_BF16
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())   # noqa: E731
+        check(lib().vince_input_u8hwc_to_rows(code, p(frames_u8), p(perm), p(crop_yx), p(flip), mean, std, ctypes.c_void_p(x0),
+                                              self.N, hs, ws, self.H, self.W, wp.value, left.value, ops.stream_ptr()))
 
     def prepare_weights_folded(self, param_ptrs, bn_running_ptrs, wcache):
         """BatchNorm-folded inference weights + biases into `wcache` (a cache separate from the training one)."""
@@ -93,7 +111,7 @@ class Trunk:
         """Eval-mode forward with folded BatchNorms: convolutions only, nothing kept for backward."""
         jh, jw = (0, 0) if jigsaw_src is None else jigsaw_src
         check(lib().vince_trunk_forward_folded(
-            self._h, ctypes.c_void_p(wcache.data_ptr()), ctypes.c_void_p(data.data_ptr()),
+            self._h, ctypes.c_void_p(wcache.data_ptr()), None if data is None else ctypes.c_void_p(data.data_ptr()),
             None if perm is None else ctypes.c_void_p(perm.data_ptr()), jh, jw, ctypes.c_void_p(workspace.data_ptr()),
             ctypes.c_void_p(pooled.data_ptr()), ops.stream_ptr()))
 

@@ -28,6 +28,46 @@ from ..engine import Trunk, nograd_workspace, pointer_table
 from ..utils import loss_util
 from .base_model import BaseModel
 
+class U8Frames:
+    """GPU input stage: raw uint8 HWC frames plus the deterministic augmentation parameters, accepted wherever
+    the reference API takes the float NCHW `data` tensor.  `frames`: uint8 [N, Hs, Ws, 3] on the GPU; `size`: (H, W) of the
+    network input; `crop_yx`: int32 [N, 2] top-left corner of each frame's H x W window (None: (0, 0)); `flip`: uint8 / bool
+    [N] horizontal flip of the window.  The crop, the flip and ToTensor + Normalize ((u8 - 255*mean) / (255*std),
+    constants.py:28-29) happen inside the layout kernel that feeds the stem -- no float copy of the frames ever exists."""
+
+    def __init__(self, frames, size, crop_yx=None, flip=None):
+        self.frames, self.size = frames, (int(size[0]), int(size[1]))
+        self.crop_yx = None if crop_yx is None else crop_yx.to(torch.int32).contiguous()
+        self.flip = None if flip is None else flip.to(torch.uint8).contiguous()
+
+    @property
+    def shape(self):   # what the float tensor would look like: batch-size logic upstream keeps working
+        return (self.frames.shape[0], 3) + self.size
+
+    @property
+    def device(self):
+        return self.frames.device
+
+    def to(self, device):
+        return U8Frames(self.frames.to(device), self.size, None if self.crop_yx is None else self.crop_yx.to(device),
+                        None if self.flip is None else self.flip.to(device))
+
+    def float_reference(self):
+        """The float NCHW tensor this stands for (tests / debugging): same arithmetic, torch ops."""
+        n = self.frames.shape[0]
+        h, w = self.size
+        out = torch.empty(n, 3, h, w, dtype=torch.float32, device=self.frames.device)
+        mean = torch.from_numpy(constants.IMAGENET_MEAN).to(self.frames.device).view(3, 1, 1)
+        std = torch.from_numpy(constants.IMAGENET_STD).to(self.frames.device).view(3, 1, 1)
+        for i in range(n):
+            cy, cx = (0, 0) if self.crop_yx is None else [int(v) for v in self.crop_yx[i]]
+            win = self.frames[i, cy:cy + h, cx:cx + w].permute(2, 0, 1).float()
+            if self.flip is not None and bool(self.flip[i]):
+                win = win.flip(-1)
+            out[i] = (win - mean) / std
+        return out
+
+
 # VINCE_FOLD_BN=0: eval-mode forwards keep the separate BatchNorm passes (cross-check aid)
 FOLD_BN = os.environ.get("VINCE_FOLD_BN", "1") != "0"
 
@@ -312,10 +352,17 @@ class VinceModel(BaseModel):
     def _encode(self, data, jigsaw, orders, with_head, save):
         """Returns (spatial, pooled, prenorm, embeddings).  data: float32 NCHW on the GPU."""
         self._require_gpu()
-        if data.dtype != torch.float32 or data.dim() != 4 or data.shape[1] != 3:
-            raise ValueError("VinceModel: expected float32 N x 3 x H x W frames, got %s %s" % (data.dtype, tuple(data.shape)))
-        data = data.to(self._flat.device).contiguous()
-        n, _, h, w = data.shape
+        u8 = data if isinstance(data, U8Frames) else None
+        if u8 is not None:
+            if jigsaw:
+                raise NotImplementedError("VinceModel: the uint8 input stage does not tile jigsaw inputs")
+            u8 = u8.to(self._flat.device)
+            n, (h, w) = u8.frames.shape[0], u8.size
+        else:
+            if data.dtype != torch.float32 or data.dim() != 4 or data.shape[1] != 3:
+                raise ValueError("VinceModel: expected float32 N x 3 x H x W frames, got %s %s" % (data.dtype, tuple(data.shape)))
+            data = data.to(self._flat.device).contiguous()
+            n, _, h, w = data.shape
         if jigsaw:
             hp, wp = (h + 3 - h % 3, w + 3 - w % 3) if (h % 3 or w % 3) else (h, w)   # vince_model.py:145-146
             trunk = self._trunk(n * 9, hp // 3, wp // 3)
@@ -332,6 +379,9 @@ class VinceModel(BaseModel):
             ws = nograd_workspace(self._flat.device, trunk.ws_bytes)
         nt = trunk.N
         pooled = torch.empty(nt, self.output_channels, device=self._flat.device, dtype=torch.float32)
+        if u8 is not None:   # GPU input stage: the stem layout is written straight from the uint8 frames
+            trunk.stage_u8(ws, u8.frames.contiguous(), u8.crop_yx, u8.flip, None, constants.IMAGENET_MEAN, constants.IMAGENET_STD)
+            data = None
         if not self.training and not save and FOLD_BN:
             # inference (extract_features for the end tasks, validation): BatchNorms folded into the convolutions
             self._ensure_folded_weights(trunk)
