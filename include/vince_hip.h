@@ -127,6 +127,8 @@ int vince_conv_igemm(const vince_conv_desc* d, int dtype, const void* in, const 
  *   dw[co, wt(a,b), ci] += sum_{n,ho,wo} dy[n,ho,wo,co] * in[n, ho*sh+dh0+a*dhs, wo*sw+dw0+b*dws, ci]
  * dw is float[Co][WT][Ci_dw] accumulated with fp32 atomics (zero it first); only ci < Ci_dw is written
  * (the stem pads Ci 3 -> 4/8).  dy is [N][Ho][Wo][Co] dense.  Also nn.Linear weight gradient (one tap).
+ * Packed row taps (d.Cs > 0): dw is float[Co][TA][Kw][Ci_dw] -- element k of tap a lands at (kw = k / Cs, c = k % Cs),
+ * the padding positions (kw >= Kw, c >= Ci_dw) are dropped -- i.e. the stem's ordinary [Co][7][7][3] gradient.
  * `variant`: 0 = default operand fetch (ds_read_b64_tr_b16 for bf16), 1 = scalar-gather fallback. */
 int vince_conv_wgrad(const vince_conv_desc* d, int dtype, const void* in, const void* dy, float* dw,
                      int32_t Ci_dw, int variant, void* stream);
