@@ -273,10 +273,18 @@ def test_three_steps_teacher_forced_vs_oracle(mode):
         for kk in ["nce_accuracy_mean", "cosine_sim", "cosine_sim_neg_max"]:
             np.testing.assert_allclose(float(met[kk]), r[kk], rtol=1e-3, atol=1e-5)
         assert queue.current_tail == r["tail"] and queue.full == r["full"]
-        # late-layer gradients are well conditioned; stem gradients only at iteration 0
-        for name in ["embedding.2.weight", "embedding.0.bias", "feature_extractor.model.layer4.1.conv2.weight",
-                     "feature_extractor.model.layer4.1.bn2.weight"]:
+        # Gradient conditioning (CPU oracle in fp32 vs fp64, same code): at iteration 0 the head and layer4 gradients agree to
+        # 6e-6 and the stem to 2e-3; from iteration 1 on -- the queue holds the encoder's own nearly collapsed keys -- the
+        # head still agrees to 2e-4 but layer4 differs by 0.24 and the stem by 0.09.  So: head every iteration, trunk
+        # gradients tightly at iteration 0 only, afterwards just a direction check.
+        for name in ["embedding.2.weight", "embedding.0.bias"]:
             assert rel(grads[name].cpu(), r["grads"][name]) < 5e-3, name
+        for name in ["feature_extractor.model.layer4.1.conv2.weight", "feature_extractor.model.layer4.1.bn2.weight"]:
+            got, want = grads[name].cpu().flatten().double(), r["grads"][name].flatten().double()
+            if it == 0:
+                assert rel(got, want) < 5e-3, name
+            else:
+                assert float(torch.nn.functional.cosine_similarity(got, want, dim=0)) > 0.9, name
         if it == 0:
             for name in ["feature_extractor.model.conv1.weight", "feature_extractor.model.bn1.weight",
                          "feature_extractor.model.layer2.0.downsample.0.weight"]:
