@@ -72,6 +72,10 @@ struct vince_trunk {
     hipStream_t side = nullptr;
     hipEvent_t ev_dy[3] = {nullptr, nullptr, nullptr}, ev_wg[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr;
     bool wg_pending[3] = {false, false, false};
+    // downsample-branch stream of the 4 stage-entry blocks (backward): its own dY buffer and events
+    hipStream_t ds_stream = nullptr;
+    hipEvent_t ev_ds_start = nullptr, ev_ds_dy = nullptr, ev_ds_wg = nullptr, ev_ds_done = nullptr;
+    size_t off_dyd = 0;
 };
 
 namespace {
@@ -299,6 +303,7 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     t->off_consts = P.ws; P.ws = align_up(P.ws + P.nf * sizeof(float));
     for (int i = 0; i < 3; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     for (int i = 0; i < 3; ++i) { t->off_dy[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
+    t->off_dyd = P.ws; P.ws = align_up(P.ws + t->max_act);
     t->ws_bytes = P.ws;
     t->off_prep_table = P.wc;
     t->off_fold = align_up(P.wc + 128 * sizeof(vince_prep_entry));
@@ -314,6 +319,11 @@ extern "C" void vince_trunk_destroy(vince_trunk_t t) {
         for (int i = 0; i < 3; ++i) { hipEventDestroy(t->ev_dy[i]); hipEventDestroy(t->ev_wg[i]); }
         hipEventDestroy(t->ev_join);
         hipStreamDestroy(t->side);
+    }
+    if (t->ds_stream) {
+        hipStreamSynchronize(t->ds_stream);
+        hipEventDestroy(t->ev_ds_start); hipEventDestroy(t->ev_ds_dy); hipEventDestroy(t->ev_ds_wg); hipEventDestroy(t->ev_ds_done);
+        hipStreamDestroy(t->ds_stream);
     }
     delete t;
 }
@@ -703,6 +713,18 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         }
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
     }
+    // the downsample branch of a stage-entry block only meets the main chain again at the block-input gradient: it runs on a
+    // third stream (VINCE_DS_STREAM=0: inline on the main stream)
+    static const bool ds_env = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0);
+    const bool ds_overlap = overlap && ds_env;
+    if (ds_overlap && !t->ds_stream) {
+        VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->ds_stream, hipStreamNonBlocking));
+        VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_start, hipEventDisableTiming));
+        VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_dy, hipEventDisableTiming));
+        VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_wg, hipEventDisableTiming));
+        VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_done, hipEventDisableTiming));
+    }
+    bool ds_wg_pending = false, ds_done_pending = false;
     for (int i = 0; i < 3; ++i) t->wg_pending[i] = false;
     int slot = 0;
     void* DY = nullptr;
@@ -757,14 +779,35 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             r2.replicas = b.bd.R;
             RC(next_dy());
             RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, nullptr, grads, last_reduced, fuse_ds ? &r2 : nullptr));
-            void* const dy_main = DY;
-            const int slot_main = slot;
-            RC(next_dy());
-            RC(bn_bwd(c, b.bd, Z, zbits, false, b.yd, rows_out, DY, nullptr, grads, fuse_ds));
-            RC(wgrad_layer(b.cd, x_in));
-            RC(dgrad(c, b.cd, DY, DX, false));
-            DY = dy_main;
-            slot = slot_main;
+            if (ds_overlap) {
+                void* DYD = at(workspace, t->off_dyd);
+                Ctx cd = c;
+                cd.stream = (void*)t->ds_stream;
+                VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_start, main_s));
+                VINCE_CHECK_HIP(hipStreamWaitEvent(t->ds_stream, t->ev_ds_start, 0));
+                if (ds_wg_pending) VINCE_CHECK_HIP(hipStreamWaitEvent(t->ds_stream, t->ev_ds_wg, 0));   // DYD still being read
+                RC(bn_bwd(cd, b.bd, Z, zbits, false, b.yd, rows_out, DYD, nullptr, grads, fuse_ds));
+                VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_dy, t->ds_stream));
+                VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_ds_dy, 0));
+                {
+                    const vince_conv_desc dd = fwd_desc(t, b.cd);
+                    RC(vince_conv_wgrad(&dd, c.dtype, x_in, DYD, grads[b.cd.param], b.cd.Ci, 0, (void*)t->side));
+                }
+                VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_wg, t->side));
+                ds_wg_pending = true;
+                RC(dgrad(cd, b.cd, DYD, DX, false));
+                VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_done, t->ds_stream));
+                ds_done_pending = true;
+            } else {
+                void* const dy_main = DY;
+                const int slot_main = slot;
+                RC(next_dy());
+                RC(bn_bwd(c, b.bd, Z, zbits, false, b.yd, rows_out, DY, nullptr, grads, fuse_ds));
+                RC(wgrad_layer(b.cd, x_in));
+                RC(dgrad(c, b.cd, DY, DX, false));
+                DY = dy_main;
+                slot = slot_main;
+            }
         } else {
             // identity branch: g = dz * (z > 0) is never materialised -- the block-input dgrad below joins it in place
             RC(next_dy());
@@ -791,6 +834,10 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                     const Blk& lo = t->blocks[bi - 1];
                     br = bn_reduce_of(c, lo.b[lo.nconv - 1], (const uint8_t*)at(workspace, lo.zmask), false, lo.y[lo.nconv - 1]);
                     rr = lo.b[lo.nconv - 1].R;
+                }
+                if (b.has_ds && ds_done_pending) {   // DX holds the downsample branch's gradient once its stream is done
+                    VINCE_CHECK_HIP(hipStreamWaitEvent(main_s, t->ev_ds_done, 0));
+                    ds_done_pending = false;
                 }
                 if (b.has_ds) RC(dgrad(c, b.c[0], DY, DX, true, nullptr, fuse ? &br : nullptr, rr));
                 else RC(dgrad(c, b.c[0], DY, Z, true, zbits, fuse ? &br : nullptr, rr));   // Z <- dgrad + Z * (z > 0)
