@@ -665,8 +665,28 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     RC(conv_bn_fwd(c, t->stem, t->stem_bn, t->off_x0, t->off_ystem, bn_running, bn_nbt, train_bn, true, &sd));
     RC(vince_stem_pool_fwd(c.dtype, at(workspace, t->off_ystem), c.consts(t->stem_bn, 0), c.consts(t->stem_bn, 1),
                            at(workspace, t->off_p0), (uint8_t*)at(workspace, t->off_amax), N, t->sH, t->sW, 64, stream));
+    // The downsample conv of a stage-entry block depends on the block input only: it (and its BatchNorm's finalize) runs
+    // on the engine's third stream next to conv1..convL and is joined before the block's last apply (VINCE_DS_STREAM=0 or
+    // profiling: inline).
+    static const bool ds_env_f = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0);
+    const bool ds_side = ds_env_f && !vince_profile_enabled();
+    if (ds_side && !t->ds_stream) {
+        VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->ds_stream, hipStreamNonBlocking));
+        VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_start, hipEventDisableTiming));
+        VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_dy, hipEventDisableTiming));
+        VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_wg, hipEventDisableTiming));
+        VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_done, hipEventDisableTiming));
+    }
     for (const Blk& b : t->blocks) {
         size_t in = b.x_in;
+        if (b.has_ds && ds_side) {
+            Ctx cd = c;
+            cd.stream = (void*)t->ds_stream;
+            VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_start, (hipStream_t)stream));
+            VINCE_CHECK_HIP(hipStreamWaitEvent(t->ds_stream, t->ev_ds_start, 0));
+            RC(conv_bn_fwd(cd, b.cd, b.bd, b.x_in, b.yd, bn_running, bn_nbt, train_bn, true));
+            VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_done, t->ds_stream));
+        }
         for (int ci = 0; ci < b.nconv; ++ci) {
             RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, false));
             if (ci < b.nconv - 1) {
@@ -678,7 +698,8 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
         const int L = b.nconv - 1;
         uint8_t* zmask = (uint8_t*)at(workspace, b.zmask);
         if (b.has_ds) {   // the downsample BatchNorm enters the join as an affine of its conv output: finalised on its own
-            RC(conv_bn_fwd(c, b.cd, b.bd, b.x_in, b.yd, bn_running, bn_nbt, train_bn, true));
+            if (ds_side) VINCE_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, t->ev_ds_done, 0));
+            else RC(conv_bn_fwd(c, b.cd, b.bd, b.x_in, b.yd, bn_running, bn_nbt, train_bn, true));
             RC(bn_apply_fwd(c, b.c[L], b.b[L], b.y[L], at(workspace, b.yd), c.consts(b.bd, 0), c.consts(b.bd, 1),
                             at(workspace, b.z), zmask, bn_running, bn_nbt, train_bn));
         } else {
