@@ -114,6 +114,12 @@ typedef struct vince_conv_epi {
                                * bits written by vince_bn_apply); bit e gates element e, so the residual join
                                * out = dgrad + out * (z > 0) (autograd of resnet.py:132-133) happens in place */
     vince_bn_reduce bnred;    /* excludes stats */
+    const float* in_scale;    /* optional operand transform: the INPUT tensor is read as relu(in * in_scale[ci] + in_shift[ci])
+                               * (float[Ci] each), applied to the staged tile in LDS -- zero padding stays zero.  This is
+                               * a BatchNorm-apply + ReLU fused into the consumer: the conv reads the producer's raw
+                               * output y and the activation tensor is never materialised (used by no-grad forwards).
+                               * Ci <= 512; direct-to-LDS kernels only */
+    const float* in_shift;
     int32_t replicas;         /* how many of the R replicas of `stats` / `bnred.sums` this launch spreads its atomics over
                                * (0 = all VINCE_STATS_REPLICAS); few workgroups need few replicas, and a consumer that
                                * folds them itself (vince_bn_train_apply, vince_bn_bwd_apply) then reads less */
@@ -360,12 +366,15 @@ int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* params, voi
 
 /* input: float NCHW (perm optional, see vince_input_nchw_to_nhwc) or, when input_is_tiles != 0, jigsaw source
  * (N/9 images [3][srcH][srcW]).  bn_buffers: per BN {running_mean, running_var} float pointers; nbt: int64 ptrs.
- * train_bn: batch statistics + running-stat update.
+ * train_bn: batch statistics + running-stat update.  save != 0: everything vince_trunk_backward reads stays in the
+ * workspace; save == 0 (no backward follows) lets the engine skip the bottleneck-internal activation tensors -- their
+ * BatchNorm + ReLU is applied inside the consuming conv (vince_conv_epi.in_scale).
  * Outputs: pooled float[N][C]; spatial (the trunk output, dtype NHWC) stays in the workspace:
  * vince_trunk_spatial_ptr(). */
 int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void* wcache, float* const* bn_running,
                         int64_t* const* bn_nbt, const float* input, const int64_t* perm, int32_t jigsaw_src_h,
-                        int32_t jigsaw_src_w, void* workspace, float* pooled, int32_t train_bn, void* stream);
+                        int32_t jigsaw_src_w, void* workspace, float* pooled, int32_t train_bn, int32_t save,
+                        void* stream);
 const void* vince_trunk_spatial_ptr(vince_trunk_t t, const void* workspace);
 /* Where the stem input lives inside `workspace` and its row layout ([N][H][row_width][4], image column w at w + left).
  * A caller may stage it itself -- e.g. straight from uint8 frames with vince_input_u8hwc_to_rows -- and then call

@@ -473,6 +473,26 @@ def test_bucketed_allreduce_machinery_single_rank():
     assert rel(p2.cpu(), p0.cpu()) < 5e-3
 
 
+@pytest.mark.parametrize("arch,embed", [("ResNet18", 64), ("ResNet50", 128)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_nograd_forward_fuses_bn_into_consumers(arch, embed, dtype, monkeypatch):
+    """With VINCE_XF=1 (opt-in: measured slower in the full step) a no-grad train-mode forward (the key encoder's) never materialises the bottleneck-internal activations: their
+    BatchNorm + ReLU runs inside the consuming conv's operand path.  It must reproduce the grad-enabled forward of the same
+    model (which keeps the separate apply passes for backward) -- same batch statistics, same rounding of the activations --
+    up to the summation order of the statistics' atomics."""
+    _, model = build(arch, embed, dtype, 13)
+    model.train()
+    x = vo.structured_frames(6, 96, 96, seed=91).to(DEV) + 0.3 * vo.gaussian_frames(6, 96, 96, 92).to(DEV)
+    monkeypatch.setenv("VINCE_XF", "1")
+    with torch.no_grad():
+        a = model.get_embeddings({"data": x})
+    monkeypatch.delenv("VINCE_XF")
+    b = model.get_embeddings({"data": x})
+    tol_ = 2e-5 if dtype == "fp32" else 2e-2
+    for k in ("extracted_features", "embeddings"):
+        assert rel(a[k].detach().cpu(), b[k].detach().cpu()) < tol_, (k, rel(a[k].detach().cpu(), b[k].detach().cpu()))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_uint8_input_stage_equals_float_frames(dtype):
     """SURVEY 8(f)-3, deterministic part: raw uint8 HWC frames with per-frame crop windows and flips through the fused input

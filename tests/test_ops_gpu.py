@@ -209,14 +209,42 @@ def test_conv_dgrad_wgrad(cfg, dtype):
         assert_close(dw, ref_dw, dtype, f32=1e-4, what="wgrad variant %d" % variant)
 
 
-def _rerun_conv_tests(extra_env):
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", CONVS + [(4, 20, 20, 128, 64, 3, 1, 1), (3, 12, 12, 512, 128, 1, 1, 0)])
+def test_conv_operand_transform(cfg, dtype):
+    """BatchNorm-apply + ReLU fused into the CONSUMER: conv(relu(x*scale + shift)) with the transform applied to the staged
+    tile in LDS must equal the conv of the materialised activation bit for bit (same rounding of the activation), including
+    zero padding of the ACTIVATION (not of x) at the borders and the fused output statistics."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, p = cfg
+    x = q(rnd(N, Ci, H, W, seed=51), dtype)
+    w = q(rnd(Co, Ci, k, k, seed=52, scale=(2.0 / (Ci * k * k)) ** 0.5), dtype)
+    scale, shift = (rnd(Ci, seed=53).abs() + 0.5), rnd(Ci, seed=54, scale=0.5)
+    wk, _ = weights_krsc(w, dtype)
+    d = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
+    xg = to_nhwc(x, dtype)
+    act = ops.bn_apply(xg, scale.to(DEV), shift.to(DEV), relu=True)                   # the materialised activation
+    want = torch.empty(N, d.Ho, d.Wo, Co, device=DEV, dtype=dtype)
+    st_want = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
+    ops.conv_igemm(d, act, wk, want, stats=st_want)
+    got = torch.empty_like(want)
+    st_got = torch.zeros_like(st_want)
+    ops.conv_igemm(d, xg, wk, got, stats=st_got, in_scale=scale.to(DEV), in_shift=shift.to(DEV))
+    assert torch.equal(got, want)
+    torch.testing.assert_close(st_got.sum(0), st_want.sum(0), rtol=1e-9, atol=1e-6)
+    # and against torch on the CPU
+    ref = F.conv2d(F.relu(x * scale[None, :, None, None] + shift[None, :, None, None]), w, None, s, p)
+    assert_close(from_nhwc(got), ref, dtype, bf16=3e-2, what="conv with operand transform")
+
+
+def _rerun_conv_tests(extra_env, select="test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem"):
     import os
     import subprocess
     import sys
     env = dict(os.environ, **extra_env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops_gpu.py"), "-q", "-m", "gpu",
-                        "-k", "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem", "-p", "no:cacheprovider"],
+                        "-k", select, "-p", "no:cacheprovider"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     tail = r.stdout[-1500:] + r.stderr[-1500:]
     assert r.returncode == 0, tail
@@ -233,7 +261,8 @@ def test_conv_suite_through_the_256_pixel_tiles():
     """The 256-pixel tile kernels (128ch x 256px for K >= 1024, 64ch x 256px for the stem / layer1) are only selected at
     benchmark-sized pixel counts; their selection thresholds are read from the environment once per process, so the conv
     parity tests of this file are re-run in a child process that forces both onto every shape."""
-    _rerun_conv_tests({"VINCE_BIG_MIN_K": "1", "VINCE_BIG_MIN_TILES": "1", "VINCE_NARROW256_MIN_TILES": "1"})
+    _rerun_conv_tests({"VINCE_BIG_MIN_K": "1", "VINCE_BIG_MIN_TILES": "1", "VINCE_NARROW256_MIN_TILES": "1"},
+                      "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem or test_conv_operand_transform")
 
 
 @pytest.mark.parametrize("rows,cin,cout", [(37, 512, 64), (256, 2048, 2048), (256, 2048, 128), (64, 1000, 96)])

@@ -24,7 +24,7 @@ class BnReduce(ctypes.Structure):
 
 class ConvEpi(ctypes.Structure):
     _fields_ = [("flags", c_int32), ("bias", c_void_p), ("stats", c_void_p), ("acc_mask", c_void_p),
-                ("bnred", BnReduce), ("replicas", c_int32)]
+                ("bnred", BnReduce), ("in_scale", c_void_p), ("in_shift", c_void_p), ("replicas", c_int32)]
 
 
 class BnTrain(ctypes.Structure):
@@ -111,7 +111,7 @@ PROTOTYPES = {
     "vince_trunk_weight_cache_bytes": (c_size_t, [c_void_p]),
     "vince_trunk_prepare_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "vince_trunk_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
-                                    c_void_p, c_void_p, c_int32, c_void_p]),
+                                    c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "vince_trunk_spatial_ptr": (c_void_p, [c_void_p, c_void_p]),
     "vince_trunk_input_ptr": (c_void_p, [c_void_p, c_void_p, P(c_int32), P(c_int32)]),
     "vince_trunk_prepare_weights_folded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -381,7 +381,10 @@ struct SmemD {
     static constexpr int MAIN = STAGES * STAGE;
     static constexpr int CRS = CT * (int)sizeof(T) + 16;
     static constexpr int EPI = PTL * CRS + 4 * CT * 2 * 4;
-    static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
+    static constexpr int BYTES0 = MAIN > EPI ? MAIN : EPI;
+    // operand-transform table (scale[512], shift[512] floats) lives right behind the ring; only the XF instantiations pay
+    static constexpr int XF_OFF = MAIN, XF_BYTES = 2 * 512 * 4;
+    static constexpr int BYTES_XF = BYTES0 > MAIN + XF_BYTES ? BYTES0 : MAIN + XF_BYTES;
 };
 
 // K tile = KC 16-byte chunks per row; STAGES-deep LDS ring, prefetch distance STAGES-1 tiles, counted vmcnt so that the
@@ -389,7 +392,7 @@ struct SmemD {
 // PTL = pixels per workgroup tile (128 or 256).  The L2 -> LDS fill rate of a CU (measured ~19 B/clk with every CU
 // streaming) caps a 128x128 tile at ~700 TFLOP/s chip-wide: 256 B of operands per K element feed 32768 FLOP.  The
 // 256-pixel tile moves 25 % fewer bytes per FLOP (each wave owns 128 pixels x CT/2 channels).
-template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, bool BWD>
+template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, bool BWD, bool XF = false>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64, PI = PTL / 64;
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     constexpr int XROWS = PTL / RPP, WROWS = CT / RPP;
     constexpr int PER_STAGE = XROWS + WROWS;       // DMA instructions per thread per stage
     constexpr int SWSH = KC == 8 ? 1 : 2, SWMASK = KC - 1;   // slot swizzle = (row >> SWSH) & SWMASK
-    __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XF ? S::BYTES_XF : S::BYTES0];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -459,6 +462,48 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
             offw[e] = ok ? (((uint32_t)co * (uint32_t)d.WT + (uint32_t)widx) * (uint32_t)d.Ci + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
         }
     };
+    // ---- operand transform (XF): in' = relu(in * scale[ci] + shift[ci]) on this thread's own DMA'd pieces, in place in LDS.
+    // A piece is 16 bytes = CH channels of one input pixel; pieces that were zero-filled (out-of-image tap, tile tail) stay
+    // zero, which is what zero padding of the ACTIVATION means.  vmask[stage] remembers which of this thread's pieces of
+    // that stage hold real data.
+    uint32_t vmask[STAGES];
+#pragma unroll
+    for (int st = 0; st < STAGES; ++st) vmask[st] = 0;
+    const float* xf_tab = (const float*)(smem + S::XF_OFF);
+    if constexpr (XF) {
+        float* tabw = (float*)(smem + S::XF_OFF);
+        for (int ci = tid; ci < d.Ci; ci += 256) {
+            tabw[ci] = p.e.in_scale[ci];
+            tabw[512 + ci] = p.e.in_shift[ci];
+        }
+        // (visible to everyone after the prologue's barrier)
+    }
+    auto transform_tile = [&](int kt, int buf) {
+        if constexpr (XF) {
+            const int q = kt * KC + c_log;
+            const int cc = q & p.cpt_mask;                     // chunk within the tap = channel group
+            float sc[CH], sh[CH];
+#pragma unroll
+            for (int e4 = 0; e4 < CH; e4 += 4) {
+                const float4 a = *(const float4*)(xf_tab + cc * CH + e4);
+                const float4 b = *(const float4*)(xf_tab + 512 + cc * CH + e4);
+                sc[e4] = a.x; sc[e4 + 1] = a.y; sc[e4 + 2] = a.z; sc[e4 + 3] = a.w;
+                sh[e4] = b.x; sh[e4 + 1] = b.y; sh[e4 + 2] = b.z; sh[e4 + 3] = b.w;
+            }
+            unsigned char* base = smem + buf * S::STAGE + wave * 1024 + lane * 16;
+            const uint32_t vm = buf == 0 ? vmask[0] : (buf == 1 ? vmask[1] : vmask[STAGES - 1]);   // STAGES <= 3
+#pragma unroll
+            for (int e = 0; e < XROWS; ++e) {
+                if (!((vm >> e) & 1u)) continue;
+                uint4* ptr = (uint4*)(base + e * 4096);
+                float f[CH];
+                Chunk<T>::unpack(*ptr, f);
+#pragma unroll
+                for (int c_ = 0; c_ < CH; ++c_) f[c_] = fmaxf(f[c_] * sc[c_] + sh[c_], 0.f);
+                *ptr = Chunk<T>::pack(f);
+            }
+        }
+    };
     auto issue_tile = [&](int kt, int buf) {
         if (p.uniform_taps) {
             const int tap = kt >= p.nkt ? 0x7fffff : ((kt * KC) >> p.log2_cpt);   // wave-uniform
@@ -473,6 +518,14 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
             }
         } else {
             compute_offsets(kt * KC + c_log);
+        }
+        if constexpr (XF) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int e = 0; e < XROWS; ++e) m |= (offx[e] < OOB ? 1u : 0u) << e;
+            if (buf == 0) vmask[0] = m;
+            else if (buf == 1) vmask[1] = m;
+            else vmask[STAGES - 1] = m;
         }
         const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
         const uint32_t ws = xs + S::XB;
@@ -497,6 +550,10 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
 #pragma unroll
     for (int st = 0; st < STAGES - 1; ++st) issue_tile(kt0 + st, st);
     wait_vmcnt<(STAGES - 2) * PER_STAGE>();
+    if constexpr (XF) {
+        __syncthreads();                 // the scale / shift table is complete
+        transform_tile(kt0, 0);
+    }
     __syncthreads();
     const int sw = ((lane & 31) >> SWSH) & SWMASK, khalf = lane >> 5;
     const int row_off = (lane & 31) * KB;
@@ -528,6 +585,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
         // tile kt+1 must have landed (this wave's share; the barrier extends it to all waves); the STAGES-2 younger
         // tiles stay in flight across the barrier
         wait_vmcnt<(STAGES - 2) * PER_STAGE>();
+        if constexpr (XF) {
+            if (kt + 1 < kt1) transform_tile(kt + 1, buf + 1 == STAGES ? 0 : buf + 1);   // own pieces only: no barrier needed first
+        }
         if (!(p.ablate & 4)) __syncthreads();
         buf = buf + 1 == STAGES ? 0 : buf + 1;
         nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
@@ -554,6 +614,11 @@ int launch(ConvParams& p, hipStream_t stream) {
     static int big_min_k = getenv("VINCE_BIG_MIN_K") ? atoi(getenv("VINCE_BIG_MIN_K")) : 1024;
     static int big_min_tiles = getenv("VINCE_BIG_MIN_TILES") ? atoi(getenv("VINCE_BIG_MIN_TILES")) : 256;
     static long narrow256 = getenv("VINCE_NARROW256_MIN_TILES") ? atol(getenv("VINCE_NARROW256_MIN_TILES")) : 2048;   // 0 = off
+    const bool xf = p.e.in_scale != nullptr;
+    if (xf && !(p.in_bytes && p.w_bytes && k_elems >= dlds_min_k && !BWD)) {
+        vince_set_error("vince_conv_igemm: the operand transform needs the direct-to-LDS forward kernels (tensors < 2 GiB)");
+        return VINCE_E_UNSUPPORTED;
+    }
     if (p.in_bytes && p.w_bytes && k_elems >= dlds_min_k) {
         const int cpt = p.cpt_mask == 0x7fffffff ? p.total_chunks : p.cpt_mask + 1;
         p.uniform_taps = (cpt % 4 == 0) && (p.total_chunks % 4 == 0);
@@ -564,8 +629,14 @@ int launch(ConvParams& p, hipStream_t stream) {
             if constexpr (CT == 128) {
                 p.ptiles = (p.M + 255) / 256;
                 p.variant = 1;
-                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
-                                   stream, p);
+                if (xf) {
+                    if constexpr (!BWD)
+                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, false, true>), dim3(p.ptiles * p.ctiles),
+                                           dim3(256), 0, stream, p);
+                } else {
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                                       stream, p);
+                }
             }
         } else if (CT == 64 && narrow256 && (long)((p.M + 255) / 256) >= narrow256) {
             // 64-channel layers with very many pixel tiles (stem, layer1): 256-pixel tiles halve the per-tile fixed cost
@@ -573,8 +644,14 @@ int launch(ConvParams& p, hipStream_t stream) {
             if constexpr (CT == 64) {
                 p.ptiles = (p.M + 255) / 256;
                 p.variant = 1;
-                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
-                                   stream, p);
+                if (xf) {
+                    if constexpr (!BWD)
+                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, false, true>), dim3(p.ptiles * p.ctiles),
+                                           dim3(256), 0, stream, p);
+                } else {
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                                       stream, p);
+                }
             }
         } else {   // 128-pixel tiles, 2 stages, registers capped for 4 workgroups per CU
             // Tiny-M fp32 GEMMs (the projection MLP, 256 rows: 2 pixel tiles) would leave most CUs idle: split the
@@ -582,7 +659,7 @@ int launch(ConvParams& p, hipStream_t stream) {
             int splits = 1;
             const long tiles = (long)p.ptiles * p.ctiles;
             static const bool splitk_env = !(getenv("VINCE_SPLITK") && atoi(getenv("VINCE_SPLITK")) == 0);
-            if (sizeof(T) == 4 && splitk_env && !BWD && !p.e.stats && tiles < 128 && p.nkt >= 16 &&
+            if (sizeof(T) == 4 && splitk_env && !BWD && !xf && !p.e.stats && tiles < 128 && p.nkt >= 16 &&
                 p.d.osh == 1 && p.d.osw == 1 && p.d.OH == p.d.Ho && p.d.OW == p.d.Wo) {
                 static const long target = getenv("VINCE_SPLITK_WGS") ? atol(getenv("VINCE_SPLITK_WGS")) : 256;   // (env: measurement aid) more splits cost more in atomics than they buy
                 splits = (int)min((long)(p.nkt / 8), (target + tiles - 1) / tiles);
@@ -599,6 +676,10 @@ int launch(ConvParams& p, hipStream_t stream) {
                                    stream, p);
                 if (relu) hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)min((size_t)1024, (n / 4 + 255) / 256)), dim3(256), 0,
                                              stream, (float*)p.out, n / 4);
+            } else if (xf) {
+                if constexpr (!BWD)
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, false, true>), dim3(p.ptiles * p.ctiles), dim3(256),
+                                       0, stream, p);
             } else {
                 hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
             }
@@ -631,6 +712,9 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     VINCE_CHECK_ARG(!e.acc_mask || (e.flags & VINCE_EPI_ACCUMULATE), VINCE_E_ARG, "vince_conv_igemm: acc_mask needs VINCE_EPI_ACCUMULATE");
     VINCE_CHECK_ARG(!e.bnred.y || (e.bnred.mean && e.bnred.invstd && e.bnred.sums && !e.stats), VINCE_E_ARG,
                     "vince_conv_igemm: bnred needs y, mean, invstd and sums, and excludes stats");
+    VINCE_CHECK_ARG(!e.in_scale == !e.in_shift, VINCE_E_ARG, "vince_conv_igemm: in_scale and in_shift come together");
+    VINCE_CHECK_ARG(!e.in_scale || (dd->Ci <= 512 && dd->Cs == 0 && !(e.flags & VINCE_EPI_ACCUMULATE) && !e.bnred.y), VINCE_E_UNSUPPORTED,
+                    "vince_conv_igemm: operand transform: Ci <= 512, no packed row taps, forward epilogue only");
     VINCE_CHECK_ARG(!e.bnred.mask_scale == !e.bnred.mask_shift, VINCE_E_ARG,
                     "vince_conv_igemm: bnred mask_scale and mask_shift come together");
     VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_igemm: bad dtype %d", dtype);

@@ -388,13 +388,20 @@ struct Ctx {
 // conv (+ BatchNorm statistics in train mode).  finalize_now: also run the stand-alone finalize -- needed in eval mode and
 // where the consumer of scale / shift is not vince_bn_train_apply (the stem's pool, the downsample branch's identity
 // affine); everywhere else the finalize rides in the prologue of the apply pass (bn_apply_fwd below).
+// xf_bn: the BatchNorm(+ReLU) that sits between the producer of `in` and this conv is applied to the staged input tile
+// inside this conv (vince_conv_epi.in_scale / in_shift) -- `in` is then the producer's RAW output.
 int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_off, float* const* bn_running,
-                int64_t* const* bn_nbt, int train_bn, bool finalize_now, const vince_conv_desc* desc = nullptr) {
+                int64_t* const* bn_nbt, int train_bn, bool finalize_now, const vince_conv_desc* desc = nullptr,
+                const BnL* xf_bn = nullptr) {
     vince_conv_desc d = desc ? *desc : fwd_desc(c.t, cv);
     vince_conv_epi e;
     memset(&e, 0, sizeof(e));
     e.stats = train_bn ? c.stats(bn) : nullptr;
     e.replicas = bn.R;
+    if (xf_bn) {
+        e.in_scale = c.consts(*xf_bn, 0);
+        e.in_shift = c.consts(*xf_bn, 1);
+    }
     RC(vince_conv_igemm(&d, c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), &e, c.stream));
     if (finalize_now || !train_bn) {
         const int64_t count = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
@@ -633,7 +640,8 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
 
 extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void* wcache, float* const* bn_running,
                                    int64_t* const* bn_nbt, const float* input, const int64_t* perm, int32_t jig_h,
-                                   int32_t jig_w, void* workspace, float* pooled, int32_t train_bn, void* stream) {
+                                   int32_t jig_w, void* workspace, float* pooled, int32_t train_bn, int32_t save,
+                                   void* stream) {
     VINCE_CHECK_ARG(t && params && wcache && bn_running && workspace && pooled, VINCE_E_ARG,
                     "vince_trunk_forward: null pointer");
     VINCE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, VINCE_E_ALIGN,
@@ -668,6 +676,13 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // The downsample conv of a stage-entry block depends on the block input only: it (and its BatchNorm's finalize) runs
     // on the engine's third stream next to conv1..convL and is joined before the block's last apply (VINCE_DS_STREAM=0 or
     // profiling: inline).
+    // No-grad forwards (save == 0: key encoder, validation in train-mode BN) fuse the bottleneck-internal BatchNorm + ReLU
+    // into the consuming conv's operand path (VINCE_XF=0: separate apply passes; off while profiling so that kernel tags
+    // keep their meaning; backward needs the materialised activations, so grad-enabled forwards never do this)
+    // opt-in (measured: neutral for 1x1 consumers, +1.2 ms/step for 3x3 ones -- the transform's LDS round trip costs more than the
+    // apply pass it removes); read per call so a test can switch it.  0 off, 1 every consumer, 2 only 1x1 consumers, 3 only 3x3
+    const int xf_mode = getenv("VINCE_XF") ? atoi(getenv("VINCE_XF")) : 0;
+    const bool fuse_xf = xf_mode != 0 && !save && !vince_profile_enabled();
     static const bool ds_env_f = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0);
     const bool ds_side = ds_env_f && !vince_profile_enabled();
     if (ds_side && !t->ds_stream) {
@@ -687,12 +702,21 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             RC(conv_bn_fwd(cd, b.cd, b.bd, b.x_in, b.yd, bn_running, bn_nbt, train_bn, true));
             VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_done, t->ds_stream));
         }
+        const BnL* pending = nullptr;   // BatchNorm + ReLU deferred into the next conv's operand path (no-grad forwards)
         for (int ci = 0; ci < b.nconv; ++ci) {
-            RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, false));
+            const bool defer = fuse_xf && ci < b.nconv - 1 && b.c[ci].Co <= 512 &&
+                               (xf_mode == 1 || (xf_mode == 2 && b.c[ci + 1].k == 1) || (xf_mode == 3 && b.c[ci + 1].k == 3));
+            RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, defer, nullptr, pending));
+            pending = nullptr;
             if (ci < b.nconv - 1) {
-                RC(bn_apply_fwd(c, b.c[ci], b.b[ci], b.y[ci], nullptr, nullptr, nullptr, at(workspace, b.a[ci]), nullptr,
-                                bn_running, bn_nbt, train_bn));
-                in = b.a[ci];
+                if (defer) {   // the activation is never materialised: the consumer reads y and applies scale / shift / ReLU
+                    pending = &b.b[ci];
+                    in = b.y[ci];
+                } else {
+                    RC(bn_apply_fwd(c, b.c[ci], b.b[ci], b.y[ci], nullptr, nullptr, nullptr, at(workspace, b.a[ci]), nullptr,
+                                    bn_running, bn_nbt, train_bn));
+                    in = b.a[ci];
+                }
             }
         }
         const int L = b.nconv - 1;

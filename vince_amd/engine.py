@@ -77,13 +77,15 @@ class Trunk:
         check(lib().vince_trunk_prepare_weights(self._h, param_ptrs, ctypes.c_void_p(wcache.data_ptr()), ops.stream_ptr()))
 
     def forward(self, param_ptrs, wcache, bn_running_ptrs, bn_nbt_ptrs, data, workspace, pooled, train_bn, perm=None,
-                jigsaw_src=None):
+                jigsaw_src=None, save=True):
+        """save=False: no backward follows -- the engine may skip the bottleneck-internal activation tensors."""
         jh, jw = (0, 0) if jigsaw_src is None else jigsaw_src
         check(lib().vince_trunk_forward(
             self._h, param_ptrs, ctypes.c_void_p(wcache.data_ptr()), bn_running_ptrs, bn_nbt_ptrs,
             None if data is None else ctypes.c_void_p(data.data_ptr()),      # None: the input was staged (stage_u8)
             None if perm is None else ctypes.c_void_p(perm.data_ptr()), jh, jw,
-            ctypes.c_void_p(workspace.data_ptr()), ctypes.c_void_p(pooled.data_ptr()), int(train_bn), ops.stream_ptr()))
+            ctypes.c_void_p(workspace.data_ptr()), ctypes.c_void_p(pooled.data_ptr()), int(train_bn), int(save),
+            ops.stream_ptr()))
 
     def stage_u8(self, workspace, frames_u8, crop_yx=None, flip=None, perm=None, mean255=None, std255=None):
         """GPU input stage: uint8 HWC frames [N][Hs][Ws][3] -> the stem layout inside `workspace` (crop window, flip, batch

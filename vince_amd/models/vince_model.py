@@ -388,7 +388,7 @@ class VinceModel(BaseModel):
             trunk.forward_folded(self._wcache_folded, data, ws, pooled, jigsaw_src=(h, w) if jigsaw else None)
         else:
             trunk.forward(self._param_ptrs, self._wcache, self._bn_running_ptrs, self._bn_nbt_ptrs, data, ws, pooled,
-                          train_bn=self.training, jigsaw_src=(h, w) if jigsaw else None)
+                          train_bn=self.training, jigsaw_src=(h, w) if jigsaw else None, save=bool(save))
             if self.training:
                 self._bn_version += 1   # running statistics moved
         # `spatial_features` is a copy by default: the workspace it lives in is rewritten by the next forward.  A caller that

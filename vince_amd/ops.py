@@ -115,9 +115,10 @@ def bn_reduce_arg(y, mean, invstd, sums, mask_bits=None, mask_scale=None, mask_s
     return r
 
 
-def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None, replicas=0):
+def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None, replicas=0, in_scale=None,
+               in_shift=None):
     """vince_conv_igemm with the epilogue options of vince_conv_epi."""
-    require_gpu(x, w, out, bias, stats, acc_mask)
+    require_gpu(x, w, out, bias, stats, acc_mask, in_scale, in_shift)
     e = ConvEpi()
     e.flags = flags
     e.bias = None if bias is None else bias.data_ptr()
@@ -126,6 +127,8 @@ def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, b
     if bnred is not None:
         e.bnred = bnred
     e.replicas = replicas
+    e.in_scale = None if in_scale is None else in_scale.data_ptr()   # operand transform relu(x * scale + shift)
+    e.in_shift = None if in_shift is None else in_shift.data_ptr()
     check(lib().vince_conv_igemm(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(w), _ptr(out), ctypes.byref(e),
                                  stream_ptr()))
     return out
