@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 # algorithmic work per unit (hook-counted on the reference's resnet.py)
@@ -145,7 +146,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    loss = float(last[0]["nce_loss"])
+    loss = float(last[0]["nce_loss"].detach())
     frames_per_s = 2.0 * opt.batch * world * opt.steps / dt
     ms_per_step = 1000.0 * dt / opt.steps
     step_tflop = STEP_GFLOP_PER_SAMPLE.get(opt.backbone, 0.0) * opt.batch / 1000.0
@@ -214,6 +215,34 @@ def main():
                                              "mfma_frac": round(inf_tflops / PEAK_TFLOPS[opt.dtype], 4)}
 
     if rank == 0 and world == 1 and not opt.no_extras:
+        # ---- GPU input stage: one step's 2B augmented views (MoCo-v2 recipe, train_moco_v2.sh:18) from a pool
+        # of uint8 256 x 320 frames; device time of crop+resize, colour chain and the blur/normalise/layout kernels, with the
+        # host-side parameter draws timed separately (they can run a step ahead).  Not part of `value`.
+        try:
+            from vince_amd.utils import transforms as T
+            tf = T.MoCoV2ImagenetTransform(opt.size, seed=0)
+            gpool = torch.randint(0, 256, (opt.batch, 256, 320, 3), dtype=torch.uint8, device=device)
+            src = np.tile(np.arange(opt.batch), 2).astype(np.int64)
+            th0 = time.perf_counter()
+            params = tf.draw(2 * opt.batch, (256, 320), src_index=src)
+            t_draw = time.perf_counter() - th0
+            for _ in range(2):
+                views = tf.apply(gpool, params)
+                views.float_tensor(torch.bfloat16 if opt.dtype == "bf16" else torch.float32)
+            torch.cuda.synchronize()
+            ta0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                views = tf.apply(gpool, params)
+                views.float_tensor(torch.bfloat16 if opt.dtype == "bf16" else torch.float32)
+            torch.cuda.synchronize()
+            t_aug = (time.perf_counter() - ta0) / reps
+            out["input_stage"] = {"recipe": "MoCoV2ImagenetTransform", "views": 2 * opt.batch, "source": "uint8 256x320",
+                                  "ms": round(t_aug * 1000, 3), "views_per_s": round(2 * opt.batch / t_aug, 1),
+                                  "host_draw_ms": round(t_draw * 1000, 3)}
+            del gpool, views
+        except Exception as e:
+            out["input_stage"] = {"error": repr(e)}
         # ---- roofline leg: hipEvent pairs around every conv launch for a few extra steps -------------------------
         # (streams are serialised for these steps so that every launch's event pair times that kernel running alone)
         L = lib()

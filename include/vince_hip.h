@@ -252,6 +252,32 @@ int vince_jigsaw_nchw_to_rows(int dtype, const float* in, void* out, int32_t N, 
 int vince_input_u8hwc_to_rows(int dtype, const uint8_t* in, const int64_t* perm, const int32_t* crop_yx, const uint8_t* flip,
                               const float* mean255, const float* std255, void* out, int32_t N, int32_t Hs, int32_t Ws,
                               int32_t H, int32_t W, int32_t Wp, int32_t left, void* stream);
+/* GPU input stage, random part: the per-sample PIL pipeline of utils/transforms.py:62-235
+ * (RandomResizedCrop -> ColorJitter / RandomGrayscale -> RandomHorizontalFlip -> ToTensor + Normalize -> RandomGaussianBlur)
+ * on uint8 frames resident in HBM.  The random DRAWS stay on the host (the caller passes boxes, op orders, factors, flips,
+ * blur kernels); the kernels reproduce the arithmetic of Pillow (requirements.txt:12) and torchvision 0.5 functional ops
+ * bit for bit on the uint8 stages.
+ *
+ * _resized_crop_u8: output n = BILINEAR resize to H x W of the window box[n] = {top, left, height, width} (int32[N][4]) of
+ *   frame src_index[n] (int64[N], NULL: n) of frames uint8 [..][Hs][Ws][3]  (torchvision F.resized_crop on a PIL image:
+ *   crop, then Image.resize -- Resample.c: antialiased triangle filter, 22-bit fixed-point coefficients, horizontal pass into
+ *   a uint8 intermediate, then the vertical pass).  tmp: uint8 [N][Hs][W][3] scratch; out: uint8 [N][H][W][3].
+ * _color_u8: in place on uint8 [N][H][W][3]; per image up to max_ops steps in order, op int32[N][max_ops], factor
+ *   float[N][max_ops]: -1 skip; 0 brightness, 1 contrast, 2 saturation (ImageEnhance: Image.blend(degenerate, image, factor),
+ *   Blend.c float32 arithmetic); 3 hue (factor = the uint8 shift of the H plane, i.e. uint8(hue_factor * 255), as a float;
+ *   Convert.c RGB<->HSV); 4 grayscale with 3 equal channels (RandomGrayscale; Convert.c luma).
+ * _blur_to_rows: uint8 [N][H][W][3] -> the packed stem layout (see vince_input_u8hwc_to_rows): horizontal flip (flip uint8[N]
+ *   or NULL), (u8 - mean255) / std255, and for images with do_blur[n] != 0 (uint8[N] or NULL = none) the separable Gaussian
+ *   blur of utils/util_functions.py:104-132 on the NORMALISED tensor (H direction, then W direction, zero padding) with the
+ *   per-image taps kernels float[N][ks] (ks odd; the caller evaluates exp(-d^2 / (2 sigma^2)) / sum exactly as the reference
+ *   does).  tmp: float [N][H][W][4] scratch. */
+int vince_aug_resized_crop_u8(const uint8_t* frames, const int64_t* src_index, const int32_t* box, uint8_t* tmp, uint8_t* out,
+                              int32_t N, int32_t Hs, int32_t Ws, int32_t H, int32_t W, void* stream);
+int vince_aug_color_u8(uint8_t* img, const int32_t* op, const float* factor, int32_t max_ops, int32_t N, int32_t H, int32_t W,
+                       void* stream);
+int vince_aug_blur_to_rows(int dtype, const uint8_t* img, const uint8_t* flip, const float* kernels, const uint8_t* do_blur,
+                           int32_t ks, const float* mean255, const float* std255, float* tmp, void* out, int32_t N, int32_t H,
+                           int32_t W, int32_t Wp, int32_t left, void* stream);
 /* fp32 master weights [Co][T][Ci] -> compute copy [Co][T][Cip] (dtype) and, if wt != NULL, the dgrad copy
  * [Ci][T][Co] (dtype). */
 int vince_prepare_weight(int dtype, const float* w, void* wk, void* wt, int32_t Co, int32_t T, int32_t Ci,

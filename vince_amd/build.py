@@ -15,7 +15,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libvince_hip.so")
-SOURCES = ["error.cpp", "conv_igemm.hip", "conv_wgrad.hip", "bn_pool.hip", "misc.hip", "infonce.hip", "trunk.hip"]
+SOURCES = ["error.cpp", "conv_igemm.hip", "conv_wgrad.hip", "bn_pool.hip", "misc.hip", "infonce.hip", "trunk.hip", "augment.hip"]
+# augment.hip restates Pillow's double / float arithmetic: an fma where the C library rounds twice changes results
+EXTRA_FLAGS = {"augment.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -35,7 +37,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(h, obj) for h in headers):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):

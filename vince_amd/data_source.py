@@ -26,3 +26,34 @@ class SyntheticFrames:
         self.count += 1
         return {"data": data, "queue_data": queue_data, "batch_type": "images", "batch_size": self.batch_size,
                 "data_source": self.data_source, "num_frames": self.num_frames}
+
+
+class AugmentedFrames:
+    """Raw uint8 frames + the GPU input stage: what the reference's dataset + ``--transform`` pair produces
+    (r2v2_dataset.py:55-99 applies the transform to every frame of a sample; the solver reads ``data`` / ``queue_data``,
+    vince_solver.py:191-199), with the pixel work done by csrc/augment.hip on the training GPU instead of 40 PIL workers.
+
+    ``pool``: uint8 [P, Hs, Ws, 3] frames on the device (a synthetic pool here; a decoder / loader would refill it);
+    ``transform``: an instance from ``vince_amd.utils.transforms``.  Each call takes the next ``batch_size`` frames of the pool
+    and returns two independently augmented views -- query ``data`` and key ``queue_data`` -- as ``U8Frames`` handles."""
+
+    def __init__(self, pool, transform, batch_size, num_frames=1, data_source="SYN", iterations=None):
+        if pool.dtype != torch.uint8 or pool.dim() != 4 or pool.shape[-1] != 3:
+            raise ValueError("AugmentedFrames: pool must be uint8 [P, Hs, Ws, 3]")
+        self.pool, self.transform, self.batch_size = pool.contiguous(), transform, batch_size
+        self.num_frames, self.data_source, self.iterations = num_frames, data_source, iterations
+        self.count = 0
+
+    def __call__(self, loader_id=0):
+        if self.iterations is not None and self.count >= self.iterations:
+            self.count = 0
+            return None
+        b, p = self.batch_size, self.pool.shape[0]
+        idx = (torch.arange(b) + self.count * b) % p
+        self.count += 1
+        import numpy as np
+        src = np.concatenate([idx.numpy(), idx.numpy()]).astype(np.int64)
+        params = self.transform.draw(2 * b, tuple(self.pool.shape[1:3]), src_index=src)
+        views = self.transform.apply(self.pool, params)
+        return {"data": views[0:b], "queue_data": views[b:2 * b], "batch_type": "images", "batch_size": b,
+                "data_source": self.data_source, "num_frames": self.num_frames}

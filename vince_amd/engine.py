@@ -104,6 +104,19 @@ class Trunk:
         check(lib().vince_input_u8hwc_to_rows(code, p(frames_u8), p(perm), p(crop_yx), p(flip), mean, std, ctypes.c_void_p(x0),
                                               self.N, hs, ws, self.H, self.W, wp.value, left.value, ops.stream_ptr()))
 
+    def stage_blur(self, workspace, img_u8, flip, taps, do_blur, mean255, std255):
+        """GPU input stage with RandomGaussianBlur: uint8 [N][H][W][3] (already at the input size) -> the stem layout inside
+        `workspace`: flip, (u8 - mean) / std and the per-image separable blur.  Follow with forward(..., data=None)."""
+        n, h, w, c = img_u8.shape
+        if img_u8.dtype != torch.uint8 or c != 3 or (n, h, w) != (self.N, self.H, self.W) or not img_u8.is_contiguous():
+            raise ValueError("stage_blur: expected contiguous uint8 [%d, %d, %d, 3] frames, got %s %s"
+                             % (self.N, self.H, self.W, img_u8.dtype, tuple(img_u8.shape)))
+        wp, left = ctypes.c_int32(), ctypes.c_int32()
+        x0 = lib().vince_trunk_input_ptr(self._h, ctypes.c_void_p(workspace.data_ptr()), ctypes.byref(wp), ctypes.byref(left))
+        if wp.value != ops.stem_row_width(w) or left.value != ops.STEM_LEFT:
+            raise RuntimeError("stage_blur: stem layout mismatch")
+        ops.aug_blur_to_rows(img_u8, self.dtype, mean255, std255, flip, taps, do_blur, out=int(x0))
+
     def prepare_weights_folded(self, param_ptrs, bn_running_ptrs, wcache):
         """BatchNorm-folded inference weights + biases into `wcache` (a cache separate from the training one)."""
         check(lib().vince_trunk_prepare_weights_folded(self._h, param_ptrs, bn_running_ptrs,

@@ -35,10 +35,15 @@ class U8Frames:
     [N] horizontal flip of the window.  The crop, the flip and ToTensor + Normalize ((u8 - 255*mean) / (255*std),
     constants.py:28-29) happen inside the layout kernel that feeds the stem -- no float copy of the frames ever exists."""
 
-    def __init__(self, frames, size, crop_yx=None, flip=None):
+    def __init__(self, frames, size, crop_yx=None, flip=None, blur=None):
         self.frames, self.size = frames, (int(size[0]), int(size[1]))
         self.crop_yx = None if crop_yx is None else crop_yx.to(torch.int32).contiguous()
         self.flip = None if flip is None else flip.to(torch.uint8).contiguous()
+        # blur: (taps float32 [N, ks], do_blur uint8 [N]) -- RandomGaussianBlur on the normalised tensor (utils/transforms.py
+        # SimCLR / Jigsaw / MoCo-v2 recipes), applied inside the layout kernels; frames must already be H x W (no crop window)
+        self.blur = None if blur is None else (blur[0].to(torch.float32).contiguous(), blur[1].to(torch.uint8).contiguous())
+        if self.blur is not None and (self.crop_yx is not None or tuple(frames.shape[1:3]) != self.size):
+            raise ValueError("U8Frames: blur needs frames that are already at the network input size")
 
     @property
     def shape(self):   # what the float tensor would look like: batch-size logic upstream keeps working
@@ -48,9 +53,33 @@ class U8Frames:
     def device(self):
         return self.frames.device
 
+    def __len__(self):
+        return self.frames.shape[0]
+
+    def __getitem__(self, rows):
+        """Batch slicing (split_dict_by_type slices every per-sample entry of a batch dict)."""
+        if not isinstance(rows, slice):
+            raise TypeError("U8Frames supports slice indexing only")
+        pick = lambda t: None if t is None else t[rows]   # noqa: E731
+        return U8Frames(self.frames[rows], self.size, pick(self.crop_yx), pick(self.flip),
+                        None if self.blur is None else (self.blur[0][rows], self.blur[1][rows]))
+
     def to(self, device):
         return U8Frames(self.frames.to(device), self.size, None if self.crop_yx is None else self.crop_yx.to(device),
-                        None if self.flip is None else self.flip.to(device))
+                        None if self.flip is None else self.flip.to(device),
+                        None if self.blur is None else (self.blur[0].to(device), self.blur[1].to(device)))
+
+    def float_tensor(self, dtype=torch.float32):
+        """The float NCHW tensor these frames stand for, produced by the SAME layout kernels that feed the stem (the
+        per-sample contract of the reference's transforms returns this tensor)."""
+        from .. import ops
+        mean, std = constants.IMAGENET_MEAN, constants.IMAGENET_STD
+        if self.blur is not None:
+            rows = ops.aug_blur_to_rows(self.frames.contiguous(), dtype, mean, std, self.flip, self.blur[0], self.blur[1])
+        else:
+            rows = ops.input_u8hwc_to_rows(self.frames.contiguous(), dtype, self.size, mean, std, self.crop_yx, self.flip)
+        w = self.size[1]
+        return rows[:, :, ops.STEM_LEFT:ops.STEM_LEFT + w, :3].permute(0, 3, 1, 2).contiguous()
 
     def float_reference(self):
         """The float NCHW tensor this stands for (tests / debugging): same arithmetic, torch ops."""
@@ -65,6 +94,13 @@ class U8Frames:
             if self.flip is not None and bool(self.flip[i]):
                 win = win.flip(-1)
             out[i] = (win - mean) / std
+            if self.blur is not None and bool(self.blur[1][i]):   # utils/util_functions.py:119-129
+                k = self.blur[0][i]
+                ks = k.numel()
+                x = out[i][None]
+                x = torch.nn.functional.conv2d(x, k.view(1, 1, ks, 1).expand(3, 1, ks, 1), padding=(ks // 2, 0), groups=3)
+                x = torch.nn.functional.conv2d(x, k.view(1, 1, 1, ks).expand(3, 1, 1, ks), padding=(0, ks // 2), groups=3)
+                out[i] = x[0]
         return out
 
 
@@ -380,7 +416,12 @@ class VinceModel(BaseModel):
         nt = trunk.N
         pooled = torch.empty(nt, self.output_channels, device=self._flat.device, dtype=torch.float32)
         if u8 is not None:   # GPU input stage: the stem layout is written straight from the uint8 frames
-            trunk.stage_u8(ws, u8.frames.contiguous(), u8.crop_yx, u8.flip, None, constants.IMAGENET_MEAN, constants.IMAGENET_STD)
+            if u8.blur is not None:
+                trunk.stage_blur(ws, u8.frames.contiguous(), u8.flip, u8.blur[0], u8.blur[1], constants.IMAGENET_MEAN,
+                                 constants.IMAGENET_STD)
+            else:
+                trunk.stage_u8(ws, u8.frames.contiguous(), u8.crop_yx, u8.flip, None, constants.IMAGENET_MEAN,
+                               constants.IMAGENET_STD)
             data = None
         if not self.training and not save and FOLD_BN:
             # inference (extract_features for the end tasks, validation): BatchNorms folded into the convolutions

@@ -430,3 +430,68 @@ def sgd_flat(param, grad, buf, lr, momentum=0.9, weight_decay=1e-4, grad_scale=1
     require_gpu(param, grad, buf)
     check(lib().vince_sgd_flat(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), lr, momentum, weight_decay, grad_scale,
                                stream_ptr()))
+
+
+# ------------------------------------------------------------------------------------------------ GPU input stage (csrc/augment.hip)
+def aug_resized_crop_u8(frames, box, size, src_index=None):
+    """uint8 [Ns, Hs, Ws, 3] frames + int32 [N, 4] windows (top, left, height, width) -> uint8 [N, H, W, 3]: crop, then
+    Pillow's BILINEAR resize, bit for bit."""
+    require_gpu(frames, box, src_index)
+    ns, hs, ws, c = frames.shape
+    n = box.shape[0]
+    if frames.dtype != torch.uint8 or c != 3 or not frames.is_contiguous() or box.dtype != torch.int32 or box.shape[1] != 4:
+        raise ValueError("aug_resized_crop_u8: expected contiguous uint8 [Ns, Hs, Ws, 3] frames and int32 [N, 4] boxes")
+    if src_index is None and n != ns:
+        raise ValueError("aug_resized_crop_u8: %d boxes for %d frames (pass src_index)" % (n, ns))
+    h, w = int(size[0]), int(size[1])
+    tmp = torch.empty(n, hs, w, 3, dtype=torch.uint8, device=frames.device)
+    out = torch.empty(n, h, w, 3, dtype=torch.uint8, device=frames.device)
+    check(lib().vince_aug_resized_crop_u8(_ptr(frames), _ptr(src_index), _ptr(box.contiguous()), _ptr(tmp), _ptr(out), n, hs, ws,
+                                          h, w, stream_ptr()))
+    return out
+
+
+def aug_color_u8(img, op, factor):
+    """In-place ColorJitter / RandomGrayscale chain on uint8 [N, H, W, 3]; op int32 [N, M], factor float32 [N, M]."""
+    require_gpu(img, op, factor)
+    n, h, w, c = img.shape
+    if img.dtype != torch.uint8 or c != 3 or not img.is_contiguous() or op.dtype != torch.int32 or factor.dtype != torch.float32 \
+            or op.shape != factor.shape or op.shape[0] != n:
+        raise ValueError("aug_color_u8: expected contiguous uint8 [N, H, W, 3], int32 [N, M] ops and float32 [N, M] factors")
+    check(lib().vince_aug_color_u8(_ptr(img), _ptr(op.contiguous()), _ptr(factor.contiguous()), op.shape[1], n, h, w,
+                                   stream_ptr()))
+    return img
+
+
+def aug_blur_to_rows(img, dtype, mean255, std255, flip=None, kernels=None, do_blur=None, out=None):
+    """uint8 [N, H, W, 3] -> the packed stem layout [N][H][Wp][4] with flip, (u8 - mean) / std and the optional per-image
+    separable Gaussian blur (kernels float32 [N, ks], do_blur uint8 [N])."""
+    require_gpu(img, flip, kernels, do_blur)
+    n, h, w, _ = img.shape
+    wp = stem_row_width(w)
+    if out is None:
+        out = torch.empty(n, h, wp, STEM_CS, device=img.device, dtype=dtype)
+    tmp = torch.empty(n, h, w, 4, device=img.device, dtype=torch.float32)
+    mean = (ctypes.c_float * 3)(*[float(v) for v in mean255])
+    std = (ctypes.c_float * 3)(*[float(v) for v in std255])
+    ks = 0 if kernels is None else int(kernels.shape[1])
+    code = VINCE_F32 if dtype == torch.float32 else VINCE_BF16
+    out_ptr = ctypes.c_void_p(out) if isinstance(out, int) else _ptr(out)
+    check(lib().vince_aug_blur_to_rows(code, _ptr(img), _ptr(flip), _ptr(kernels), _ptr(do_blur), ks, mean, std, _ptr(tmp),
+                                       out_ptr, n, h, w, wp, STEM_LEFT, stream_ptr()))
+    return out
+
+
+def input_u8hwc_to_rows(frames, dtype, size, mean255, std255, crop_yx=None, flip=None, perm=None):
+    """uint8 [N, Hs, Ws, 3] -> packed stem layout [N][H][Wp][4]: crop window, flip, (u8 - mean) / std (csrc/misc.hip)."""
+    require_gpu(frames, crop_yx, flip, perm)
+    n, hs, ws, _ = frames.shape
+    h, w = int(size[0]), int(size[1])
+    wp = stem_row_width(w)
+    out = torch.empty(n, h, wp, STEM_CS, device=frames.device, dtype=dtype)
+    mean = (ctypes.c_float * 3)(*[float(v) for v in mean255])
+    std = (ctypes.c_float * 3)(*[float(v) for v in std255])
+    code = VINCE_F32 if dtype == torch.float32 else VINCE_BF16
+    check(lib().vince_input_u8hwc_to_rows(code, _ptr(frames), _ptr(perm), _ptr(crop_yx), _ptr(flip), mean, std, _ptr(out), n, hs,
+                                          ws, h, w, wp, STEM_LEFT, stream_ptr()))
+    return out

@@ -22,7 +22,7 @@ import torch
 
 from .. import constants, dp
 from ..data_source import SyntheticFrames
-from ..models.vince_model import VinceModel, VinceQueueModel
+from ..models.vince_model import U8Frames, VinceModel, VinceQueueModel
 from ..optim import FlatSGD
 from ..utils.storage_queue import StorageQueue
 from .base_solver import BaseSolver
@@ -162,11 +162,11 @@ class VinceSolver(BaseSolver):
                 return None
             self.batch_count += 1
             device = self.model.device
-            batch = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+            batch = {k: (v.to(device) if isinstance(v, (torch.Tensor, U8Frames)) else v) for k, v in batch.items()}
             batch.setdefault("queue_data_cpu", None)
             batches.append(batch)
         if len(batches) == 1:
-            concat = {k: v if isinstance(v, torch.Tensor) else [v] for k, v in batches[0].items()}
+            concat = {k: v if isinstance(v, (torch.Tensor, U8Frames)) else [v] for k, v in batches[0].items()}
         else:
             concat = stack_dicts_in_list(batches, concat=True)
         concat["batch_types"] = concat.pop("batch_type")
@@ -363,7 +363,7 @@ class VinceSolver(BaseSolver):
                     if batch is None:
                         break
                     device = self.model.device
-                    batch = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+                    batch = {k: (v.to(device) if isinstance(v, (torch.Tensor, U8Frames)) else v) for k, v in batch.items()}
                     concat = {k: v if isinstance(v, torch.Tensor) else [v] for k, v in batch.items()}
                     concat["batch_types"] = concat.pop("batch_type")
                     concat["batch_sizes"] = concat.pop("batch_size")

@@ -1,0 +1,215 @@
+"""GPU input stage: the reference's train / val image transforms (utils/transforms.py:62-235) as BATCH
+operators on uint8 frames that already sit in HBM.
+
+The reference builds one torchvision ``Compose`` per class and runs it per sample on PIL images inside 40 loader
+processes.  Here each class of the same name is a *recipe* (which random draws, in which order) over three HIP launches
+(csrc/augment.hip): the host draws the per-sample parameters with torchvision 0.5's distributions, the device does all pixel
+work -- crop + Pillow-exact BILINEAR resize, the ColorJitter / RandomGrayscale chain, and flip + ToTensor/Normalize
+[+ Gaussian blur] fused into the kernel that writes the stem's input layout.  The result is a ``U8Frames`` handle that
+``VinceModel.get_embeddings`` accepts in place of the float ``data`` tensor, or (``as_tensor=True`` / single-image call, the
+reference's per-sample contract) the float CHW tensor itself.
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import constants
+
+OP_NONE, OP_BRIGHTNESS, OP_CONTRAST, OP_SATURATION, OP_HUE, OP_GRAY = -1, 0, 1, 2, 3, 4
+MAX_OPS = 5   # four jitter components + grayscale
+
+
+@dataclass(frozen=True)
+class Recipe:
+    """What one reference transform class draws (utils/transforms.py line of its Compose in the comment of RECIPES)."""
+    crop_scale: Tuple[float, float]
+    crop_ratio: Tuple[float, float] = (3.0 / 4.0, 4.0 / 3.0)            # torchvision RandomResizedCrop default
+    jitter: Optional[Tuple[float, float, float, float]] = None          # brightness, contrast, saturation, hue
+    gray_p: float = 0.0
+    gray_first: bool = False                                            # RandomGrayscale before ColorJitter (MoCo v2)
+    flip_p: float = 0.5
+    blur_p: float = 0.0                                                 # RandomApply([RandomGaussianBlur(size // 10)])
+
+
+RECIPES = {
+    "BasicImagenetTransform": Recipe((0.2, 1.0), (0.7, 1.4), (0.4, 0.4, 0.4, 0.2), 0.2),                     # :64-76
+    "StandardVideoTransform": Recipe((0.2, 1.0), jitter=(0.4, 0.4, 0.4, 0.2), gray_p=0.2),                   # :91-103
+    "SimCLRTransform": Recipe((0.2, 1.0), jitter=(0.8, 0.8, 0.8, 0.2), gray_p=0.2, blur_p=0.5),              # :106-119
+    "JigsawTransform": Recipe((0.7, 1.0), jitter=(0.8, 0.8, 0.8, 0.2), gray_p=0.2, blur_p=0.5),              # :122-135
+    "SunSceneTransform": Recipe((0.7, 1.0), jitter=(0.4, 0.4, 0.4, 0.2), gray_p=0.2),                        # :138-150
+    "Kinetics400Transform": Recipe((0.5, 1.0), jitter=(0.4, 0.4, 0.4, 0.2), gray_p=0.2),                     # :153-165
+    "GOT10KTransform": Recipe((0.2, 1.0)),                                                                   # :168-178
+    "MoCoV1ImagenetTransform": Recipe((0.08, 1.0), jitter=(0.4, 0.4, 0.4, 0.2), gray_p=0.2),                 # :211-224
+    "MoCoV2ImagenetTransform": Recipe((0.2, 1.0), jitter=(0.4, 0.4, 0.4, 0.4), gray_p=0.2, gray_first=True,
+                                      blur_p=0.5),                                                           # :227-239
+}
+
+
+@dataclass
+class AugmentParams:
+    """Host-side draws for a batch of N outputs."""
+    box: np.ndarray                       # int32 [N, 4]  top, left, height, width of the crop window
+    op: np.ndarray                        # int32 [N, MAX_OPS]
+    factor: np.ndarray                    # float32 [N, MAX_OPS]  (hue slot: the uint8 H-plane shift)
+    flip: np.ndarray                      # uint8 [N]
+    sigma: np.ndarray                     # float32 [N]  Gaussian-blur sigma, 0 = not blurred
+    src_index: Optional[np.ndarray] = None   # int64 [N]  source frame of each output (None: identity)
+
+
+def blur_kernel_size(size):
+    ks = int(size) // 10                  # RandomGaussianBlur(self.size[0] // 10), utils/transforms.py:117
+    return ks + 1 if ks % 2 == 0 else ks  # utils/util_functions.py:107-108
+
+
+def blur_taps(sigma, ks):
+    """utils/util_functions.py:110,115-117 for a vector of sigmas: float32 [N, ks] (rows with sigma == 0 are unused)."""
+    sigma = torch.as_tensor(sigma, dtype=torch.float64)
+    rng = (ks - 1) * 0.5 - torch.arange(ks)                                       # float32, like the reference's buffer
+    out = torch.zeros(sigma.numel(), ks, dtype=torch.float32)
+    for i, s in enumerate(sigma.tolist()):
+        if s > 0:
+            k = torch.exp(-0.5 / (s ** 2) * (rng ** 2))
+            out[i] = k / max(1e-10, k.sum())
+    return out
+
+
+def hue_shift_u8(hue_factor):
+    """torchvision F.adjust_hue: np.uint8(hue_factor * 255) added to the H plane with wrap-around."""
+    return float(int(hue_factor * 255) & 0xFF)
+
+
+class BatchTransform:
+    """Base of the recipe classes.  ``size``: (H, W) or int; ``data_subset``: "train" | "val" (utils/transforms.py:38-59)."""
+
+    recipe: Recipe = None
+
+    def __init__(self, size, data_subset="train", seed=None):
+        self.size = (int(size), int(size)) if isinstance(size, (int, float)) else (int(size[0]), int(size[1]))
+        self.data_subset = data_subset
+        self.rng = np.random.default_rng(seed)
+        if data_subset not in ("train", "val"):
+            raise NotImplementedError("No transform for data_subset %s" % data_subset)
+
+    # ------------------------------------------------------------------------------------------ draws (host)
+    def _draw_box(self, hs, ws):
+        """torchvision 0.5 RandomResizedCrop.get_params: ten tries for an area / log-uniform aspect draw that fits, then the
+        central crop with the aspect clamped into range."""
+        r, area = self.recipe, hs * ws
+        lo, hi = math.log(r.crop_ratio[0]), math.log(r.crop_ratio[1])
+        for _ in range(10):
+            target = self.rng.uniform(*r.crop_scale) * area
+            aspect = math.exp(self.rng.uniform(lo, hi))
+            w = int(round(math.sqrt(target * aspect)))
+            h = int(round(math.sqrt(target / aspect)))
+            if 0 < w <= ws and 0 < h <= hs:
+                return int(self.rng.integers(0, hs - h + 1)), int(self.rng.integers(0, ws - w + 1)), h, w
+        in_ratio = ws / hs
+        if in_ratio < r.crop_ratio[0]:
+            w, h = ws, int(round(ws / r.crop_ratio[0]))
+        elif in_ratio > r.crop_ratio[1]:
+            h, w = hs, int(round(hs * r.crop_ratio[1]))
+        else:
+            w, h = ws, hs
+        return (hs - h) // 2, (ws - w) // 2, h, w
+
+    def _draw_color(self):
+        r = self.recipe
+        steps = []
+        if r.jitter is not None:
+            b, c, s, h = r.jitter
+            jit = []
+            if b > 0:
+                jit.append((OP_BRIGHTNESS, self.rng.uniform(max(0.0, 1 - b), 1 + b)))
+            if c > 0:
+                jit.append((OP_CONTRAST, self.rng.uniform(max(0.0, 1 - c), 1 + c)))
+            if s > 0:
+                jit.append((OP_SATURATION, self.rng.uniform(max(0.0, 1 - s), 1 + s)))
+            if h > 0:
+                jit.append((OP_HUE, hue_shift_u8(self.rng.uniform(-h, h))))
+            order = self.rng.permutation(len(jit))            # ColorJitter.get_params shuffles the component order
+            steps = [jit[i] for i in order]
+        if r.gray_p > 0 and self.rng.random() < r.gray_p:
+            steps = [(OP_GRAY, 0.0)] + steps if r.gray_first else steps + [(OP_GRAY, 0.0)]
+        return steps
+
+    def draw(self, n, src_hw, src_index=None):
+        hs, ws = src_hw
+        p = AugmentParams(np.zeros((n, 4), np.int32), np.full((n, MAX_OPS), OP_NONE, np.int32), np.zeros((n, MAX_OPS), np.float32),
+                          np.zeros(n, np.uint8), np.zeros(n, np.float32),
+                          None if src_index is None else np.asarray(src_index, np.int64))
+        r = self.recipe
+        for i in range(n):
+            p.box[i] = self._draw_box(hs, ws)
+            for j, (code, f) in enumerate(self._draw_color()):
+                p.op[i, j], p.factor[i, j] = code, f
+            p.flip[i] = self.rng.random() < r.flip_p
+            if r.blur_p > 0 and self.rng.random() < r.blur_p:
+                p.sigma[i] = self.rng.random() * (2.0 - 0.1) + 0.1       # utils/util_functions.py:105,114
+        return p
+
+    # ------------------------------------------------------------------------------------------ device work
+    def apply(self, frames, params):
+        """frames: uint8 [Ns, Hs, Ws, 3] on the GPU; params: AugmentParams -> U8Frames (uint8 [N, H, W, 3] + flip + blur)."""
+        from .. import ops
+        from ..models.vince_model import U8Frames
+        dev = frames.device
+        box = torch.from_numpy(params.box).to(dev)
+        src = None if params.src_index is None else torch.from_numpy(params.src_index).to(dev)
+        img = ops.aug_resized_crop_u8(frames, box, self.size, src)
+        if (params.op >= 0).any():
+            ops.aug_color_u8(img, torch.from_numpy(params.op).to(dev), torch.from_numpy(params.factor).to(dev))
+        flip = torch.from_numpy(params.flip).to(dev) if params.flip.any() else None
+        blur = None
+        if (params.sigma > 0).any():
+            ks = blur_kernel_size(self.size[0])
+            blur = (blur_taps(params.sigma, ks).to(dev), torch.from_numpy((params.sigma > 0).astype(np.uint8)).to(dev))
+        return U8Frames(img, self.size, None, flip, blur=blur)
+
+    def apply_val(self, frames):
+        """Resize((H / 0.875, W / 0.875), BILINEAR) + CenterCrop(size) (utils/transforms.py:78-88); the crop is taken by the
+        layout kernel."""
+        from .. import ops
+        from ..models.vince_model import U8Frames
+        n, hs, ws, _ = frames.shape
+        rh, rw = int(self.size[0] / 0.875), int(self.size[1] / 0.875)
+        box = torch.tensor([[0, 0, hs, ws]] * n, dtype=torch.int32, device=frames.device)
+        img = ops.aug_resized_crop_u8(frames, box, (rh, rw))
+        # torchvision center_crop: int(round((h - th) / 2.))
+        cy, cx = int(round((rh - self.size[0]) / 2.0)), int(round((rw - self.size[1]) / 2.0))
+        crop = torch.tensor([[cy, cx]] * n, dtype=torch.int32, device=frames.device)
+        return U8Frames(img, self.size, crop, None)
+
+    def __call__(self, frames, repeats=1, as_tensor=False):
+        """Batch call: uint8 [N, Hs, Ws, 3] GPU tensor -> U8Frames of N * repeats views (view v of frame i at v * N + i).
+        Per-sample call (the reference contract, utils/transforms.py:52-59): one HWC uint8 image (numpy or tensor) -> the
+        float CHW tensor."""
+        single = getattr(frames, "ndim", 0) == 3
+        if single:
+            frames = torch.as_tensor(np.asarray(frames) if not torch.is_tensor(frames) else frames)[None]
+        if not frames.is_cuda:
+            if not torch.cuda.is_available():
+                raise RuntimeError("vince_amd transforms run on the GPU (csrc/augment.hip); no CPU fallback")
+            frames = frames.cuda()
+        frames = frames.contiguous()
+        n, hs, ws, _ = frames.shape
+        if self.data_subset == "val":
+            out = self.apply_val(frames)
+        else:
+            src = None if repeats == 1 else np.tile(np.arange(n), repeats)
+            out = self.apply(frames, self.draw(n * repeats, (hs, ws), src))
+        if single:
+            return out.float_tensor()[0]
+        return out.float_tensor() if as_tensor else out
+
+
+def _make(name, recipe):
+    return type(name, (BatchTransform,), {"recipe": recipe, "__doc__": "utils/transforms.py `%s` as a batch recipe: %r" % (name, recipe)})
+
+
+for _name, _recipe in RECIPES.items():
+    globals()[_name] = _make(_name, _recipe)
+
+__all__ = list(RECIPES) + ["BatchTransform", "AugmentParams", "Recipe"]
