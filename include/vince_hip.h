@@ -261,7 +261,8 @@ int vince_input_u8hwc_to_rows(int dtype, const uint8_t* in, const int64_t* perm,
  * _resized_crop_u8: output n = BILINEAR resize to H x W of the window box[n] = {top, left, height, width} (int32[N][4]) of
  *   frame src_index[n] (int64[N], NULL: n) of frames uint8 [..][Hs][Ws][3]  (torchvision F.resized_crop on a PIL image:
  *   crop, then Image.resize -- Resample.c: antialiased triangle filter, 22-bit fixed-point coefficients, horizontal pass into
- *   a uint8 intermediate, then the vertical pass).  tmp: uint8 [N][Hs][W][3] scratch; out: uint8 [N][H][W][3].
+ *   a uint8 intermediate, then the vertical pass).  tmp: uint8 [N][Hs][W][3] scratch; table: int32 scratch of
+ *   vince_aug_resample_table_ints() entries; out: uint8 [N][H][W][3].  Windows must lie inside the frame.
  * _color_u8: in place on uint8 [N][H][W][3]; per image up to max_ops steps in order, op int32[N][max_ops], factor
  *   float[N][max_ops]: -1 skip; 0 brightness, 1 contrast, 2 saturation (ImageEnhance: Image.blend(degenerate, image, factor),
  *   Blend.c float32 arithmetic); 3 hue (factor = the uint8 shift of the H plane, i.e. uint8(hue_factor * 255), as a float;
@@ -270,9 +271,13 @@ int vince_input_u8hwc_to_rows(int dtype, const uint8_t* in, const int64_t* perm,
  *   or NULL), (u8 - mean255) / std255, and for images with do_blur[n] != 0 (uint8[N] or NULL = none) the separable Gaussian
  *   blur of utils/util_functions.py:104-132 on the NORMALISED tensor (H direction, then W direction, zero padding) with the
  *   per-image taps kernels float[N][ks] (ks odd; the caller evaluates exp(-d^2 / (2 sigma^2)) / sum exactly as the reference
- *   does).  tmp: float [N][H][W][4] scratch. */
-int vince_aug_resized_crop_u8(const uint8_t* frames, const int64_t* src_index, const int32_t* box, uint8_t* tmp, uint8_t* out,
-                              int32_t N, int32_t Hs, int32_t Ws, int32_t H, int32_t W, void* stream);
+ *   does).  tmp: float [N][H][W][4] scratch, used only when the kernel is too long for the fused LDS path (ks > ~40). */
+int vince_aug_resized_crop_u8(const uint8_t* frames, const int64_t* src_index, const int32_t* box, int32_t* table, uint8_t* tmp,
+                              uint8_t* out, int32_t N, int32_t Hs, int32_t Ws, int32_t H, int32_t W, void* stream);
+/* ints of the `table` scratch above (the per-image filter coefficient tables, computed once per call by a small kernel) and
+ * the longest filter a window inside an Hs x Ws frame can need (Resample.c ksize). */
+int64_t vince_aug_resample_table_ints(int32_t N, int32_t Hs, int32_t Ws, int32_t H, int32_t W);
+int vince_aug_resample_kmax(int32_t Hs, int32_t Ws, int32_t H, int32_t W);
 int vince_aug_color_u8(uint8_t* img, const int32_t* op, const float* factor, int32_t max_ops, int32_t N, int32_t H, int32_t W,
                        void* stream);
 int vince_aug_blur_to_rows(int dtype, const uint8_t* img, const uint8_t* flip, const float* kernels, const uint8_t* do_blur,

@@ -86,7 +86,7 @@ def test_blur_taps_and_separable_blur():
     taps = T.blur_taps(np.array([0.0, 0.1, 1.3, 2.0], np.float32), ks)
     assert float(taps[0].abs().sum()) == 0.0
     for i, s in [(1, 0.1), (2, 1.3), (3, 2.0)]:
-        assert torch.equal(taps[i], ao.gaussian_kernel(224 // 10, float(np.float32(s))))
+        assert torch.allclose(taps[i], ao.gaussian_kernel(224 // 10, float(np.float32(s))), rtol=1e-6, atol=1e-9)
         assert abs(float(taps[i].sum()) - 1.0) < 1e-6
     x = torch.randn(3, 20, 24, generator=torch.Generator().manual_seed(0)).numpy()
     y = ao.gaussian_blur_chw(x, ao.gaussian_kernel(6, 1.0))

@@ -82,8 +82,10 @@ PROTOTYPES = {
                                           c_int32, c_int32, c_void_p]),
     "vince_input_u8hwc_to_rows": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, P(c_float), P(c_float), c_void_p,
                                           c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "vince_aug_resized_crop_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
-                                          c_int32, c_void_p]),
+    "vince_aug_resized_crop_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                          c_int32, c_int32, c_void_p]),
+    "vince_aug_resample_table_ints": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "vince_aug_resample_kmax": (c_int, [c_int32, c_int32, c_int32, c_int32]),
     "vince_aug_color_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "vince_aug_blur_to_rows": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, P(c_float), P(c_float), c_void_p,
                                        c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -446,8 +446,9 @@ def aug_resized_crop_u8(frames, box, size, src_index=None):
     h, w = int(size[0]), int(size[1])
     tmp = torch.empty(n, hs, w, 3, dtype=torch.uint8, device=frames.device)
     out = torch.empty(n, h, w, 3, dtype=torch.uint8, device=frames.device)
-    check(lib().vince_aug_resized_crop_u8(_ptr(frames), _ptr(src_index), _ptr(box.contiguous()), _ptr(tmp), _ptr(out), n, hs, ws,
-                                          h, w, stream_ptr()))
+    table = torch.empty(int(lib().vince_aug_resample_table_ints(n, hs, ws, h, w)), dtype=torch.int32, device=frames.device)
+    check(lib().vince_aug_resized_crop_u8(_ptr(frames), _ptr(src_index), _ptr(box.contiguous()), _ptr(table), _ptr(tmp), _ptr(out),
+                                          n, hs, ws, h, w, stream_ptr()))
     return out
 
 

@@ -65,15 +65,16 @@ def blur_kernel_size(size):
 
 
 def blur_taps(sigma, ks):
-    """utils/util_functions.py:110,115-117 for a vector of sigmas: float32 [N, ks] (rows with sigma == 0 are unused)."""
-    sigma = torch.as_tensor(sigma, dtype=torch.float64)
-    rng = (ks - 1) * 0.5 - torch.arange(ks)                                       # float32, like the reference's buffer
-    out = torch.zeros(sigma.numel(), ks, dtype=torch.float32)
-    for i, s in enumerate(sigma.tolist()):
-        if s > 0:
-            k = torch.exp(-0.5 / (s ** 2) * (rng ** 2))
-            out[i] = k / max(1e-10, k.sum())
-    return out
+    """utils/util_functions.py:110,115-117 for a vector of sigmas: float32 [N, ks] (rows with sigma == 0 stay zero).  One
+    broadcast expression instead of a per-sample loop; equal to the per-sample evaluation up to the summation order of the
+    normalising sum (1 ulp)."""
+    sigma = np.asarray(sigma, np.float64)
+    d2 = ((ks - 1) * 0.5 - np.arange(ks, dtype=np.float32)) ** 2                  # float32, like the reference's buffer
+    on = sigma > 0
+    coef = (-0.5 / np.where(on, sigma, 1.0) ** 2).astype(np.float32)              # the Python scalar of :115
+    k = np.exp(coef[:, None] * d2[None, :])                                       # (numpy: torch.exp on a small CPU tensor
+    k = k / np.maximum(k.sum(axis=1, keepdims=True, dtype=np.float32), np.float32(1e-10))   # costs ~60 ms of thread start-up)
+    return torch.from_numpy(np.where(on[:, None], k, np.float32(0)).astype(np.float32))
 
 
 def hue_shift_u8(hue_factor):
@@ -106,14 +107,7 @@ class BatchTransform:
             h = int(round(math.sqrt(target / aspect)))
             if 0 < w <= ws and 0 < h <= hs:
                 return int(self.rng.integers(0, hs - h + 1)), int(self.rng.integers(0, ws - w + 1)), h, w
-        in_ratio = ws / hs
-        if in_ratio < r.crop_ratio[0]:
-            w, h = ws, int(round(ws / r.crop_ratio[0]))
-        elif in_ratio > r.crop_ratio[1]:
-            h, w = hs, int(round(hs * r.crop_ratio[1]))
-        else:
-            w, h = ws, hs
-        return (hs - h) // 2, (ws - w) // 2, h, w
+        return self._fallback_box(hs, ws)
 
     def _draw_color(self):
         r = self.recipe
@@ -136,19 +130,66 @@ class BatchTransform:
         return steps
 
     def draw(self, n, src_hw, src_index=None):
+        """All draws of a batch at once (numpy, no per-sample Python): same distributions as _draw_box / _draw_color."""
         hs, ws = src_hw
+        r, g = self.recipe, self.rng
         p = AugmentParams(np.zeros((n, 4), np.int32), np.full((n, MAX_OPS), OP_NONE, np.int32), np.zeros((n, MAX_OPS), np.float32),
                           np.zeros(n, np.uint8), np.zeros(n, np.float32),
                           None if src_index is None else np.asarray(src_index, np.int64))
-        r = self.recipe
-        for i in range(n):
-            p.box[i] = self._draw_box(hs, ws)
-            for j, (code, f) in enumerate(self._draw_color()):
-                p.op[i, j], p.factor[i, j] = code, f
-            p.flip[i] = self.rng.random() < r.flip_p
-            if r.blur_p > 0 and self.rng.random() < r.blur_p:
-                p.sigma[i] = self.rng.random() * (2.0 - 0.1) + 0.1       # utils/util_functions.py:105,114
+        # ---- crop windows: ten candidate (area, aspect) draws per sample, the first that fits wins
+        target = g.uniform(r.crop_scale[0], r.crop_scale[1], (n, 10)) * (hs * ws)
+        aspect = np.exp(g.uniform(math.log(r.crop_ratio[0]), math.log(r.crop_ratio[1]), (n, 10)))
+        w = np.rint(np.sqrt(target * aspect)).astype(np.int64)
+        h = np.rint(np.sqrt(target / aspect)).astype(np.int64)
+        ok = (w > 0) & (w <= ws) & (h > 0) & (h <= hs)
+        first = np.argmax(ok, axis=1)
+        rows = np.arange(n)
+        bw, bh = w[rows, first], h[rows, first]
+        top = np.floor(g.random(n) * (hs - bh + 1)).astype(np.int64)
+        left = np.floor(g.random(n) * (ws - bw + 1)).astype(np.int64)
+        none = ~ok.any(axis=1)
+        if none.any():
+            ft, fl, fh, fw = self._fallback_box(hs, ws)
+            top[none], left[none], bh[none], bw[none] = ft, fl, fh, fw
+        p.box[:] = np.stack([top, left, bh, bw], 1)
+        # ---- colour chain
+        jit = []
+        if r.jitter is not None:
+            for code, lim in zip((OP_BRIGHTNESS, OP_CONTRAST, OP_SATURATION), r.jitter[:3]):
+                if lim > 0:
+                    jit.append((code, g.uniform(max(0.0, 1 - lim), 1 + lim, n)))
+            if r.jitter[3] > 0:
+                hue = g.uniform(-r.jitter[3], r.jitter[3], n)
+                jit.append((OP_HUE, ((hue * 255).astype(np.int64) & 0xFF).astype(np.float64)))   # trunc, then uint8 wrap
+        gray = g.random(n) < r.gray_p if r.gray_p > 0 else np.zeros(n, bool)
+        nj = len(jit)
+        if nj:
+            order = g.permuted(np.tile(np.arange(nj), (n, 1)), axis=1)            # ColorJitter shuffles its components
+            codes = np.array([c for c, _ in jit], np.int32)[order]
+            facs = np.stack([f for _, f in jit], 1)[rows[:, None], order]
+            shift = (gray & r.gray_first).astype(np.int64)                        # grayscale first: jitter moves one slot right
+            for j in range(nj):
+                p.op[rows, j + shift] = codes[:, j]
+                p.factor[rows, j + shift] = facs[:, j]
+        gpos = np.where(r.gray_first, 0, nj)
+        p.op[gray, gpos] = OP_GRAY
+        p.flip[:] = g.random(n) < r.flip_p
+        if r.blur_p > 0:
+            blur = g.random(n) < r.blur_p
+            p.sigma[:] = np.where(blur, g.random(n) * (2.0 - 0.1) + 0.1, 0.0)      # utils/util_functions.py:105,114
         return p
+
+    def _fallback_box(self, hs, ws):
+        """RandomResizedCrop's fallback: the central crop with the aspect clamped into the allowed range."""
+        r = self.recipe
+        in_ratio = ws / hs
+        if in_ratio < r.crop_ratio[0]:
+            w, h = ws, int(round(ws / r.crop_ratio[0]))
+        elif in_ratio > r.crop_ratio[1]:
+            h, w = hs, int(round(hs * r.crop_ratio[1]))
+        else:
+            w, h = ws, hs
+        return (hs - h) // 2, (ws - w) // 2, h, w
 
     # ------------------------------------------------------------------------------------------ device work
     def apply(self, frames, params):
