@@ -93,6 +93,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline and cpu_baseline legs")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--input", default="float", choices=["float", "u8aug"],
+                    help="float: normalised float frames resident in HBM (the headline metric); u8aug: raw uint8 256x320 frames "
+                         "through the GPU input stage (MoCo-v2 recipe: resized crop, grayscale, colour jitter, flip, blur) "
+                         "inside the timed step")
     opt = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,7 +119,15 @@ def main():
     from vince_amd.solvers.vince_solver import VinceSolver
     from vince_amd._lib import lib
 
-    pool = PooledFrames(opt.batch, opt.size, opt.size, 1, device, pool=4, rank=rank, world=world)
+    if opt.input == "u8aug":
+        from vince_amd.data_source import AugmentedFrames
+        from vince_amd.utils import transforms as T
+        g = torch.Generator(device=device)
+        g.manual_seed(1000 + rank)
+        raw = torch.randint(0, 256, (4 * opt.batch, 256, 320, 3), dtype=torch.uint8, device=device, generator=g)
+        pool = AugmentedFrames(raw, T.MoCoV2ImagenetTransform(opt.size, seed=rank), opt.batch)
+    else:
+        pool = PooledFrames(opt.batch, opt.size, opt.size, 1, device, pool=4, rank=rank, world=world)
     args = make_args(backbone=opt.backbone, batch_size=opt.batch, vince_queue_size=opt.queue,
                      vince_embedding_size=opt.embed, vince_temperature=opt.temperature, compute_dtype=opt.dtype,
                      input_size=(opt.size, opt.size), base_lr=0.03, pytorch_gpu_ids=[local],
@@ -160,7 +172,9 @@ def main():
         "config": {"workload": "BASELINE config 3: %s %dx%d, B=%d per GPU, K=%d, D=%d, T=%g (MoCo-v2 mode), random init"
                                % (opt.backbone, opt.size, opt.size, opt.batch, opt.queue, opt.embed, opt.temperature),
                    "global_batch": opt.batch * world, "frames_per_step": 2 * opt.batch * world,
-                   "parallelism": "dp%d" % world, "final_loss": round(loss, 5)},
+                   "parallelism": "dp%d" % world, "final_loss": round(loss, 5),
+                   "input": ("float32 NCHW frames resident in HBM" if opt.input == "float" else
+                             "uint8 256x320 frames resident in HBM, GPU input stage (MoCoV2ImagenetTransform) inside the step")},
         "step_mfma_frac": round(whole_step_tflops / PEAK_TFLOPS[opt.dtype], 4),
         "step_tflops_per_gpu": round(whole_step_tflops, 2),
     }

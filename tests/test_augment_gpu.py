@@ -247,3 +247,19 @@ def test_solver_trains_on_augmented_uint8_frames():
     lb, tail_b = run(FloatTwin())
     assert all(np.isfinite(la)) and tail_a == tail_b == 48
     assert abs(la[0] - lb[0]) < 1e-4 * max(1.0, abs(lb[0])), (la, lb)
+
+
+def test_jigsaw_accepts_augmented_frames():
+    """The jigsaw side (vince_model.py:144-171) fed with a transform's handle == fed with the float tensor it stands for."""
+    from test_model_gpu import build, rel
+    from vince_amd.utils import transforms as T
+    _, model = build("ResNet18", 64, "fp32", 7, jigsaw=True)
+    t = T.JigsawTransform(66, seed=1)
+    u8 = t.apply(torch.from_numpy(_frames(4, 80, 96, 6)).to(DEV), t.draw(4, (80, 96)))
+    model.eval()
+    with torch.no_grad():
+        torch.manual_seed(3)
+        a = model.get_embeddings({"data": u8}, jigsaw=True)
+        torch.manual_seed(3)
+        b = model.get_embeddings({"data": u8.float_tensor()}, jigsaw=True)
+    assert rel(a["embeddings"].cpu(), b["embeddings"].cpu()) < 1e-6

@@ -37,12 +37,18 @@ class AugmentedFrames:
     ``transform``: an instance from ``vince_amd.utils.transforms``.  Each call takes the next ``batch_size`` frames of the pool
     and returns two independently augmented views -- query ``data`` and key ``queue_data`` -- as ``U8Frames`` handles."""
 
-    def __init__(self, pool, transform, batch_size, num_frames=1, data_source="SYN", iterations=None):
+    def __init__(self, pool, transform, batch_size, num_frames=1, data_source="SYN", iterations=None, side_stream=False):
         if pool.dtype != torch.uint8 or pool.dim() != 4 or pool.shape[-1] != 3:
             raise ValueError("AugmentedFrames: pool must be uint8 [P, Hs, Ws, 3]")
         self.pool, self.transform, self.batch_size = pool.contiguous(), transform, batch_size
         self.num_frames, self.data_source, self.iterations = num_frames, data_source, iterations
         self.count = 0
+        # side_stream: run the augmentation kernels on their own stream.  Off by default -- measured at BASELINE config 3 the
+        # three launches cost their 1.0 ms of device time when they sit on the consumer's stream (29.0 -> 30.0 ms/step) but
+        # 2.9 ms from a fifth concurrent stream (the step already keeps four busy; VINCE_AUG_STREAM=1 forces it on)
+        import os
+        side_stream = side_stream or os.environ.get("VINCE_AUG_STREAM", "0") == "1"
+        self._stream = torch.cuda.Stream(device=pool.device) if (side_stream and pool.is_cuda) else None
 
     def __call__(self, loader_id=0):
         if self.iterations is not None and self.count >= self.iterations:
@@ -54,6 +60,15 @@ class AugmentedFrames:
         import numpy as np
         src = np.concatenate([idx.numpy(), idx.numpy()]).astype(np.int64)
         params = self.transform.draw(2 * b, tuple(self.pool.shape[1:3]), src_index=src)
-        views = self.transform.apply(self.pool, params)
+        if self._stream is None:
+            views = self.transform.apply(self.pool, params)
+        else:
+            consumer = torch.cuda.current_stream(self.pool.device)
+            with torch.cuda.stream(self._stream):     # (a caller that refills `pool` must order that against this stream)
+                views = self.transform.apply(self.pool, params)
+            consumer.wait_stream(self._stream)          # device-side join, no host wait
+            for t in (views.frames, views.flip) + (views.blur or ()):
+                if t is not None:
+                    t.record_stream(consumer)
         return {"data": views[0:b], "queue_data": views[b:2 * b], "batch_type": "images", "batch_size": b,
                 "data_source": self.data_source, "num_frames": self.num_frames}

@@ -389,9 +389,10 @@ class VinceModel(BaseModel):
         """Returns (spatial, pooled, prenorm, embeddings).  data: float32 NCHW on the GPU."""
         self._require_gpu()
         u8 = data if isinstance(data, U8Frames) else None
+        if u8 is not None and jigsaw:
+            # the 3 x 3 tiling kernel reads float NCHW: materialise the tensor the handle stands for (same layout kernels)
+            data, u8 = u8.to(self._flat.device).float_tensor(), None
         if u8 is not None:
-            if jigsaw:
-                raise NotImplementedError("VinceModel: the uint8 input stage does not tile jigsaw inputs")
             u8 = u8.to(self._flat.device)
             n, (h, w) = u8.frames.shape[0], u8.size
         else:

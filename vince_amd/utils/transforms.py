@@ -193,21 +193,53 @@ class BatchTransform:
 
     # ------------------------------------------------------------------------------------------ device work
     def apply(self, frames, params):
-        """frames: uint8 [Ns, Hs, Ws, 3] on the GPU; params: AugmentParams -> U8Frames (uint8 [N, H, W, 3] + flip + blur)."""
+        """frames: uint8 [Ns, Hs, Ws, 3] on the GPU; params: AugmentParams -> U8Frames (uint8 [N, H, W, 3] + flip + blur).
+        All per-sample parameters cross PCIe as ONE pinned, asynchronous copy (a pageable copy would make the host wait for
+        the stream, i.e. for the previous training step)."""
         from .. import ops
         from ..models.vince_model import U8Frames
         dev = frames.device
-        box = torch.from_numpy(params.box).to(dev)
-        src = None if params.src_index is None else torch.from_numpy(params.src_index).to(dev)
-        img = ops.aug_resized_crop_u8(frames, box, self.size, src)
-        if (params.op >= 0).any():
-            ops.aug_color_u8(img, torch.from_numpy(params.op).to(dev), torch.from_numpy(params.factor).to(dev))
-        flip = torch.from_numpy(params.flip).to(dev) if params.flip.any() else None
-        blur = None
-        if (params.sigma > 0).any():
-            ks = blur_kernel_size(self.size[0])
-            blur = (blur_taps(params.sigma, ks).to(dev), torch.from_numpy((params.sigma > 0).astype(np.uint8)).to(dev))
-        return U8Frames(img, self.size, None, flip, blur=blur)
+        n = params.box.shape[0]
+        has_color = bool((params.op >= 0).any())
+        has_flip = bool(params.flip.any())
+        has_blur = bool((params.sigma > 0).any())
+        ks = blur_kernel_size(self.size[0])
+        parts = [("src", (params.src_index if params.src_index is not None else np.arange(n)).astype(np.int64)),
+                 ("box", params.box.astype(np.int32)), ("op", params.op.astype(np.int32)),
+                 ("factor", params.factor.astype(np.float32)),
+                 ("taps", blur_taps(params.sigma, ks).numpy() if has_blur else np.zeros((0, ks), np.float32)),
+                 ("flip", params.flip.astype(np.uint8)), ("do_blur", (params.sigma > 0).astype(np.uint8))]
+        sizes = [a.nbytes for _, a in parts]
+        offs = np.concatenate([[0], np.cumsum([(b + 7) // 8 * 8 for b in sizes])])
+        host = self._staging(int(offs[-1]))
+        hview = host.numpy()
+        for (name, a), o, b in zip(parts, offs, sizes):
+            hview[o:o + b] = a.reshape(-1).view(np.uint8)
+        blob = host.to(dev, non_blocking=True)
+        self._ring[self._ring_pos][1].record()          # the staging buffer is free again once this copy has run
+        d = {}
+        for (name, a), o, b in zip(parts, offs, sizes):
+            d[name] = blob[int(o):int(o) + b].view(torch.from_numpy(a[:0]).dtype).view(a.shape)
+        img = ops.aug_resized_crop_u8(frames, d["box"], self.size, None if params.src_index is None else d["src"])
+        if has_color:
+            ops.aug_color_u8(img, d["op"], d["factor"])
+        return U8Frames(img, self.size, None, d["flip"] if has_flip else None,
+                        blur=(d["taps"], d["do_blur"]) if has_blur else None)
+
+    def _staging(self, nbytes):
+        """A pinned host buffer from a small ring (allocated once: pinning memory synchronises the device), guarded by the
+        event of the copy that last read it."""
+        if getattr(self, "_ring", None) is None or self._ring[0][0].numel() < nbytes:
+            self._ring = [(torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory(), torch.cuda.Event())
+                          for _ in range(4)]
+            self._ring_pos = -1
+            self._ring_used = [False] * 4
+        self._ring_pos = (self._ring_pos + 1) % 4
+        buf, ev = self._ring[self._ring_pos]
+        if self._ring_used[self._ring_pos]:
+            ev.synchronize()
+        self._ring_used[self._ring_pos] = True
+        return buf[:nbytes]
 
     def apply_val(self, frames):
         """Resize((H / 0.875, W / 0.875), BILINEAR) + CenterCrop(size) (utils/transforms.py:78-88); the crop is taken by the
