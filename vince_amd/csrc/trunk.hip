@@ -683,7 +683,11 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // apply pass it removes); read per call so a test can switch it.  0 off, 1 every consumer, 2 only 1x1 consumers, 3 only 3x3
     const int xf_mode = getenv("VINCE_XF") ? atoi(getenv("VINCE_XF")) : 0;
     const bool fuse_xf = xf_mode != 0 && !save && !vince_profile_enabled();
-    static const bool ds_env_f = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0);
+    // The forward downsample conv on its own stream is OPT-IN (VINCE_DS_STREAM_FWD=1): worth 0.1 ms when it happens to share a
+    // hardware queue with another stream (GPU_MAX_HW_QUEUES=4, the default), but +4 ms when every stream gets its own queue
+    // (two overlapped encoders x two streams each thrash) -- the mapping depends on stream creation order, so it is not relied on.
+    static const bool ds_env_f = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0) &&
+                                 (getenv("VINCE_DS_STREAM_FWD") && atoi(getenv("VINCE_DS_STREAM_FWD")) != 0);
     const bool ds_side = ds_env_f && !vince_profile_enabled();
     if (ds_side && !t->ds_stream) {
         VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->ds_stream, hipStreamNonBlocking));
@@ -760,7 +764,8 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     }
     // the downsample branch of a stage-entry block only meets the main chain again at the block-input gradient: it runs on a
     // third stream (VINCE_DS_STREAM=0: inline on the main stream)
-    static const bool ds_env = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0);
+    static const bool ds_env = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0) &&
+                               !(getenv("VINCE_DS_STREAM_BWD") && atoi(getenv("VINCE_DS_STREAM_BWD")) == 0);
     const bool ds_overlap = overlap && ds_env;
     if (ds_overlap && !t->ds_stream) {
         VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->ds_stream, hipStreamNonBlocking));
