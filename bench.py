@@ -112,6 +112,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo" if one_gpu else "nccl")
+    elif os.environ.get("VINCE_FORCE_DP"):
+        # debug aid: a single-rank RCCL group, so that the bucketed all-reduce / key all-gather machinery (its streams and
+        # events) runs inside the measured step on a one-GPU box
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1)
     assert world == opt.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (opt.gpus, world)
     device = torch.device("cuda", local)
 
