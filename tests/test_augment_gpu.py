@@ -263,3 +263,32 @@ def test_jigsaw_accepts_augmented_frames():
         torch.manual_seed(3)
         b = model.get_embeddings({"data": u8.float_tensor()}, jigsaw=True)
     assert rel(a["embeddings"].cpu(), b["embeddings"].cpu()) < 1e-6
+
+
+def test_kernels_against_the_committed_pillow_fixture():
+    """tests/golden/g8_augment_pillow.npz: Pillow's own outputs (written by oracle/make_golden_augment.py) for crop + resize,
+    every enhance op, hue shifts, grayscale and a five-step chain -- the kernels must reproduce every byte."""
+    import os
+    from oracle import make_golden_augment as mg
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_augment_pillow.npz"))
+    ops = _ops()
+    img = torch.from_numpy(g["image"]).to(DEV)[None].contiguous()
+    for i, (box, (oh, ow)) in enumerate(zip(mg.BOXES, mg.SIZES)):
+        out = ops.aug_resized_crop_u8(img, torch.tensor([box], dtype=torch.int32, device=DEV), (oh, ow))[0].cpu().numpy()
+        assert np.array_equal(out, g["resized_crop_%d" % i]), i
+
+    def run(chain):
+        op = np.full((1, 5), -1, np.int32)
+        fac = np.zeros((1, 5), np.float32)
+        for j, (code, f) in enumerate(chain):
+            op[0, j], fac[0, j] = code, f
+        return ops.aug_color_u8(img.clone(), torch.from_numpy(op).to(DEV), torch.from_numpy(fac).to(DEV))[0].cpu().numpy()
+
+    for f in mg.FACTORS:
+        assert np.array_equal(run([(0, f)]), g["brightness_%g" % f]), f
+        assert np.array_equal(run([(1, f)]), g["contrast_%g" % f]), f
+        assert np.array_equal(run([(2, f)]), g["saturation_%g" % f]), f
+    for s in mg.SHIFTS:
+        assert np.array_equal(run([(3, float(s))]), g["hue_%d" % s]), s
+    assert np.array_equal(run([(4, 0.0)]), g["gray"])
+    assert np.array_equal(run(mg.CHAIN), g["chain"])

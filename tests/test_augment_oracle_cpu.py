@@ -135,3 +135,36 @@ def test_recipes_match_the_reference_class_list_and_draws_are_valid():
     t = T.StandardVideoTransform(224, seed=0)
     t.recipe = T.Recipe((4.0, 5.0))
     assert t._draw_box(100, 400) == (0, 133, 100, 133) or t._draw_box(100, 400)[2:] == (100, 133)
+
+
+def _g8():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_augment_pillow.npz"))
+
+
+def _hue_by_shift(img, shift):
+    hsv = ao.rgb_to_hsv_u8(img)
+    hsv[..., 0] = ((hsv[..., 0].astype(np.int32) + int(shift)) & 0xFF).astype(np.uint8)
+    return ao.hsv_to_rgb_u8(hsv)
+
+
+def test_oracle_against_the_committed_pillow_fixture():
+    """tests/golden/g8_augment_pillow.npz (oracle/make_golden_augment.py) holds Pillow's own outputs: this check does not
+    need Pillow where it runs."""
+    from oracle import make_golden_augment as mg
+    g = _g8()
+    img = g["image"]
+    assert np.array_equal(img, mg.seeded_image())
+    for i, ((top, left, ch, cw), (oh, ow)) in enumerate(zip(mg.BOXES, mg.SIZES)):
+        assert np.array_equal(ao.resized_crop_u8(img, top, left, ch, cw, oh, ow), g["resized_crop_%d" % i]), i
+    for f in mg.FACTORS:
+        assert np.array_equal(ao.adjust_brightness(img, f), g["brightness_%g" % f])
+        assert np.array_equal(ao.adjust_contrast(img, f), g["contrast_%g" % f])
+        assert np.array_equal(ao.adjust_saturation(img, f), g["saturation_%g" % f])
+    for s in mg.SHIFTS:
+        assert np.array_equal(_hue_by_shift(img, s), g["hue_%d" % s])
+    assert np.array_equal(ao.to_grayscale3(img), g["gray"])
+    cur = img
+    for code, f in mg.CHAIN:
+        cur = _hue_by_shift(cur, f) if code == 3 else ao.color_chain(cur, [(code, f)])
+    assert np.array_equal(cur, g["chain"])
