@@ -311,6 +311,11 @@ def main():
                                "flops_per_launch": round(k["tflops"] * 1e12 * k["avg_us"] * 1e-6),
                                "avg_us": k["avg_us"], "launches_per_step": k["launches_per_step"],
                                "ms_per_step": k["ms_per_step"], "longest_kernel_family": dom}
+            if traffic:
+                # the same kernel against the HBM roof ("HBM is the secondary bound and must be reported
+                # alongside"): measured bytes per launch / measured duration
+                gbs = traffic / (k["avg_us"] * 1e-6) / 1e9
+                out["roofline"]["hbm"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
         out["kernels"] = kernels
         # ---- cpu_baseline leg ----------------------------------------------------------------------------------------
         try:
