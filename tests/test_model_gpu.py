@@ -571,3 +571,54 @@ def test_cpu_model_forward_raises():
     model = VinceModel(make_args())
     with pytest.raises(RuntimeError):
         model.get_embeddings({"data": torch.randn(2, 3, 64, 64)})
+
+
+def test_imagenet_side_decoders_train_beside_the_contrastive_loss():
+    """vince_model.py:79-90,244-248,282-288,344-348: with --use-imagenet two linear probes read DETACHED pooled features of
+    "IN" batches; their cross-entropy joins the loss dict, their accuracy the metrics, their weights train, and the encoder's
+    trajectory is untouched by them."""
+    from vince_amd.config import make_args
+    from vince_amd.data_source import SyntheticFrames
+    from vince_amd.solvers.vince_solver import VinceSolver
+
+    class Labelled(SyntheticFrames):
+        labelled = True
+
+        def __call__(self, loader_id=0):
+            b = super().__call__(loader_id)
+            if self.labelled:     # (like the reference, an "IN" batch without --use-imagenet is an error: vince_model.py:244-246)
+                b["data_source"] = "IN"
+                b["imagenet_labels"] = (torch.arange(self.batch_size, device=self.device) * 37) % 1000
+            return b
+
+    def run(use_imagenet):
+        torch.manual_seed(0)
+        src = Labelled(16, 64, 64, 1, device=DEV, seed=5)
+        src.labelled = use_imagenet
+        args = make_args(backbone="ResNet18", batch_size=16, vince_queue_size=64, input_size=(64, 64), compute_dtype="fp32",
+                         use_imagenet=use_imagenet, batch_source=src)
+        solver = VinceSolver(args)
+        sd = vo.seeded_state(vo.model_spec("ResNet18", 64), 2)
+        solver.model.load_state_dict(sd, strict=False)
+        solver.queue_model.queue_network.load_state_dict(sd, strict=False)
+        solver.vince_queue.vector_queue.copy_(torch.nn.functional.normalize(
+            torch.randn(64, 64, generator=torch.Generator().manual_seed(1)), dim=1))
+        solver.reset_epoch()
+        w0 = [p.detach().clone() for p in solver.model.imagenet_decoders.parameters()] if use_imagenet else None
+        out = [solver.run_train_iteration() for _ in range(2)]
+        return solver, out, w0
+
+    s1, o1, w0 = run(True)
+    s0, o0, _ = run(False)
+    for (l1, m1), (l0, m0) in zip(o1, o0):
+        assert {"imagenet_loss_0", "imagenet_loss_1"} <= set(l1) and "imagenet_loss_0" not in l0
+        assert {"imagenet_accuracy_0", "imagenet_accuracy_1"} <= set(m1)
+        for k in ("imagenet_loss_0", "imagenet_loss_1"):
+            v = float(l1[k].detach())
+            assert np.isfinite(v) and 5.0 < v < 9.0          # ~ln(1000) for an untrained probe
+        assert abs(float(l1["nce_loss"].detach()) - float(l0["nce_loss"].detach())) < 1e-5
+    moved = [float((p.detach() - w).abs().max()) for p, w in zip(s1.model.imagenet_decoders.parameters(), w0)]
+    assert all(m > 0 for m in moved)
+    # the probes see detached features: encoder parameters evolve exactly as without them
+    assert rel(s1.model._flat[:s1.model._n_train].cpu(), s0.model._flat[:s0.model._n_train].cpu()) < 1e-4
+    assert {"imagenet_loss_0", "imagenet_loss_1"} <= set(s1.model.loss(None)) and "imagenet_accuracy_1" in s1.model.get_metrics(None)
