@@ -240,7 +240,7 @@ class VinceSolver(BaseSolver):
         if on_gpu and self.overlap_key_encoder:
             main = torch.cuda.current_stream()
             if self._key_stream is None:
-                self._key_stream = torch.cuda.Stream()
+                self._key_stream = torch.cuda.Stream(priority=int(os.environ.get("VINCE_KEY_PRIO", "0")))
             self._key_stream.wait_stream(main)
             with torch.cuda.stream(self._key_stream):
                 queue_batches, gathered_keys = self._encode_keys(image_batch_concat, jig_key)
