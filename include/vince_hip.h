@@ -45,6 +45,12 @@ int vince_abi_version(void);
  * 5 = conv_wgrad bf16.  collect() synchronises, returns per-tag total milliseconds / algorithmic FLOPs / launches and
  * clears the log.  Not for production runs (one event pair per launch). */
 int vince_profile_enable(int on);
+/* How many streams of its own the trunk engine may use beside the caller's: 2 (default) = weight gradients + the backward of
+ * the downsample branch, 1 = weight gradients only, 0 = everything on the caller's stream.  This runtime serves at most
+ * GPU_MAX_HW_QUEUES (4) hardware queues; streams beyond that share queues in creation order and serialise against each
+ * other, so a host that brings streams of its own (a key-encoder stream, an RCCL communicator) lowers the engine's share:
+ * the data-parallel solver sets 1.  Process-wide; call before the first backward. */
+int vince_set_side_streams(int32_t n);
 int vince_profile_collect(int32_t ntags, double* ms, double* flops, int64_t* count);
 
 /* ---------------------------------------------------------------------------------------------

@@ -462,6 +462,8 @@ def test_bucketed_allreduce_machinery_single_rank():
     finally:
         os.environ.pop("VINCE_FORCE_DP", None)
         dist.destroy_process_group()
+        from vince_amd._lib import lib
+        lib().vince_set_side_streams(2)      # the data-parallel solver lowered the engine's stream budget process-wide
     assert not r0 and r1
     # (two steps only: fp32 atomics make weight gradients order-dependent in the last bits and a freshly initialised
     # encoder amplifies that chaotically from the third step on)

@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // ---------------------------------------------------------------------------------------------
 void vince_set_error(const char* fmt, ...);
 bool vince_profile_enabled();
+int vince_side_stream_budget();   // vince_set_side_streams(): 2 = wgrad + downsample streams, 1 = wgrad only, 0 = none
 void vince_profile_begin_launch(int tag, double work, void* stream, void** token);
 void vince_profile_end_launch(void* token, void* stream);
 void vince_profile_set_tag(void* token, int tag);

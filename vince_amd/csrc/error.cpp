@@ -55,6 +55,14 @@ void vince_profile_end_launch(void* token, void* stream) {
     hipEventRecord(g_prof[idx].b, (hipStream_t)stream);
 }
 
+static int g_side_streams = 2;
+int vince_side_stream_budget() { return g_side_streams; }
+
+extern "C" int vince_set_side_streams(int32_t n) {
+    g_side_streams = n < 0 ? 0 : (n > 2 ? 2 : n);
+    return 0;
+}
+
 extern "C" int vince_profile_enable(int on) {
     g_prof_on = on != 0;
     return 0;

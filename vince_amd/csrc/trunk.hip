@@ -688,7 +688,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // (two overlapped encoders x two streams each thrash) -- the mapping depends on stream creation order, so it is not relied on.
     static const bool ds_env_f = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0) &&
                                  (getenv("VINCE_DS_STREAM_FWD") && atoi(getenv("VINCE_DS_STREAM_FWD")) != 0);
-    const bool ds_side = ds_env_f && !vince_profile_enabled();
+    const bool ds_side = ds_env_f && !vince_profile_enabled() && vince_side_stream_budget() >= 2;
     if (ds_side && !t->ds_stream) {
         VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->ds_stream, hipStreamNonBlocking));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_start, hipEventDisableTiming));
@@ -752,7 +752,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     // that read it has finished (ev_wg), and a wgrad starts when its dY is complete (ev_dy).
     // (per-kernel event timing wants kernels to run alone: overlap is off while vince_profile_enable(1) is in effect)
     static const bool overlap_env = !(getenv("VINCE_WGRAD_STREAM") && atoi(getenv("VINCE_WGRAD_STREAM")) == 0);
-    const bool overlap = overlap_env && !vince_profile_enabled();
+    const bool overlap = overlap_env && !vince_profile_enabled() && vince_side_stream_budget() >= 1;
     hipStream_t main_s = (hipStream_t)stream;
     if (overlap && !t->side) {
         // The weight gradients are off the critical path (the chain of dgrad / BatchNorm launches on the caller's stream):
@@ -775,7 +775,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     // third stream (VINCE_DS_STREAM=0: inline on the main stream)
     static const bool ds_env = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0) &&
                                !(getenv("VINCE_DS_STREAM_BWD") && atoi(getenv("VINCE_DS_STREAM_BWD")) == 0);
-    const bool ds_overlap = overlap && ds_env;
+    const bool ds_overlap = overlap && ds_env && vince_side_stream_budget() >= 2;
     if (ds_overlap && !t->ds_stream) {
         VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->ds_stream, hipStreamNonBlocking));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_start, hipEventDisableTiming));

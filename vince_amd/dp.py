@@ -49,12 +49,15 @@ def bucket_plan(model, arch_layers):
 class GradientReducer:
     """Bucketed all-reduce of VinceModel's flat gradient buffer, overlapped with the rest of backward."""
 
-    def __init__(self, model, arch_layers):
+    def __init__(self, model, arch_layers, comm_stream=None):
+        """comm_stream: the stream the bucket all-reduces are enqueued on (each waits for its bucket's event there).  The
+        solver passes its key-encoder stream, which is idle during backward: one stream fewer competing for the runtime's
+        four hardware queues."""
         self.model = model
         self.plan = bucket_plan(model, arch_layers)
         self.on_gpu = model._flat.is_cuda
         if self.on_gpu:
-            self.comm_stream = torch.cuda.Stream()
+            self.comm_stream = comm_stream if comm_stream is not None else torch.cuda.Stream()
             self.events = [torch.cuda.Event() for _ in self.plan]
             for ev in self.events:
                 ev.record()          # torch creates the underlying hipEvent lazily; the engine needs a live handle

@@ -89,7 +89,17 @@ class VinceSolver(BaseSolver):
         w, _ = dp.world()
         if w > 1 or (os.environ.get("VINCE_FORCE_DP") and torch.distributed.is_initialized()):
             # (VINCE_FORCE_DP exercises the bucketed all-reduce machinery with a single-rank process group)
-            self.reducer = dp.GradientReducer(self.model, ARCH_LAYERS[self.model.feature_extractor.arch])
+            comm = None
+            if self.model.device.type == "cuda":
+                # stream budget (include/vince_hip.h vince_set_side_streams): main, key encoder (= gradient all-reduce during
+                # backward), weight gradients, RCCL's own -- the downsample-branch stream gives its hardware queue away
+                from .._lib import lib
+                lib().vince_set_side_streams(1)
+                if self.overlap_key_encoder:
+                    with torch.cuda.device(self.model.device):
+                        self._key_stream = torch.cuda.Stream()
+                    comm = self._key_stream
+            self.reducer = dp.GradientReducer(self.model, ARCH_LAYERS[self.model.feature_extractor.arch], comm_stream=comm)
             self.optimizer.grad_scale = 1.0 / w
         self.print_optimizer()
 
@@ -240,7 +250,7 @@ class VinceSolver(BaseSolver):
         if on_gpu and self.overlap_key_encoder:
             main = torch.cuda.current_stream()
             if self._key_stream is None:
-                self._key_stream = torch.cuda.Stream(priority=int(os.environ.get("VINCE_KEY_PRIO", "0")))
+                self._key_stream = torch.cuda.Stream()
             self._key_stream.wait_stream(main)
             with torch.cuda.stream(self._key_stream):
                 queue_batches, gathered_keys = self._encode_keys(image_batch_concat, jig_key)
