@@ -17,3 +17,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -d $O/pmc_mf
 M=$(find $O/pmc_mfma -name '*.db' | head -1); timeout 60 python tools/pmc_mfma.py $M > $O/pmc_mfma_util.txt 2>&1
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_mfma
 cat $O/pmc_summary.txt | head -12
+# GPU input stage: kernel stats of 512 MoCo-v2 views + the step fed from raw uint8 frames
+bash tools/aug_profile.sh > /dev/null 2>&1; cp gpurun_out/aug_kstats.txt $O/input_stage_kernel_stats.txt
+timeout 300 python bench.py --no-extras --input u8aug > $O/bench_u8aug.json 2>/dev/null
+timeout 20 python tools/bench_brief.py $O/bench_u8aug.json u8aug
