@@ -131,3 +131,28 @@ def test_gradient_bucket_plan_partitions_the_flat_buffer():
         # buckets come in the order backward finishes them: layer4 (+heads) first, stem/layer1 last
         assert [blk for blk, _, _ in plan] == [sum(layers[:3]), sum(layers[:2]), layers[0], None]
         assert plan[0][2] - plan[0][1] > plan[-1][2] - plan[-1][1]
+
+
+def test_loader_output_to_batch_dict_layouts():
+    """vince_solver.py:180-224: how loader output becomes the batch dict the step reads -- frames of one clip / views of one
+    image on consecutive rows, labels repeated per frame (-1 for video)."""
+    import torch
+    from vince_amd.solvers.vince_solver import VinceSolver
+    clips, F = 3, 4
+    data = torch.arange(clips * F * 3 * 2 * 2, dtype=torch.float32).view(clips, F, 3, 2, 2)
+    b = VinceSolver.process_video_data({"data": data, "queue_data": data + 1000}, F)
+    assert b["data"].shape == (clips * F, 3, 2, 2) and b["batch_size"] == clips * F and b["batch_type"] == "video"
+    assert torch.equal(b["data"][1 * F + 2], data[1, 2]) and torch.equal(b["queue_data"][2 * F + 3], data[2, 3] + 1000)
+    assert b["data_source"] == "YT" and b["num_frames"] == F and (b["imagenet_labels"] == -1).all()
+    B = 5
+    views = [torch.full((B, 3, 2, 2), float(v)) + torch.arange(B).view(B, 1, 1, 1) * 100 for v in range(2 * F)]
+    labels = torch.arange(B) * 7
+    s = VinceSolver.process_imagenet_data((views, labels), F)
+    assert s["data"].shape == (B * F, 3, 2, 2) and s["data_source"] == "IN" and s["batch_type"] == "images"
+    for img in range(B):
+        for f in range(F):
+            assert float(s["data"][img * F + f, 0, 0, 0]) == f + img * 100
+            assert float(s["queue_data"][img * F + f, 0, 0, 0]) == F + f + img * 100
+    assert torch.equal(s["imagenet_labels"], labels.repeat_interleave(F))
+    one = VinceSolver.process_imagenet_data(([views[0], views[1]], labels), 1)
+    assert one["data"] is views[0] and one["queue_data"] is views[1] and one["batch_size"] == B

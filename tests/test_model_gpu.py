@@ -624,3 +624,26 @@ def test_imagenet_side_decoders_train_beside_the_contrastive_loss():
     # the probes see detached features: encoder parameters evolve exactly as without them
     assert rel(s1.model._flat[:s1.model._n_train].cpu(), s0.model._flat[:s0.model._n_train].cpu()) < 1e-4
     assert {"imagenet_loss_0", "imagenet_loss_1"} <= set(s1.model.loss(None)) and "imagenet_accuracy_1" in s1.model.get_metrics(None)
+
+
+def test_fill_queue_with_distinct_batches():
+    """vince_solver.py:293-313 `fill_queue`: K rows from as many different batches as needed; with K not a multiple of the
+    batch the last enqueue wraps (storage_queue.py:35-43), so the queue is full and the tail sits at the overshoot."""
+    from vince_amd.config import make_args
+    from vince_amd.data_source import SyntheticFrames
+    from vince_amd.solvers.vince_solver import VinceSolver
+    args = make_args(backbone="ResNet18", batch_size=16, vince_queue_size=40, input_size=(64, 64), compute_dtype="fp32",
+                     batch_source=SyntheticFrames(16, 64, 64, 1, device=DEV, seed=5))
+    solver = VinceSolver(args)
+    solver.model.load_state_dict(vo.seeded_state(vo.model_spec("ResNet18", 64), 2))
+    solver.reset_epoch()
+    solver.fill_queue()
+    q = solver.vince_queue
+    assert q.full and q.current_tail == 8 and len(q) == 40
+    rows = q.dequeue()["queue_vectors"].cpu()
+    assert np.allclose(rows.norm(dim=1).numpy(), 1.0, atol=1e-5)
+    # three different batches went in: rows written by batch 2 (8..15 kept from batch 0? no -- overwritten) differ from batch 1's
+    assert not torch.allclose(rows[0:8], rows[16:24])
+    # the key encoder is a hard copy of the encoder after the fill (param_update(model, 0))
+    n = solver.model._n_ema
+    assert torch.equal(solver.queue_model.queue_network._flat[:n], solver.model._flat[:n])

@@ -157,6 +157,48 @@ class VinceSolver(BaseSolver):
         self.vince_queue.full = False
         print("Queue filled with repeats")
 
+    def fill_queue(self):
+        """vince_solver.py:293-313: the other way to warm the queue -- keys of as many DIFFERENT batches as it takes to write
+        K rows (the last batch may wrap the ring, so the queue ends up full with the tail wherever the overshoot left it)."""
+        self.queue_model.param_update(self.model, 0)
+        self.vince_queue.clear()
+        written = 0
+        print("Filling queue")
+        with torch.no_grad():
+            while written < self.vince_queue.maxsize:
+                concat, parts = self.get_batch()
+                for part, out in zip(parts, self.queue_model(concat)):
+                    keys = dp.gather_keys(out["queue_embeddings"])
+                    self.vince_queue.enqueue(keys, part.get("queue_data_cpu"), part["data_source"])
+                    written += keys.shape[0]
+                    if written >= self.vince_queue.maxsize:
+                        break
+        print("Queue filled")
+
+    # ------------------------------------------------------------------------------------------ loader output -> batch dict
+    @staticmethod
+    def process_video_data(batch, num_frames):
+        """vince_solver.py:212-224: a video loader hands over [clips, frames, 3, H, W] for `data` and `queue_data`; the path
+        wants the frames of a clip as consecutive rows (row c * F + f), no labels."""
+        data, queue_data = (batch[k].flatten(0, 1) for k in ("data", "queue_data"))
+        n = data.shape[0]
+        return {"data": data, "queue_data": queue_data, "data_source": "YT", "batch_type": "video", "batch_size": n,
+                "num_frames": num_frames, "imagenet_labels": torch.full((n,), -1, dtype=torch.int64)}
+
+    @staticmethod
+    def process_imagenet_data(sample, num_frames):
+        """vince_solver.py:180-200: (list of 2F augmented views [B, 3, H, W] each, labels [B]) -> views 0..F-1 are the query
+        frames, F..2F-1 the key frames, interleaved per image (row b * F + f); labels repeated per frame."""
+        views, labels = sample
+        q, k = views[:num_frames], views[num_frames:]
+        if num_frames > 1:
+            data, queue_data = torch.stack(q, dim=1).flatten(0, 1), torch.stack(k, dim=1).flatten(0, 1)
+            labels = labels.repeat_interleave(num_frames)
+        else:
+            data, queue_data = q[0], k[0]
+        return {"data": data, "queue_data": queue_data, "imagenet_labels": labels, "data_source": "IN",
+                "num_frames": num_frames, "batch_type": "images", "batch_size": data.shape[0]}
+
     def reset_epoch(self):
         super(VinceSolver, self).reset_epoch()
         self.queue_model.train()   # the key encoder never leaves train mode (vince_solver.py:337)
