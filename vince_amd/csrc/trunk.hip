@@ -686,9 +686,12 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // The forward downsample conv on its own stream is OPT-IN (VINCE_DS_STREAM_FWD=1): worth 0.1 ms when it happens to share a
     // hardware queue with another stream (GPU_MAX_HW_QUEUES=4, the default), but +4 ms when every stream gets its own queue
     // (two overlapped encoders x two streams each thrash) -- the mapping depends on stream creation order, so it is not relied on.
-    static const bool ds_env_f = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0) &&
-                                 (getenv("VINCE_DS_STREAM_FWD") && atoi(getenv("VINCE_DS_STREAM_FWD")) != 0);
-    const bool ds_side = ds_env_f && !vince_profile_enabled() && vince_side_stream_budget() >= 2;
+    static const int ds_fwd_mode = (getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0) ? 0
+                                   : (getenv("VINCE_DS_STREAM_FWD") ? atoi(getenv("VINCE_DS_STREAM_FWD")) : 0);
+    // mode 2: only a handle that already owns a downsample stream from an earlier backward (the query encoder's) uses it in
+    // forward too -- no stream is created for it, the key encoder stays inline
+    const bool ds_side = (ds_fwd_mode == 1 || (ds_fwd_mode == 2 && save && t->ds_stream)) && !vince_profile_enabled() &&
+                         vince_side_stream_budget() >= 2;
     if (ds_side && !t->ds_stream) {
         VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->ds_stream, hipStreamNonBlocking));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_start, hipEventDisableTiming));
