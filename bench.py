@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline and cpu_baseline legs")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--mode", default="moco", choices=["moco", "vince"],
+                    help="moco: BASELINE config 3 (the headline); vince: config 5's per-GPU work -- 4 frames per clip, inter-batch + "
+                         "self-batch comparison (self T 0.03) and the jigsaw head on one side per step")
     ap.add_argument("--input", default="float", choices=["float", "u8aug"],
                     help="float: normalised float frames resident in HBM (the headline metric); u8aug: raw uint8 256x320 frames "
                          "through the GPU input stage (MoCo-v2 recipe: resized crop, grayscale, colour jitter, flip, blur) "
@@ -134,14 +137,18 @@ def main():
         raw = torch.randint(0, 256, (4 * opt.batch, 256, 320, 3), dtype=torch.uint8, device=device, generator=g)
         pool = AugmentedFrames(raw, T.MoCoV2ImagenetTransform(opt.size, seed=rank), opt.batch)
     else:
-        pool = PooledFrames(opt.batch, opt.size, opt.size, 1, device, pool=4, rank=rank, world=world)
+        pool = PooledFrames(opt.batch, opt.size, opt.size, 4 if opt.mode == "vince" else 1, device, pool=4, rank=rank, world=world)
     args = make_args(backbone=opt.backbone, batch_size=opt.batch, vince_queue_size=opt.queue,
                      vince_embedding_size=opt.embed, vince_temperature=opt.temperature, compute_dtype=opt.dtype,
                      input_size=(opt.size, opt.size), base_lr=0.03, pytorch_gpu_ids=[local],
                      feature_extractor_gpu_ids=[local], batch_source=pool, log_frequency=10 ** 9,
-                     iterations_per_epoch=10 ** 9)
+                     iterations_per_epoch=10 ** 9,
+                     **(dict(num_frames=4, inter_batch_comparison=True, self_batch_comparison=True, jigsaw=True,
+                             vince_self_temperature=0.03) if opt.mode == "vince" else {}))
     import contextlib
     import io
+    import random
+    random.seed(1234 + rank)      # the per-step jigsaw side coin (vince_solver.py:397-403) is part of the workload: pin it
     with contextlib.redirect_stdout(io.StringIO() if rank != 0 else sys.stderr):
         solver = VinceSolver(args)
         solver.reset_epoch()
@@ -176,7 +183,10 @@ def main():
         "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": opt.dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE config 3: %s %dx%d, B=%d per GPU, K=%d, D=%d, T=%g (MoCo-v2 mode), random init"
+        "config": {"workload": ("BASELINE config 3: %s %dx%d, B=%d per GPU, K=%d, D=%d, T=%g (MoCo-v2 mode), random init"
+                                if opt.mode == "moco" else
+                                "BASELINE config 5 per-GPU work: %s %dx%d, B=%d frames (4 per clip) per GPU, K=%d, D=%d, T=%g, "
+                                "inter-batch + self-batch comparison, jigsaw side, random init")
                                % (opt.backbone, opt.size, opt.size, opt.batch, opt.queue, opt.embed, opt.temperature),
                    "global_batch": opt.batch * world, "frames_per_step": 2 * opt.batch * world,
                    "parallelism": "dp%d" % world, "final_loss": round(loss, 5),

@@ -293,6 +293,9 @@ int vince_aug_blur_to_rows(int dtype, const uint8_t* img, const uint8_t* flip, c
  * [Ci][T][Co] (dtype). */
 int vince_prepare_weight(int dtype, const float* w, void* wk, void* wt, int32_t Co, int32_t T, int32_t Ci,
                          int32_t Cip, void* stream);
+/* out[cols][rows] = transpose of in[rows][cols] (fp32; the input-gradient copy W^T of an nn.Linear weight, vince_model.py:38-49:
+ * made on demand by the host, only for heads whose backward actually runs). */
+int vince_transpose_f32(const float* in, float* out, int32_t rows, int32_t cols, void* stream);
 /* The same for many layers in ONE launch; `table_dev` is a device array of n entries. */
 typedef struct vince_prep_entry {
     const void* w; /* float [Co][T][Ci] */

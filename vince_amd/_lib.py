@@ -91,6 +91,7 @@ PROTOTYPES = {
     "vince_aug_blur_to_rows": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, P(c_float), P(c_float), c_void_p,
                                        c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "vince_prepare_weight": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "vince_transpose_f32": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "vince_prepare_weights_batched": (c_int, [c_int, c_void_p, c_int32, c_void_p]),
     "vince_nhwc_to_nchw_f32": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "vince_l2norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),

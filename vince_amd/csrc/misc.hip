@@ -383,6 +383,34 @@ extern "C" int vince_prepare_weight(int dtype, const float* w, void* wk, void* w
     return VINCE_OK;
 }
 
+namespace {
+// out[c][r] = in[r][c] through a padded 64 x 64 LDS tile: both sides move 256-byte row segments
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        tile[ty + 4 * i][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[tx][ty + 4 * i];
+    }
+}
+}  // namespace
+
+extern "C" int vince_transpose_f32(const float* in, float* out, int32_t rows, int32_t cols, void* stream) {
+    VINCE_CHECK_ARG(in && out && rows > 0 && cols > 0, VINCE_E_ARG, "vince_transpose_f32: bad arguments");
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, out,
+                       rows, cols);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
 extern "C" int vince_prepare_weights_batched(int dtype, const vince_prep_entry* table_dev, int32_t n, void* stream) {
     DTYPE_OK("vince_prepare_weights_batched");
     VINCE_CHECK_ARG(table_dev && n > 0, VINCE_E_ARG, "vince_prepare_weights_batched: bad arguments");

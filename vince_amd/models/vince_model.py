@@ -119,6 +119,20 @@ def _compute_dtype(args):
     raise ValueError("compute_dtype must be bf16 or fp32, got %r" % name)
 
 
+class _TransposedHeads(dict):
+    """W^T of the head Linears for their input gradients, made on first use after every parameter update: a model that never
+    runs backward (the key encoder) or a head the step does not touch (the jigsaw head in MoCo mode, 151 MB) costs nothing."""
+
+    def __init__(self, params):
+        super().__init__()
+        self._params = {id(p): p for p in params if p.dim() == 2}
+
+    def __missing__(self, key):
+        wt = ops.transpose_f32(self._params[key].data)
+        self[key] = wt
+        return wt
+
+
 class LazySimilarities:
     """Stand-in for the reference's ``vince_similarities`` tensor: shape is known, values are produced on demand."""
 
@@ -369,11 +383,7 @@ class VinceModel(BaseModel):
             self._wcache = torch.empty(trunk.wc_bytes, dtype=torch.uint8, device=self._flat.device)
         if self._wcache_version != self._param_version:
             trunk.prepare_weights(self._param_ptrs, self._wcache)
-            self._head_t = {}
-            for p in self._head_params:
-                if p.dim() == 2:
-                    self._head_t[id(p)] = ops.prepare_weight(p.data.view(p.shape[0], 1, p.shape[1]), torch.float32)[1].view(
-                        p.shape[1], p.shape[0])
+            self._head_t = _TransposedHeads(self._head_params)
             self._wcache_version = self._param_version
 
     def _ensure_folded_weights(self, trunk):

@@ -362,6 +362,15 @@ def prepare_weight(w_master, dtype, cip=None, want_transposed=True):
     return wk, wt
 
 
+def transpose_f32(x):
+    """fp32 [R, C] -> [C, R] (LDS-tiled)."""
+    require_gpu(x)
+    r, c = x.shape
+    out = torch.empty(c, r, device=x.device, dtype=torch.float32)
+    check(lib().vince_transpose_f32(_ptr(x.contiguous()), _ptr(out), r, c, stream_ptr()))
+    return out
+
+
 def nhwc_to_nchw_f32(x):
     require_gpu(x)
     N, H, W, C = x.shape
