@@ -6,6 +6,10 @@ timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 20 python tools/bench_brief.py $O/bench.json bench
 timeout 600 rocprofv3 --kernel-trace -d $O/kt -o kt -- python bench.py --no-extras > $O/kt.log 2>&1
 DB=$(find $O/kt -name '*.db' | head -1); timeout 60 python tools/rocpd_stats.py $DB 45 > $O/kernel_stats.txt 2>&1; rm -rf $O/kt
+# the same with every stream serialised (one kernel at a time, like the instrumented steps behind bench.py's `roofline`): the
+# per-kernel average durations of THIS file are the ones that agree with roofline.avg_us
+VINCE_OVERLAP_KEY=0 VINCE_WGRAD_STREAM=0 VINCE_DS_STREAM=0 timeout 600 rocprofv3 --kernel-trace -d $O/kts -o kt -- python bench.py --no-extras > $O/kts.log 2>&1
+DB=$(find $O/kts -name '*.db' | head -1); timeout 60 python tools/rocpd_stats.py $DB 45 > $O/kernel_stats_serialised.txt 2>&1; rm -rf $O/kts
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --steps 2 --warmup 1 --no-extras > $O/pmc_$C.log 2>&1
 done
