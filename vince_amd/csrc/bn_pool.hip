@@ -668,6 +668,14 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 }
 
 // workgroups per element-wise BatchNorm launch (VINCE_BN_BLOCKS: measurement knob)
+inline int bn_bwd_target_blocks() {
+    // bn_bwd_apply opens with the replica fold + seven per-channel constant vectors: ~3 us of dependent L2 latency per
+    // workgroup before the first row moves.  Half as many, twice as long workgroups than the forward apply: -0.4 ms/step
+    // (swept 512..3072; the forward apply stays best at 2048).
+    static const int n = getenv("VINCE_BN_BWD_BLOCKS") ? atoi(getenv("VINCE_BN_BWD_BLOCKS")) : 1024;
+    return n;
+}
+
 inline int bn_target_blocks() {
     static const int n = getenv("VINCE_BN_BLOCKS") ? atoi(getenv("VINCE_BN_BLOCKS")) : 2048;   // swept 1024..16384: 1536-2048 best
     return n;
@@ -782,7 +790,7 @@ extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_sr
     VINCE_CHECK_ARG(dz && y && mean && invstd && gamma && sums && dy && rows > 0 && count > 0, VINCE_E_ARG,
                     "vince_bn_bwd_apply: bad arguments");
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_bwd_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
-    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_target_blocks());
+    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_bwd_target_blocks());
     dim3 grid(w.colgroups, w.rowblocks);
     const double inv_count = 1.0 / (double)count;
     if (dtype == VINCE_F32)
