@@ -296,7 +296,10 @@ __global__ void bn_bwd_fold_kernel(double* sums, int C, float* dgamma, float* db
     if (dbeta) dbeta[c] += (float)sg;
 }
 
-template <typename T>
+#ifndef BWD_APPLY_ROWS
+#define BWD_APPLY_ROWS 2
+#endif
+template <typename T, bool R2>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const MaskArgs msk,
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
@@ -330,9 +333,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
     const int col = blockIdx.x * w.tpc + (threadIdx.x % w.tpc);
     const bool cv = col < w.cpr;
-    const T* __restrict__ y2 = (const T*)r2.y;
+    const T* __restrict__ y2 = R2 ? (const T*)r2.y : nullptr;
     if (!cv && !y2) return;
-    float mu[CH], is[CH], k1[CH], ma[CH], mb[CH], msc[CH], msh[CH];
+    // dx = k1 * (g - ma - (y - mu) * is * mb) as ca * g + cb * y + cc: three constants per channel in registers instead of
+    // five (register count decides how many workgroups stay resident)
+    float ca[CH], cb[CH], cc[CH], msc[CH], msh[CH];
     // second reduction (r2): the downsample BatchNorm of the same block consumes the SAME masked gradient g -- its
     // (sum g, sum g*xhat) is accumulated here, on the g this pass has in registers, instead of a separate pass over dz
     float mu2[CH], is2[CH], sg2[CH], sgx2[CH];
@@ -341,18 +346,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const int c = col * CH + e, cl = (threadIdx.x % w.tpc) * CH + e;
         msc[e] = (cv && msk.scale) ? msk.scale[c] : 0.f;
         msh[e] = (cv && msk.scale) ? msk.shift[c] : 0.f;
-        mu[e] = cv ? mean[c] : 0.f;
-        is[e] = cv ? invstd[c] : 0.f;
-        k1[e] = cv ? gamma[c] * is[e] : 0.f;
-        ma[e] = fold[0][cl];
-        mb[e] = fold[1][cl];
+        {
+            const float mu = cv ? mean[c] : 0.f, is = cv ? invstd[c] : 0.f;
+            const float k1 = cv ? gamma[c] * is : 0.f;
+            ca[e] = k1;
+            cb[e] = -k1 * is * fold[1][cl];
+            cc[e] = -k1 * fold[0][cl] - cb[e] * mu;
+        }
         mu2[e] = (cv && y2) ? r2.mean[c] : 0.f;
         is2[e] = (cv && y2) ? r2.invstd[c] : 0.f;
         sg2[e] = sgx2[e] = 0.f;
     }
     const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + threadIdx.x / w.tpc;
     const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
-    constexpr int U = 4;
+    constexpr int U = BWD_APPLY_ROWS;
     if (cv)
         for (int64_t rb = r0; rb < r1; rb += (int64_t)U * w.rpp) {
             uint4 dv[U], yv[U], y2v[U];
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                     const size_t off = (size_t)r * C + (size_t)col * CH;
                     dv[u] = *(const uint4*)(dz + off);
                     yv[u] = *(const uint4*)(y + off);
-                    if (y2) y2v[u] = *(const uint4*)(y2 + off);
+                    if constexpr (R2) { if (y2) y2v[u] = *(const uint4*)(y2 + off); }
                 }
             }
 #pragma unroll
@@ -378,9 +385,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 if (gout) *(uint4*)(gout + off) = Chunk<T>::pack(g);
                 float o[CH];
 #pragma unroll
-                for (int e = 0; e < CH; ++e) o[e] = k1[e] * (g[e] - ma[e] - (yy[e] - mu[e]) * is[e] * mb[e]);
+                for (int e = 0; e < CH; ++e) o[e] = ca[e] * g[e] + (cb[e] * yy[e] + cc[e]);
                 *(uint4*)(dy + off) = Chunk<T>::pack(o);
-                if (y2) {
+                if constexpr (R2) if (y2) {
                     float y2f[CH];
                     Chunk<T>::unpack(y2v[u], y2f);
 #pragma unroll
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 }
             }
         }
-    if (y2) {   // uniform: registers -> LDS -> one fp64 atomic per channel per workgroup (as bn_bwd_reduce_kernel)
+    if constexpr (R2) if (y2) {   // uniform: registers -> LDS -> one fp64 atomic per channel per workgroup (as bn_bwd_reduce_kernel)
         __shared__ float red2[256 * 2 * CH];
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
@@ -793,14 +800,14 @@ extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_sr
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_bwd_target_blocks());
     dim3 grid(w.colgroups, w.rowblocks);
     const double inv_count = 1.0 / (double)count;
-    if (dtype == VINCE_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
-                           msk, (const float*)y, mean, invstd, gamma, sums, inv_count, (float*)dy,
-                           (float*)g_out, dgamma, dbeta, rows, C, w, replicas, r2);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz,
-                           msk, (const bf16_t*)y, mean, invstd, gamma, sums, inv_count, (bf16_t*)dy,
-                           (bf16_t*)g_out, dgamma, dbeta, rows, C, w, replicas, r2);
+#define VINCE_BWD_APPLY(TT, RR)                                                                                          \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, RR>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)dz, msk,       \
+                       (const TT*)y, mean, invstd, gamma, sums, inv_count, (TT*)dy, (TT*)g_out, dgamma, dbeta, rows, C, w, \
+                       replicas, r2)
+    const bool has_r2 = r2.y != nullptr;
+    if (dtype == VINCE_F32) { if (has_r2) VINCE_BWD_APPLY(float, true); else VINCE_BWD_APPLY(float, false); }
+    else { if (has_r2) VINCE_BWD_APPLY(bf16_t, true); else VINCE_BWD_APPLY(bf16_t, false); }
+#undef VINCE_BWD_APPLY
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
