@@ -17,3 +17,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _hip_library_present():
+    """The product never builds or falls back on its own; the test session makes sure the in-tree library exists (a fresh
+    checkout has none: *.so is git-ignored) by running the same incremental build `__graft_entry__.build()` runs."""
+    from vince_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        build.build(verbose=False)
