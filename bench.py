@@ -125,6 +125,14 @@ def main():
     assert world == opt.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (opt.gpus, world)
     device = torch.device("cuda", local)
 
+    from vince_amd import _lib as _vlib
+    if not os.path.exists(_vlib.LIB_PATH):
+        # a checkout that never ran __graft_entry__.build(): the harness builds (rank 0 first), the product itself never does
+        from vince_amd import build as _vbuild
+        if rank == 0:
+            _vbuild.build(verbose=False)
+        if world > 1:
+            torch.distributed.barrier()
     from vince_amd.config import make_args
     from vince_amd.solvers.vince_solver import VinceSolver
     from vince_amd._lib import lib
