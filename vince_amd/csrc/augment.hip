@@ -234,7 +234,8 @@ __global__ __launch_bounds__(COLOR_THREADS) void color_chain_kernel(uint8_t* __r
             else if (code == 1) r = blend(Rgb{mean, mean, mean}, v, f);
             else if (code == 2) { const int l = luma(v); r = blend(Rgb{l, l, l}, v, f); }
             else if (code == 3) r = hue_shift(v, (int)f & 0xFF);
-            else { const int l = luma(v); r = Rgb{l, l, l}; }
+            else if (code == 4) { const int l = luma(v); r = Rgb{l, l, l}; }
+            else r = v;                                   // unknown step code: leave the pixel alone
             px[0] = (uint8_t)r.r;
             px[1] = (uint8_t)r.g;
             px[2] = (uint8_t)r.b;
