@@ -110,3 +110,34 @@ def test_bucketed_gradient_allreduce_sums_every_element_once():
     out = run2(_reduce_case)
     want = torch.arange(1000, dtype=torch.float32) * 3
     assert torch.equal(out[0], want) and torch.equal(out[1], want)
+
+
+def _coin_case(rank, world):
+    """with one process per GPU every rank must pick the same jigsaw side each step."""
+    import random
+    from vince_amd.solvers.vince_solver import VinceSolver
+    random.seed(1234 + rank)   # the per-process RNG differs between ranks on purpose
+    stub = types.SimpleNamespace(args=types.SimpleNamespace(jigsaw=True), _jigsaw_rng=None)
+    return [VinceSolver._jigsaw_coin(stub) < 0.5 for _ in range(64)]
+
+
+def test_jigsaw_side_is_drawn_in_lockstep_across_ranks():
+    out = run2(_coin_case)
+    assert out[0] == out[1]
+    assert 8 < sum(out[0]) < 56   # and it is still a coin
+
+
+def _save_case(rank, world):
+    import tempfile
+    from vince_amd.solvers.vince_solver import VinceSolver
+    d = os.path.join(tempfile.gettempdir(), "vince_save_case_%s" % os.environ["MASTER_PORT"])
+    calls = []
+    model = types.SimpleNamespace(save=lambda it, keep: calls.append((it, keep)))
+    stub = types.SimpleNamespace(model=model, iteration=512)
+    VinceSolver.save(stub, 5)
+    return calls
+
+
+def test_only_rank_zero_writes_checkpoints():
+    out = run2(_save_case)
+    assert out[0] == [(512, 5)] and out[1] == []

@@ -22,11 +22,16 @@ def _ckpt_iteration(path):
 def save_checkpoint(model, directory, num_to_keep, iteration):
     os.makedirs(directory, exist_ok=True)
     path = os.path.join(directory, "%09d.pt" % iteration)
-    torch.save({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}, path)
+    tmp = path + ".tmp%d" % os.getpid()
+    torch.save({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}, tmp)
+    os.replace(tmp, path)   # readers never see a half-written checkpoint
     if num_to_keep is not None and num_to_keep > 0:
         files = sorted(glob.glob(os.path.join(directory, "*.pt")), key=_ckpt_iteration)
         for old in files[:-num_to_keep]:
-            os.remove(old)
+            try:
+                os.remove(old)
+            except FileNotFoundError:   # another process pruned it first
+                pass
     return path
 
 

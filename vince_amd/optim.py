@@ -3,8 +3,11 @@
 
 Keeps the small part of torch.optim's surface the reference's driver touches: ``param_groups`` (solver_runner.py:36-43
 rewrites ``pg["lr"]`` during warm-up; base_solver.py:107-129 reads ``initial_lr``), ``zero_grad()``, ``step()``.
-One fused kernel per contiguous role range (trunk / projection head / jigsaw head); a range whose parameters
-received no gradient in this step is skipped, as torch skips parameters with ``grad is None`` (App. D item 10).
+One fused kernel per contiguous role range (trunk / projection head / jigsaw head).  A range that has NEVER received a
+gradient is skipped, as torch skips parameters whose ``.grad`` is None (App. D item 10: the unused ``resnet.fc``, a head
+that was never run).  Once a range has been used it is stepped on every later step, idle or not: the reference pins
+torch==1.4.0 (requirements.txt:17), whose ``optimizer.zero_grad()`` zeroes gradients in place and never resets them to
+None, so under ``--jigsaw`` alternation the idle head keeps receiving weight decay and momentum with a zero gradient.
 Parameters outside the flat buffer (the optional ImageNet side decoders) go through a plain torch SGD.
 """
 import torch
@@ -21,6 +24,7 @@ class FlatSGD:
         flat, grad, n_train, _ = model.flat_parameters()
         self.momentum_buffer = torch.zeros(n_train, dtype=torch.float32, device=flat.device)
         self.grad_scale = 1.0   # 1/world_size when gradients were SUM-all-reduced
+        self._ever_touched = set()   # roles that have received a gradient at least once (their .grad is a tensor in torch 1.4)
         extra = [p for p in (model.imagenet_decoders.parameters() if hasattr(model, "imagenet_decoders") else [])]
         self._extra = torch.optim.SGD(extra, lr=lr, momentum=momentum, weight_decay=weight_decay) if extra else None
 
@@ -32,8 +36,15 @@ class FlatSGD:
         flat, grad, n_train, _ = self.model.flat_parameters()
         if self.momentum_buffer.device != flat.device:
             self.momentum_buffer = self.momentum_buffer.to(flat.device)
+        if getattr(self.model, "_grad_zero_pending", False):   # zero_grad() with no backward since: gradients are zero
+            grad.zero_()
+            self.model._grad_zero_pending = False
         for role, (a, b) in self.model._segments.items():
-            if b > a and self.model._touched.get(role, False):
+            if self.model._touched.get(role, False):
+                self._ever_touched.add(role)
+            # an idle range's flat gradient is all zeros here (the whole buffer is cleared before backward): the kernel then
+            # applies exactly weight decay + momentum, which is what torch 1.4 does with an in-place-zeroed .grad
+            if b > a and role in self._ever_touched:
                 ops.sgd_flat(flat[a:b], grad[a:b], self.momentum_buffer[a:b], lr, self.momentum, self.weight_decay,
                              self.grad_scale)
         self.model._touch()
@@ -43,11 +54,12 @@ class FlatSGD:
             self._extra.step()
 
     def state_dict(self):
-        return {"momentum_buffer": self.momentum_buffer, "param_groups": [{k: v for k, v in g.items() if k != "params"}
+        return {"momentum_buffer": self.momentum_buffer, "ever_touched": sorted(self._ever_touched), "param_groups": [{k: v for k, v in g.items() if k != "params"}
                                                                           for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         self.momentum_buffer.copy_(sd["momentum_buffer"])
+        self._ever_touched = set(sd.get("ever_touched", ()))
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
 

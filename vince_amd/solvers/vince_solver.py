@@ -58,6 +58,7 @@ class VinceSolver(BaseSolver):
         self.reducer = None
         self._dp_step = 0
         self._key_stream = None
+        self._jigsaw_rng = None
         self.overlap_key_encoder = bool(int(os.environ.get("VINCE_OVERLAP_KEY", "1")))
         super(VinceSolver, self).__init__(args, train_logger, val_logger)
 
@@ -105,6 +106,11 @@ class VinceSolver(BaseSolver):
 
     def setup_model(self):
         device = self._torch_device()
+        if device.type == "cuda":
+            # the reference remaps devices through CUDA_VISIBLE_DEVICES (arg_parser.py:203-208) so its model always sits on
+            # the current device; here the ordinal is used directly, so make it current -- stream handles
+            # (ops.stream_ptr, the key-encoder stream) are taken from the CURRENT device
+            torch.cuda.set_device(device)
         args = copy.copy(self.args)
         args.title = os.path.join(getattr(args, "title", "vince"), "VinceModel")
         if getattr(args, "checkpoint_dir", None):
@@ -271,6 +277,27 @@ class VinceSolver(BaseSolver):
         mine = {"queue_embeddings": natural[r * B:(r + 1) * B].contiguous()}
         return [mine], natural
 
+    def save(self, num_to_keep=-1):
+        """Replicas are bit-identical, so only rank 0 writes (concurrent ranks would race on one file and on the pruning of
+        old checkpoints); the others wait so nobody runs ahead into a collective while rank 0 is still on the disk."""
+        w, r = dp.world()
+        if r == 0:
+            self.model.save(self.iteration, num_to_keep)
+        if w > 1:
+            torch.distributed.barrier()
+
+    def _jigsaw_coin(self):
+        """Which side is jigsawed this step (vince_solver.py:397-403).  The reference is one process and makes one
+        `random.random()` draw; with one process per GPU every rank must make the SAME choice -- otherwise the ranks touch
+        different heads, the all-reduced gradient mixes both and each rank steps a different segment -- so data-parallel
+        runs draw from a generator every rank seeds identically (`args.jigsaw_seed`, default 0) and advance in lockstep."""
+        w, _ = dp.world()
+        if w == 1 and getattr(self.args, "jigsaw_seed", None) is None:
+            return random.random()
+        if self._jigsaw_rng is None:
+            self._jigsaw_rng = random.Random(0x5EED + int(getattr(self.args, "jigsaw_seed", None) or 0))
+        return self._jigsaw_rng.random()
+
     # ------------------------------------------------------------------------------------------ the hot loop
     def run_train_iteration(self):
         total_t_start = time.time()
@@ -284,7 +311,7 @@ class VinceSolver(BaseSolver):
         # weights, different workspaces), so the key encoder runs on a side HIP stream and its kernels fill the launch
         # tails of the query encoder's; the main stream joins it before the similarity stage.
         if self.args.jigsaw:
-            jig_key = random.random() < 0.5
+            jig_key = self._jigsaw_coin() < 0.5
             jig_query = not jig_key
         else:
             jig_key = jig_query = False
@@ -359,7 +386,7 @@ class VinceSolver(BaseSolver):
         self.queue_model.vince_update(self.model)
 
         if self.logger_iteration % self.args.save_frequency == 0:
-            self.model.save(self.iteration, 5)
+            self.save(5)
 
         if self.logger_iteration % self.args.log_frequency == 0:
             # the only host synchronisation of the step: scalar read-back for the meters (the reference's
@@ -416,7 +443,7 @@ class VinceSolver(BaseSolver):
                         break
                     device = self.model.device
                     batch = {k: (v.to(device) if isinstance(v, (torch.Tensor, U8Frames)) else v) for k, v in batch.items()}
-                    concat = {k: v if isinstance(v, torch.Tensor) else [v] for k, v in batch.items()}
+                    concat = {k: v if isinstance(v, (torch.Tensor, U8Frames)) else [v] for k, v in batch.items()}
                     concat["batch_types"] = concat.pop("batch_type")
                     concat["batch_sizes"] = concat.pop("batch_size")
                     queue_batches = self.queue_model(concat, shuffle=False)
