@@ -52,6 +52,10 @@ int vince_profile_enable(int on);
  * the data-parallel solver sets 1.  Process-wide; call before the first backward. */
 int vince_set_side_streams(int32_t n);
 int vince_profile_collect(int32_t ntags, double* ms, double* flops, int64_t* count);
+/* Calibration aid (bench.py `roofline.hbm_achievable`, tools/ceilings.py): copies `bytes` (multiple of 16) with a plain
+ * 16-byte-per-lane grid-stride kernel of `blocks` workgroups (<= 0: 2048) -- the HBM streaming rate this box gives an
+ * element-wise pass, measured with the library's own code instead of a framework copy.  nontemporal != 0: `nt` loads and stores. */
+int vince_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks, int32_t nontemporal, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Generalised tap convolution as implicit GEMM on MFMA (K1-K3, K8 forward; dgrad of the same).

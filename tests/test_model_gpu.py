@@ -548,6 +548,43 @@ def test_solver_runner_cli_end_to_end(capsys):
     assert "Traceback" not in out
 
 
+def test_reference_entry_point_control_flow_through_compat_names(tmp_path):
+    """SURVEY 8b / VERDICT r1 missing #2: a driver that uses ONLY the reference's import names (`arg_parser`,
+    `solvers.base_solver`, `dg_util...tensorboard_logger`) and restates solver_runner.py:12-54 runs the HIP solver, the
+    loggers receive the reference's keys (vince_solver.py:503-512, base_solver.py:121-128), the warm-up ramps the lr."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "compat"), os.path.join(root, "compat", "_standins"), root])
+    cmd = [sys.executable, os.path.join(root, "tests", "compat_driver.py"), "--title", "compat", "--description", "t",
+           "--solver", "VinceSolver", "--backbone", "ResNet18", "--batch-size", "16", "--vince-queue-size", "64",
+           "--vince-embedding-size", "32", "--input-width", "64", "--input-height", "64", "--epochs", "2",
+           "--iterations-per-epoch", "3", "--base-lr", "0.03", "--no-save", "--no-restore", "--log-frequency", "1",
+           "--base-logdir", str(tmp_path)]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("COMPAT_RESULT ")][-1]
+    out = json.loads(line[len("COMPAT_RESULT "):])
+    assert out["solver"] == "vince_amd.solvers.vince_solver.VinceSolver" and out["model"].startswith("vince_amd.models")
+    assert out["iteration"] == 6 * 16 and out["tail"] == (6 * 16) % 64
+    assert out["events_file"]
+    # six logged iterations, each with the reference's three key families
+    assert [s for s, _ in out["train_dicts"]] == [16 * i for i in range(6)]
+    keys = out["train_dicts"][-1][1]
+    full = "VinceSolver_VinceModel"   # base_solver.py:60-62: "%s_%s" % (solver_name, model_name)
+    assert "losses/%s/nce_loss" % full in keys
+    for k in ("nce_accuracy_mean", "nce_softmax_weight_mean", "cosine_sim", "cosine_sim_neg_max"):
+        assert "metrics/%s/%s" % (full, k) in keys
+    for k in ("total_time", "forward_time", "backward_time", "data_cache_time", "metrics_time"):
+        assert "times/%s/%s" % (full, k) in keys
+    tags = [t for t, _ in out["train_scalars"]]
+    assert "metrics/%s/lr" % full in tags and "metrics/%s/epoch" % full in tags
+    # solver_runner.py:36-43: lr_i = min(1, i/500) * peak for the first 500 iterations
+    np.testing.assert_allclose(out["lrs"], [out["peak"] * (i + 1) / 500.0 for i in range(6)], rtol=1e-12)
+
+
 def test_two_ranks_on_one_gpu_stay_identical():
     """The multi-rank path on GPU hardware: two data-parallel ranks of the full solver share this one GPU through the
     gloo backend (NCCL refuses two ranks per device) -- parameter / queue broadcast, bucketed gradient all-reduce behind

@@ -34,3 +34,22 @@ t = timeit(lambda: dst.copy_(src))
 print("HBM stream copy 2 GiB: %.2f TB/s read+write   [spec ~8]" % (2.0 * nbytes / t / 1e12))
 t = timeit(lambda: dst.zero_())
 print("HBM write-only (fill 2 GiB): %.2f TB/s" % (nbytes / t / 1e12))
+
+# ---- the library's own float4 copy kernel (vince_stream_copy): the streaming ceiling element-wise passes are held against
+import sys
+sys.path.insert(0, ".")
+from vince_amd import _lib
+L = _lib.lib()
+for nbytes in (256 << 20, 1 << 30, 2 << 30):
+    s = src[:nbytes]
+    d = dst[:nbytes]
+    for nt in (0, 1):
+        best = None
+        for blocks in (1024, 2048, 4096, 8192, 16384):
+            st = torch.cuda.current_stream().cuda_stream
+            t = timeit(lambda: _lib.check(L.vince_stream_copy(d.data_ptr(), s.data_ptr(), nbytes, blocks, nt, st)), n=10)
+            r = 2.0 * nbytes / t / 1e12
+            if best is None or r > best[0]:
+                best = (r, blocks)
+            print("vince_stream_copy %4d MiB nt=%d blocks=%5d: %.2f TB/s read+write" % (nbytes >> 20, nt, blocks, r))
+        print("  best %d MiB nt=%d: %.2f TB/s at %d blocks" % (nbytes >> 20, nt, best[0], best[1]))

@@ -106,9 +106,8 @@ def finalize(args):
     args.feature_extractor_gpu_ids = [local]
     args.saved_variable_prefix = args.saved_variable_prefix.split(",")
     args.new_variable_prefix = args.new_variable_prefix.split(",")
-    if args.use_imagenet:
-        print("note: --use-imagenet side decoders need labelled ImageNet batches; synthetic batches carry none")
-        args.use_imagenet = False
+    # --use-imagenet (vince/train_moco_v2.sh:39) is kept as parsed: the side decoders are built and train on every batch whose
+    # data_source is "IN" (labelled, VinceSolver.process_imagenet_data); batches from other sources never reach them
     return args
 
 

@@ -523,6 +523,43 @@ __global__ __launch_bounds__(256) void zero_kernel(uint4* p, size_t n16) {
 }
 }  // namespace
 
+namespace {
+// Calibration kernel (bench.py `roofline.hbm_achievable`): a plain 16-byte-per-lane grid-stride copy, UNROLL loads in flight per
+// thread -- the streaming rate an element-wise pass of this library can be held against on the box it runs on.
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4_t* __restrict__ src, f32x4_t* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+        f32x4_t v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (NT) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+            else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int vince_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks, int32_t nontemporal, void* stream) {
+    VINCE_CHECK_ARG(dst && src && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0 && (bytes & 15) == 0, VINCE_E_ALIGN,
+                    "vince_stream_copy: 16-byte granularity");
+    if (bytes == 0) return VINCE_OK;
+    const size_t n16 = bytes / 16;
+    if (blocks <= 0) blocks = 2048;
+    if (nontemporal)
+        hipLaunchKernelGGL((stream_copy_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const f32x4_t*)src, (f32x4_t*)dst, n16);
+    else
+        hipLaunchKernelGGL((stream_copy_kernel<4, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const f32x4_t*)src, (f32x4_t*)dst, n16);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
 int vince_zero_async(void* ptr, size_t bytes, void* stream) {
     VINCE_CHECK_ARG(ptr && ((uintptr_t)ptr & 15) == 0 && (bytes & 15) == 0, VINCE_E_ALIGN, "vince_zero_async: 16-byte granularity");
     if (bytes == 0) return VINCE_OK;

@@ -58,11 +58,27 @@ def _train(args, solver):
     solver.end()
 
 
-def main(argv=None):
+def _make_loggers(args):
+    """solver_runner.py:15-20: no loggers with --debug, else one per split under args.tensorboard_dir.  dg_util's
+    TensorBoard logger is used when it is installed; otherwise the JSON-lines logger with the same two methods the path
+    calls.  Only rank 0 logs (replicas are identical)."""
+    if args.debug or int(os.environ.get("RANK", "0")) != 0:
+        return None, None
+    try:
+        from dg_util.python_utils import tensorboard_logger as tb
+    except ImportError:
+        from .utils import jsonl_logger as tb
+    return (tb.Logger(os.path.join(args.tensorboard_dir, "train")), tb.Logger(os.path.join(args.tensorboard_dir, "val")))
+
+
+def main(argv=None, train_logger=None, val_logger=None):
+    """solver_runner.py:12-54.  Loggers: any object with `dict_log(dict, step)` / `scalar_summary(tag, value, step)`; when
+    none is passed they are made the way the reference makes them (_make_loggers)."""
     args = arg_parser.parse_args(argv)
     _join_process_group()
-    # dg_util's TensorBoard logger is not part of the path: a caller that wants logging constructs the solver itself
-    solver = args.solver(args, None, None)
+    if train_logger is None and val_logger is None:
+        train_logger, val_logger = _make_loggers(args)
+    solver = args.solver(args, train_logger, val_logger)   # solver_runner.py:22
     try:
         _train(args, solver)
     except Exception:   # the reference prints the traceback and still saves (solver_runner.py:47-54)
