@@ -78,6 +78,61 @@ def cpu_baseline(arch, embed, K, T, hw, batch, steps):
     return 2.0 * batch * steps / dt
 
 
+def kernel_source_hash():
+    """sha256 over the HIP sources (csrc/*.hip, *.cpp, common.h) + include/vince_hip.h: what a PMC pass was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.listdir(os.path.join(ROOT, "vince_amd", "csrc")))
+    for f in files:
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(open(os.path.join(ROOT, "vince_amd", "csrc", f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "vince_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def workload_label(opt, world):
+    """Names the BASELINE.json configuration the ARGUMENTS describe (never a fixed string: a ResNet-18 fp32 run is config 2)."""
+    shape = "%s %dx%d, B=%d per GPU, K=%d, D=%d, T=%g, %s trunk" % (opt.backbone, opt.size, opt.size, opt.batch, opt.queue,
+                                                                   opt.embed, opt.temperature, opt.dtype)
+    c3 = (opt.backbone, opt.size, opt.batch, opt.queue, opt.embed, opt.dtype) == ("ResNet50", 224, 256, 65536, 128, "bf16") \
+        and abs(opt.temperature - 0.2) < 1e-9
+    c2 = (opt.backbone, opt.size, opt.batch, opt.queue, opt.dtype) == ("ResNet18", 224, 256, 4096, "fp32")
+    if opt.mode == "vince":
+        name = "BASELINE config 5 per-GPU work (4 frames per clip, inter-batch + self-batch comparison, jigsaw side)" if \
+            (opt.backbone, opt.size, opt.queue) == ("ResNet50", 224, 65536) else "multi-frame + jigsaw mode, not a BASELINE size"
+    elif c3:
+        name = "BASELINE config 3" if world == 1 else "BASELINE config 4 (config 3 per GPU x %d, data parallel)" % world
+    elif c2 and opt.mode == "moco":
+        name = "BASELINE config 2"
+    else:
+        name = "not a BASELINE configuration"
+    return "%s: %s, %s, random init" % (name, shape, "MoCo-v2 mode" if opt.mode == "moco" else "VINCE mode")
+
+
+def measure_copy_ceiling(L, device, nbytes=1 << 30):
+    """TB/s (read + write) of the library's own 16-byte-per-lane copy kernel on this box: the rate an element-wise pass can be
+    held against (`roofline.hbm_achievable`).  Best of a few grid sizes, nt and plain."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    st = torch.cuda.current_stream().cuda_stream
+    best = (0.0, None)
+    for nt in (1, 0):
+        for blocks in (4096, 16384):
+            for _ in range(2):
+                L.vince_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, blocks, nt, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                L.vince_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, blocks, nt, st)
+            e1.record()
+            torch.cuda.synchronize()
+            r = 2.0 * nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            if r > best[0]:
+                best = (r, "vince_stream_copy, 1 GiB, %d blocks, %s" % (blocks, "nt" if nt else "plain"))
+    del src, dst
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +148,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline and cpu_baseline legs")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--fp32-steps", type=int, default=5,
+                    help="extra leg: the same step with an fp32 trunk (the precision the reference's own config-3 script runs, "
+                         "vince/train_moco_v2.sh:40 has --use-apex commented out); 0 = skip")
     ap.add_argument("--mode", default="moco", choices=["moco", "vince"],
                     help="moco: BASELINE config 3 (the headline); vince: config 5's per-GPU work -- 4 frames per clip, inter-batch + "
                          "self-batch comparison (self T 0.03) and the jigsaw head on one side per step")
@@ -191,11 +249,7 @@ def main():
         "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": opt.dtype, "data": "synthetic",
-        "config": {"workload": ("BASELINE config 3: %s %dx%d, B=%d per GPU, K=%d, D=%d, T=%g (MoCo-v2 mode), random init"
-                                if opt.mode == "moco" else
-                                "BASELINE config 5 per-GPU work: %s %dx%d, B=%d frames (4 per clip) per GPU, K=%d, D=%d, T=%g, "
-                                "inter-batch + self-batch comparison, jigsaw side, random init")
-                               % (opt.backbone, opt.size, opt.size, opt.batch, opt.queue, opt.embed, opt.temperature),
+        "config": {"workload": workload_label(opt, world),
                    "global_batch": opt.batch * world, "frames_per_step": 2 * opt.batch * world,
                    "parallelism": "dp%d" % world, "final_loss": round(loss, 5),
                    "input": ("float32 NCHW frames resident in HBM" if opt.input == "float" else
@@ -309,12 +363,16 @@ def main():
             # HBM bytes per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note in
             # MI355X_MICROARCH.md, + WRITE_SIZE), recorded by tools/rocpd_pmc.py into profiles/ -- bench.py cannot run
             # the counter passes itself
-            traffic = traffic_source = None
+            traffic = traffic_source = traffic_stamp = None
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_conv_igemm.json")) as fh:
                     pm = json.load(fh)
                 traffic = pm["kernels"][dom_conv]["bytes_per_launch"]      # HBM bytes per launch of that kernel
                 traffic_source = pm["source"]
+                # the PMC passes are a separate rocprofv3 run: the file says which kernel sources it was taken from, and a
+                # mismatch with what is built now is reported instead of silently quoting a stale number
+                traffic_stamp = {"kernel_source_hash": pm.get("kernel_source_hash"), "git_head": pm.get("git_head"),
+                                 "stale": pm.get("kernel_source_hash") != kernel_source_hash()}
                 if pm.get("step"):
                     # whole-step HBM view: the step as a whole is bandwidth-bound
                     out["step_hbm"] = {"bytes_per_step": pm["step"]["bytes"], "unit": "GB/s", "peak": 8000.0,
@@ -329,12 +387,50 @@ def main():
                                "flops_per_launch": round(k["tflops"] * 1e12 * k["avg_us"] * 1e-6),
                                "avg_us": k["avg_us"], "launches_per_step": k["launches_per_step"],
                                "ms_per_step": k["ms_per_step"], "longest_kernel_family": dom}
+            if traffic_stamp is not None:
+                out["roofline"]["traffic_stale"] = bool(traffic_stamp["stale"])
+                out["roofline"]["traffic_taken_from"] = {k2: traffic_stamp[k2] for k2 in ("git_head", "kernel_source_hash")}
+                if "step_hbm" in out:
+                    out["step_hbm"]["stale"] = bool(traffic_stamp["stale"])
+            try:
+                ceil, how = measure_copy_ceiling(L, device)
+                out["roofline"]["hbm_achievable"] = {"value": round(ceil * 1000.0, 1), "unit": "GB/s", "how": how}
+            except Exception as e:
+                out["roofline"]["hbm_achievable"] = {"error": repr(e)}
             if traffic:
                 # the same kernel against the HBM roof ("HBM is the secondary bound and must be reported
                 # alongside"): measured bytes per launch / measured duration
                 gbs = traffic / (k["avg_us"] * 1e-6) / 1e9
                 out["roofline"]["hbm"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
+                ach = out["roofline"].get("hbm_achievable", {}).get("value")
+                if ach:
+                    out["roofline"]["hbm"]["frac_of_achievable"] = round(gbs / ach, 4)
         out["kernels"] = kernels
+        # ---- fp32 leg: the reference's own config-3 script runs fp32 (train_moco_v2.sh:40); same step, fp32 trunk ------------
+        if opt.fp32_steps > 0 and opt.dtype != "fp32":
+            try:
+                del solver
+                torch.cuda.empty_cache()
+                args32 = make_args(**{**{k_: getattr(args, k_) for k_ in vars(args)}, "compute_dtype": "fp32"})
+                with contextlib.redirect_stdout(sys.stderr):
+                    s32 = VinceSolver(args32)
+                    s32.reset_epoch()
+                for _ in range(2):
+                    s32.run_train_iteration()
+                barrier()
+                t32 = time.perf_counter()
+                for _ in range(opt.fp32_steps):
+                    s32.run_train_iteration()
+                barrier()
+                t32 = (time.perf_counter() - t32) / opt.fp32_steps
+                tf32 = step_tflop / t32
+                out["fp32_step"] = {"frames_per_s_per_gpu": round(2.0 * opt.batch / t32, 1), "ms_per_step": round(t32 * 1000, 3),
+                                    "steps": opt.fp32_steps, "tflops": round(tf32, 1),
+                                    "mfma_frac": round(tf32 / PEAK_TFLOPS["fp32"], 4), "dtype": "fp32"}
+                del s32
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out["fp32_step"] = {"error": repr(e)}
         # ---- cpu_baseline leg ----------------------------------------------------------------------------------------
         try:
             if opt.cpu_steps <= 0:

@@ -1,0 +1,80 @@
+"""Helper of tests/test_full_size_gpu.py: ONE grad-enabled forward + InfoNCE + backward of BASELINE config 3 (ResNet-50,
+B=256, 224x224, K=65536, D=128, T=0.2) on the G9 inputs, dumped as an .npz.  Run as a child process so that the engine's
+environment switches (VINCE_WGRAD_STREAM, VINCE_DS_STREAM, ... -- read once per process) can differ between two runs.
+usage: full_size_grad_dump.py <out.npz> <bf16|fp32>"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import vince_oracle as vo   # noqa: E402  (test infrastructure: inputs + seeded weights + checksums only)
+
+
+def main():
+    out_path, dtype = sys.argv[1], sys.argv[2]
+    from vince_amd.config import make_args
+    from vince_amd.models.vince_model import VinceModel, VinceQueueModel
+    dev = "cuda:0"
+    args = make_args(backbone="ResNet50", vince_embedding_size=128, compute_dtype=dtype, batch_size=256,
+                     vince_queue_size=65536, vince_temperature=0.2, base_lr=0.03, input_size=(224, 224))
+    model = VinceModel(args)
+    model.load_state_dict(vo.seeded_state(vo.model_spec("ResNet50", 128, False), 9))
+    model.to(dev)
+    model.train()
+    qm = VinceQueueModel(args, model)
+    qm.to(dev)
+    qm.train()
+    queue = torch.nn.functional.normalize(torch.randn(65536, 128, generator=torch.Generator().manual_seed(9 + 77)), dim=-1).to(dev)
+    data, qdata = vo.g9_inputs()
+    batch = {"data": data.to(dev), "queue_data": qdata.to(dev), "batch_types": ["images"], "batch_sizes": [256],
+             "data_source": ["XX"], "num_frames": [1]}
+    if os.environ.get("VINCE_OVERLAP_KEY", "1") != "0":   # the solver's arrangement: key encoder on its own stream
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            qb = qm(batch, shuffle=True)
+        o = model.get_embeddings(batch, shuffle=True)[0]
+        torch.cuda.current_stream().wait_stream(side)
+    else:
+        qb = qm(batch, shuffle=True)
+        o = model.get_embeddings(batch, shuffle=True)[0]
+    o.update({"queue_vectors": queue, "queue_images": None, "queue_data_sources": None})
+    o.update(model.split_dict_by_type(batch["batch_types"], batch["batch_sizes"], batch)[0])
+    o.update(qb[0])
+    o.update(model(o))
+    ld = model.loss(o)
+    met = model.get_metrics(o)
+    loss = sum(w * v for w, v in ld.values())
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    res = {"loss": np.array(float(loss))}
+    res.update({"m_" + k: np.array(float(v)) for k, v in met.items()})
+    res["embeddings"] = o["embeddings"].detach().float().cpu().numpy()
+    res["queue_embeddings"] = qb[0]["queue_embeddings"].float().cpu().numpy()
+    res["prenorm"] = o["prenorm_features"].detach().float().cpu().numpy()
+    res["extracted_head"] = o["extracted_features"].detach().float().cpu().numpy()[:4]
+    res["extracted_checksum"] = np.array(vo.tensor_checksum(o["extracted_features"].detach().float().cpu()))
+    names, cs = [], []
+    named = dict(model.named_parameters())
+    for n in sorted(named):
+        if named[n].grad is not None:
+            names.append(n)
+            cs.append(vo.tensor_checksum(named[n].grad.detach().float().cpu().contiguous()))
+    res["grad_names"] = np.array(names)
+    res["grad_checksums"] = np.array(cs)
+    for n in sys.argv[3:]:
+        res["grad_" + n] = named[n].grad.detach().float().cpu().numpy()
+    sd = model.state_dict()
+    for k in list(sd):
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            if any(t in k for t in (".bn1.", "layer1.2.bn3", "layer3.5.bn2", "layer4.2.bn3")) and k.count(".") <= 5:
+                res["run_" + k] = sd[k].float().cpu().numpy()
+    np.savez(out_path, **res)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,10 +1,11 @@
 """world_size-2 tests of the data-parallel glue on CPU (gloo, 127.0.0.1): key all-gather order + replicated queue
-(golden set G7 by composition with the oracle), cross-rank key shuffle, bucketed gradient all-reduce."""
+(golden set G7: the reference run chunk-wise, tests/golden/g7_dp.npz), cross-rank key shuffle, bucketed gradient all-reduce."""
 import os
 import socket
 import types
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -73,6 +74,37 @@ def test_replicated_queue_identical_and_matches_oracle():
         oq.enqueue(np.concatenate(blocks))
     np.testing.assert_array_equal(q0, oq.vectors)
     assert t0[-1] == oq.current_tail and f0 == oq.full
+
+
+def _g7_case(rank, world):
+    """Each rank contributes ITS rows of the reference's key block; the gathered block, the ring arithmetic and the
+    replicated queue must reproduce what the reference's StorageQueue held after enqueueing the rank-ordered block."""
+    from vince_amd import dp
+    from vince_amd.utils.queue_index import enqueue_segments
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_dp.npz"))
+    p = "w%d_" % world
+    keys = g[p + "keys"]
+    b = keys.shape[0] // world
+    K = g[p + "queue_before"].shape[0]
+    queue = g[p + "queue_before"].copy()
+    gathered = dp.gather_keys(torch.from_numpy(keys[rank * b:(rank + 1) * b].copy()))
+    segs, tail, wrapped = enqueue_segments(K - 5, gathered.shape[0], K)
+    for dst, src, ln in segs:
+        queue[dst:dst + ln] = gathered[src:src + ln].numpy()
+    return queue, tail, bool(wrapped), gathered.numpy()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_g7_reference_chunkwise_emulation_keys_and_queue(world):
+    """Golden set G7: the REFERENCE run chunk-wise to emulate `world` ranks (oracle/make_golden_full.py)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_dp.npz"))
+    out = run2(_g7_case, world=world)
+    p = "w%d_" % world
+    for r in range(world):
+        queue, tail, wrapped, gathered = out[r]
+        np.testing.assert_array_equal(gathered, g[p + "keys"])                    # rank order
+        np.testing.assert_array_equal(queue, g[p + "queue_after"])                # bit-exact: a copy, no arithmetic
+        assert tail == int(g[p + "tail"]) and wrapped == bool(g[p + "full"])
 
 
 def _shuffle_case(rank, world):

@@ -138,3 +138,165 @@ def test_full_batch_trunk_eval_folded_vs_separate_passes(monkeypatch):
     rel = float((a - b).abs().max() / b.abs().max())
     cos = float(torch.nn.functional.cosine_similarity(a, b, dim=1).min())
     assert rel < 8e-2 and cos > 0.995, (rel, cos)
+
+
+# ------------------------------------------------------------------------------------------ gradient kernels at full size
+@pytest.mark.parametrize("name,hw,ci,co,k", FULL_LAYERS + [("layer2 1x1 128->512", 28, 128, 512, 1)])
+def test_dgrad_wgrad_full_size_homogeneity_and_sampled_fp64(name, hw, ci, co, k):
+    """the input-gradient and weight-gradient kernels at N=256 (256-pixel tiles, XCD-pinned wgrad split
+    sized to one resident wave of workgroups, fp32 atomics).  dgrad(2*dy) == 2*dgrad(dy) bit-exactly in bf16; wgrad(2*dy) ==
+    2*wgrad(dy) up to the summation order of the atomics; sampled entries of both against fp64 dot products of the same bf16
+    operands."""
+    ops = _ops()
+    N = 256
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(N, hw, hw, ci, device=DEV, generator=g).clamp_(min=0).bfloat16()
+    dy = (torch.randn(N, hw, hw, co, device=DEV, generator=g) * 0.1).bfloat16()
+    w = (torch.randn(co, k * k, ci, device=DEV, generator=g) * (2.0 / (ci * k * k)) ** 0.5).bfloat16()
+    wt = w.permute(2, 1, 0).contiguous()                                  # [Ci][T][Co]: the dgrad operand layout
+    # ---- dgrad
+    dxs = []
+    for scale in (1.0, 2.0):
+        dx = torch.empty(N, hw, hw, ci, device=DEV, dtype=torch.bfloat16)
+        for d in ops.dgrad_descs(N, hw, hw, ci, co, k, 1, k // 2):
+            ops.conv_igemm(d, (dy * scale).contiguous(), wt, dx)
+        dxs.append(dx)
+    assert torch.equal(dxs[1].float(), dxs[0].float() * 2)
+    sel = torch.randint(0, N * hw * hw, (48,), generator=torch.Generator().manual_seed(4))
+    dyp = torch.nn.functional.pad(dy.float().permute(0, 3, 1, 2), (k // 2,) * 4).double()     # [N][Co][H+2p][W+2p]
+    wd = w.float().double().reshape(co, k, k, ci)
+    for pix in sel.tolist():
+        n, rem = divmod(pix, hw * hw)
+        h, ww = divmod(rem, hw)
+        # dx[n,h,w,ci] = sum_{a,b,co} dy[n, h + p - a, w + p - b, co] * W[co, a, b, ci]
+        patch = dyp[n, :, h:h + k, ww:ww + k].flip(1, 2)                                     # [Co][a][b]
+        want = torch.einsum("oab,oabi->i", patch, wd)
+        got = dxs[0][n, h, ww].float().double()
+        assert float((got - want).abs().max()) <= 1.5e-2 * float(want.abs().max()) + 1e-3, (name, pix)
+    # ---- wgrad
+    d = ops.conv_desc(N, hw, hw, ci, co, k, 1, k // 2)
+    dws = []
+    for scale in (1.0, 2.0):
+        dw = torch.zeros(co, k * k, ci, device=DEV)
+        ops.conv_wgrad(d, x, (dy * scale).contiguous(), dw)
+        dws.append(dw)
+    assert float((dws[1] - 2 * dws[0]).abs().max()) <= 2e-5 * float(dws[0].abs().max())
+    xp = torch.nn.functional.pad(x.float().permute(0, 3, 1, 2), (k // 2,) * 4).double()       # [N][Ci][H+2p][W+2p]
+    gsel = torch.Generator().manual_seed(8)
+    for _ in range(24):
+        o_, t_, i_ = (int(torch.randint(0, m, (1,), generator=gsel)) for m in (co, k * k, ci))
+        a, b = divmod(t_, k)
+        want = (dy[..., o_].float().double() * xp[:, i_, a:a + hw, b:b + hw]).sum()
+        got = float(dws[0][o_, t_, i_])
+        scale_ref = float((dy[..., o_].float().double().abs() * xp[:, i_, a:a + hw, b:b + hw].abs()).sum())
+        assert abs(got - float(want)) <= 2e-5 * scale_ref + 1e-4, (name, o_, t_, i_, got, float(want))
+
+
+def _dump(tmp_path, tag, dtype, env_extra, sampled=()):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / ("dump_%s.npz" % tag))
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "full_size_grad_dump.py"), out, dtype] + list(sampled),
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return np.load(out)
+
+
+G9_SAMPLED = [("feature_extractor.model.conv1.weight", None, 3e-2), ("feature_extractor.model.bn1.weight", None, 3e-2),
+              ("feature_extractor.model.layer1.0.conv1.weight", None, 3e-2),
+              ("feature_extractor.model.layer1.2.conv3.weight", 16, 3e-2), ("feature_extractor.model.layer2.0.conv2.weight", 4, 2e-2),
+              ("feature_extractor.model.layer2.3.bn3.weight", None, 2e-2), ("feature_extractor.model.layer3.0.downsample.0.weight", 8, 2e-2),
+              ("feature_extractor.model.layer3.5.conv2.weight", 2, 2e-2), ("feature_extractor.model.layer3.5.bn2.bias", None, 2e-2),
+              ("feature_extractor.model.layer4.0.conv1.weight", 8, 5e-3), ("feature_extractor.model.layer4.2.conv3.weight", 8, 5e-3),
+              ("feature_extractor.model.layer4.2.bn3.weight", None, 5e-3), ("embedding.0.weight", 8, 5e-3),
+              ("embedding.0.bias", None, 5e-3), ("embedding.2.weight", 16, 5e-3), ("embedding.2.bias", None, 5e-3)]
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_g9_config3_full_size_fp32_vs_reference(tmp_path, golden_dir):
+    """Golden set G9 (VERDICT r1 missing #3): BASELINE config 3 at its REAL size -- ResNet-50, B=256, 224x224, K=65536, D=128,
+    T=0.2 -- one full iteration (key forward, query forward, InfoNCE, metrics, backward) of the imported REFERENCE on CPU
+    (oracle/make_golden_full.py) against the fp32 HIP path: loss / embeddings within the north-star 1e-3, every gradient's
+    checksum, sampled gradient rows, BatchNorm running statistics."""
+    g = np.load(os.path.join(golden_dir, "g9_full.npz"))
+    r = _dump(tmp_path, "fp32", "fp32", {}, [n for n, _, _ in G9_SAMPLED])
+    np.testing.assert_allclose(float(r["loss"]), float(g["loss"]), rtol=1e-3)
+    for k in ("nce_accuracy_mean", "cosine_sim", "cosine_sim_neg_max", "nce_softmax_weight_mean"):
+        np.testing.assert_allclose(float(r["m_" + k]), float(g["m_" + k]), rtol=1e-3, atol=1e-5)
+    assert _rel(r["embeddings"], g["embeddings"]) < 1e-3
+    assert _rel(r["queue_embeddings"], g["queue_embeddings"]) < 1e-3
+    assert _rel(r["prenorm"], g["prenorm"]) < 1e-3
+    assert _rel(r["extracted_head"], g["extracted_head"]) < 1e-3
+    np.testing.assert_allclose(r["extracted_checksum"][2], g["extracted_checksum"][2], rtol=1e-4)
+    bad = []
+    for n, rows, tol in G9_SAMPLED:
+        got = r["grad_" + n]
+        e = _rel(got if rows is None else got[:rows], g["grad_" + n])
+        if not e < tol:
+            bad.append((n, e, tol))
+    assert not bad, bad
+    # every gradient tensor: sum of |g| (a 161-tensor sweep; stem-adjacent tensors are conditioned to ~1e-2, see DESIGN 3)
+    gn = list(g["grad_names"])
+    worst = {}
+    for i, n in enumerate(r["grad_names"]):
+        j = gn.index(n)
+        early = any(n.startswith("feature_extractor.model." + s) for s in ("conv1", "bn1", "layer1"))
+        e = abs(r["grad_checksums"][i][2] / g["grad_checksums"][j][2] - 1)
+        worst[n] = e
+        if not e < (3e-2 if early else 1e-2):
+            bad.append((n, e))
+    print("G9 fp32: loss rel err %.2e, embeddings %.2e, worst sum|g| error %.2e (%s)" % (
+        abs(float(r["loss"]) / float(g["loss"]) - 1), _rel(r["embeddings"], g["embeddings"]), max(worst.values()),
+        max(worst, key=worst.get)))
+    assert not bad, bad
+    for k in g.files:
+        if k.startswith("run_"):
+            np.testing.assert_allclose(r[k], g[k], rtol=2e-3, atol=1e-5, err_msg=k)
+
+
+def test_g9_config3_full_size_bf16_loss_and_reported_embedding_error(tmp_path, golden_dir):
+    """The dtype the bench line is quoted in, at the full size, against the same reference fixture: InfoNCE loss within the
+    north-star 1e-3; the embedding error of the bf16 trunk is REPORTED against the fixture (printed, bounded at twice the
+    measured value) -- SURVEY 8d: 'any miss reported as a number, not hidden'."""
+    g = np.load(os.path.join(golden_dir, "g9_full.npz"))
+    r = _dump(tmp_path, "bf16", "bf16", {})
+    np.testing.assert_allclose(float(r["loss"]), float(g["loss"]), rtol=1e-3)
+    err = _rel(r["embeddings"], g["embeddings"])
+    kerr = _rel(r["queue_embeddings"], g["queue_embeddings"])
+    e, ge = r["embeddings"].astype(np.float64), g["embeddings"].astype(np.float64)
+    cos = float(((e * ge).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(ge, axis=1))).min())
+    print("G9 bf16: loss rel err %.2e, embeddings max err / max|e| %.3e (keys %.3e), min cosine %.5f"
+          % (abs(float(r["loss"]) / float(g["loss"]) - 1), err, kerr, cos))
+    assert err < BF16_EMB_BOUND and kerr < BF16_EMB_BOUND and cos > 0.99
+    np.testing.assert_allclose(float(r["m_nce_accuracy_mean"]), float(g["m_nce_accuracy_mean"]), atol=2e-2)
+
+
+BF16_EMB_BOUND = 0.22   # twice the measured value (0.102 queries / 0.108 keys of max|e|, min cosine 0.9954; DESIGN section 3)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_full_size_backward_serialised_vs_overlapped_streams(tmp_path, dtype):
+    """N=256 backward with every engine stream serialised (VINCE_WGRAD_STREAM=0, VINCE_DS_STREAM=0, key encoder inline)
+    against the shipped arrangement (weight gradients, downsample branch and key encoder on their own streams, 3-slot dY
+    ring).  A stream race is size-dependent and moves gradients by O(1); what legitimately differs is summation order --
+    fp32 atomics (1e-6) and, at the four stage-entry blocks, which of the two branch gradients is stored first and which is
+    added onto it (one rounding of the stored type: nothing in fp32, one bf16 ulp = 4e-3 per element in bf16).  So the fp32
+    run is held tightly and the bf16 run to bf16 noise."""
+    sampled = ["feature_extractor.model.layer1.0.downsample.0.weight", "feature_extractor.model.layer2.0.downsample.0.weight",
+               "feature_extractor.model.layer3.2.conv2.weight", "feature_extractor.model.conv1.weight"]
+    a = _dump(tmp_path, "ser", dtype, {"VINCE_WGRAD_STREAM": "0", "VINCE_DS_STREAM": "0", "VINCE_OVERLAP_KEY": "0"}, sampled)
+    b = _dump(tmp_path, "ovl", dtype, {}, sampled)
+    assert float(a["loss"]) == pytest.approx(float(b["loss"]), rel=1e-6)
+    np.testing.assert_allclose(a["embeddings"], b["embeddings"], rtol=0, atol=1e-6)
+    assert list(a["grad_names"]) == list(b["grad_names"])
+    worst = float(np.abs(a["grad_checksums"][:, 2] / b["grad_checksums"][:, 2] - 1).max())
+    print("serialised vs overlapped (%s): worst sum|g| ratio error %.2e" % (dtype, worst))
+    np.testing.assert_allclose(a["grad_checksums"][:, 2], b["grad_checksums"][:, 2], rtol=2e-4 if dtype == "fp32" else 2e-2)
+    for n in sampled:
+        assert _rel(a["grad_" + n], b["grad_" + n]) < (2e-3 if dtype == "fp32" else 5e-2), n

@@ -8,7 +8,9 @@ from vince_amd import ops
 dev = "cuda"
 SHAPES = [("l1 1x1 64->256", 56, 64, 256, 1), ("l1 3x3 64", 56, 64, 64, 3), ("l1 1x1 256->64", 56, 256, 64, 1),
           ("l2 3x3 128", 28, 128, 128, 3), ("l3 3x3 256", 14, 256, 256, 3), ("l3 1x1 1024->256", 14, 1024, 256, 1),
-          ("l3 1x1 256->1024", 14, 256, 1024, 1), ("l4 3x3 512", 7, 512, 512, 3)]
+          ("l3 1x1 256->1024", 14, 256, 1024, 1), ("l4 3x3 512", 7, 512, 512, 3),
+          ("l2 1x1 128->512", 28, 128, 512, 1), ("l2 1x1 512->128", 28, 512, 128, 1), ("l2 1x1 256->128@56", 56, 256, 128, 1),
+          ("l4 1x1 512->2048", 7, 512, 2048, 1), ("l4 1x1 2048->512", 7, 2048, 512, 1)]
 N = 256
 res = []
 for name, hw, ci, co, k in SHAPES:

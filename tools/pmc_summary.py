@@ -76,7 +76,24 @@ def main(fetch_db, write_db, out_json, source):
                 "bytes": int(2.0 * sf * 1024.0 + sw * 1024.0)}
         print("whole training step: fetch %.2f GB  write %.2f GB  total %.2f GB" % (step["fetch_bytes"] / 1e9,
               step["write_bytes"] / 1e9, step["bytes"] / 1e9))
-    json.dump({"kernels": kernels, "step": step, "source": source}, open(out_json, "w"), indent=1)
+    # stamp: which sources these counters were taken from (bench.py prints traffic_stale when the built kernels differ)
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        from bench import kernel_source_hash
+        khash = kernel_source_hash()
+    except Exception:
+        khash = None
+    head = os.environ.get("VINCE_GIT_HEAD")      # the GPU box has no .git: the caller exports it (tools/final_profile.sh)
+    if not head:
+        try:
+            head = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        except Exception:
+            head = None
+    json.dump({"kernels": kernels, "step": step, "source": source, "kernel_source_hash": khash, "git_head": head},
+              open(out_json, "w"), indent=1)
     for t, v in kernels.items():
         print("%-40s launches %5d  fetch %8.1f MB  write %8.1f MB  total %8.1f MB / launch"
               % (t, v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["bytes_per_launch"] / 1e6))
