@@ -133,6 +133,13 @@ typedef struct vince_conv_epi {
     int32_t replicas;         /* how many of the R replicas of `stats` / `bnred.sums` this launch spreads its atomics over
                                * (0 = all VINCE_STATS_REPLICAS); few workgroups need few replicas, and a consumer that
                                * folds them itself (vince_bn_train_apply, vince_bn_bwd_apply) then reads less */
+    /* Residual join with KNOWN BatchNorm constants (vince_bn_gram_finalize), only with VINCE_EPI_ACCUMULATE, in place:
+     *   out = [relu]( conv * out_scale[co] + bias[co] + (id_scale ? out_old * id_scale[co] + id_shift[co] : out_old) )
+     * i.e. the block's last BatchNorm (resnet.py:125-126), the identity / downsample-BatchNorm branch (:128-131) and the
+     * ReLU (:133) all in the epilogue of conv3 -- its raw output is never written.  NULL = 1 / identity. */
+    const float* out_scale;
+    const float* id_scale;
+    const float* id_shift;
 } vince_conv_epi;
 
 /* in/w/out have element type `dtype`.  epi may be NULL (plain store). */
@@ -176,10 +183,28 @@ typedef struct vince_bn_train {
     float* shift;
     float* save_mean;             /* optional outputs */
     float* save_invstd;
+    double* out_sum;              /* optional double[out_sum_replicas][C], zeroed by the caller: per-channel sums of the values
+                                   * this launch STORES (after ReLU, rounded to dtype), atomically accumulated -- the column sums
+                                   * vince_bn_gram_finalize needs beside the Gram matrix of the same tensor */
+    int32_t out_sum_replicas;
 } vince_bn_train;
 int vince_bn_train_apply(int dtype, const void* y, const vince_bn_train* bt, const void* identity, const float* id_scale,
                          const float* id_shift, void* out, uint8_t* mask_out, int64_t rows, int32_t C, int relu,
                          void* stream);
+
+/* Train-mode BatchNorm constants of a 1x1 convolution's output WITHOUT running the convolution first (resnet.py:125-126:
+ * bn3(conv3(a))).  For y = W a per pixel, mean_y = W mean_a and var_y[c] = w_c^T Cov(a) w_c, so the batch statistics of y follow
+ * from the Gram matrix of the conv INPUT:  gram = sum_pix a a^T  (float[K][K]; vince_conv_wgrad with in = dy = a) and its column
+ * sums (colsum double[R][K]; vince_bn_train.out_sum of the pass that wrote a).  Products are exact in fp32 for bf16 operands and
+ * the covariance is formed and contracted in fp64, so the result is the statistic of the UNROUNDED conv output -- closer to
+ * the fp32 reference than the statistics of a bf16-stored output.  K <= 512, K and Co multiples of the 16-byte chunk.
+ * Outputs as vince_bn_finalize(train): scale = gamma * invstd, shift = beta - mean * scale, save_mean / save_invstd, running
+ * statistics with the unbiased variance, num_batches_tracked += 1.  What this buys: conv3's epilogue can then apply BatchNorm +
+ * identity + ReLU (vince_conv_epi.out_scale) and the [rows][Co] raw output is neither written nor re-read. */
+int vince_bn_gram_finalize(int dtype, const float* gram, const double* colsum, int32_t colsum_replicas, int64_t count,
+                           const void* w, int32_t K, int32_t Co, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* scale,
+                           float* shift, float* save_mean, float* save_invstd, void* stream);
 
 /* out = [relu]( y*scale + shift + (identity ? (id_scale ? identity*id_scale + id_shift : identity) : 0) ).
  * mask_out (optional): one byte per 16-byte chunk of `out` (8 bf16 / 4 f32 channels), bit e = pre-ReLU value e > 0 --

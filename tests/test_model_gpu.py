@@ -759,6 +759,35 @@ def test_g7_per_rank_computation_vs_reference_chunkwise_emulation(world):
     assert rel((grads["feature_extractor.model.conv1.weight"] / world).cpu(), g[p + "meangrad_feature_extractor.model.conv1.weight"]) < 3e-2
 
 
+@pytest.mark.parametrize("dtype,arch", [("fp32", "ResNet50"), ("bf16", "ResNet50")])
+def test_gram_statistics_join_equals_separate_passes_in_the_model(monkeypatch, dtype, arch):
+    """No-grad train-mode forwards (the key encoder, forward + InfoNCE) take the Gram-statistics residual join in layer1 /
+    layer2 (csrc/trunk.hip gram_on); VINCE_GRAM_JOIN=0 runs the separate passes.  Same embeddings, same running statistics;
+    and the fp32 run still reproduces the reference's G3 goldens."""
+    g = load("g3_trunk.npz")
+    outs, stats = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VINCE_GRAM_JOIN", mode)
+        _, model = build(arch, 128, dtype, 11)
+        model.train()
+        x = vo.structured_frames(2, 224, 224, seed=500 + 224).to(DEV)
+        with torch.no_grad():
+            o = model.get_embeddings({"data": x})
+        outs[mode] = {k: o[k].float().cpu() for k in ("embeddings", "prenorm_features", "extracted_features")}
+        sd = model.state_dict()
+        stats[mode] = {k: sd[k].float().cpu() for k in sd if "layer1.1.bn3.running" in k or "layer2.0.bn3.running" in k
+                       or "layer2.0.downsample.1.running" in k or "layer1.0.bn3.num_batches" in k}
+    tol_e = 1e-4 if dtype == "fp32" else 0.15   # (2-image batch: the hardest case for bf16, DESIGN section 3)
+    for k in outs["1"]:
+        assert rel(outs["1"][k], outs["0"][k]) < tol_e, k
+    for k in stats["1"]:
+        assert rel(stats["1"][k], stats["0"][k]) < (1e-5 if dtype == "fp32" else 2e-2), k
+    if dtype == "fp32":
+        p = "%s_224_train_" % arch
+        assert rel(outs["1"]["embeddings"], g[p + "embeddings"]) < 5e-4
+        assert rel(outs["1"]["extracted_features"], g[p + "extracted"]) < 5e-4
+
+
 def test_two_ranks_on_one_gpu_stay_identical():
     """The multi-rank path on GPU hardware: two data-parallel ranks of the full solver share this one GPU through the
     gloo backend (NCCL refuses two ranks per device) -- parameter / queue broadcast, bucketed gradient all-reduce behind

@@ -563,3 +563,55 @@ def test_cpu_tensor_is_rejected():
     ops = _ops()
     with pytest.raises(RuntimeError):
         ops.l2norm_fwd(torch.randn(4, 64))
+
+
+# ---------------------------------------------------------------------------------------------- Gram-statistics residual join
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,hw,K,Co,ds", [(4, 14, 64, 256, False), (3, 9, 128, 512, True), (2, 5, 64, 256, True)])
+def test_gram_statistics_join_vs_separate_passes(dtype, N, hw, K, Co, ds):
+    """bn3(conv3(a)) + identity + ReLU (resnet.py:125-133) three ways: torch fp32/fp64 on the CPU, the engine's separate
+    passes, and the Gram route -- column sums from the pass that writes a, Gram matrix through the weight-gradient kernel,
+    vince_bn_gram_finalize, conv3 with the join in its epilogue (in place on the identity)."""
+    ops = _ops()
+    from vince_amd._lib import EPI_ACCUMULATE, EPI_RELU
+    rows = N * hw * hw
+    y2 = rnd(rows, K, seed=1) * (0.5 + torch.rand(K, generator=torch.Generator().manual_seed(2))) + rnd(K, seed=3) * 0.5
+    g2, b2 = torch.rand(K, generator=torch.Generator().manual_seed(4)) + 0.5, rnd(K, seed=5) * 0.3
+    w3 = rnd(Co, K, seed=6) * (2.0 / Co) ** 0.5
+    g3, b3 = torch.rand(Co, generator=torch.Generator().manual_seed(7)) + 0.5, rnd(Co, seed=8) * 0.3
+    idn = rnd(rows, Co, seed=9)
+    isc, ish = torch.rand(Co, generator=torch.Generator().manual_seed(10)) + 0.5, rnd(Co, seed=11) * 0.2
+    # ---- CPU reference in fp64 on the dtype-rounded operands
+    y2q, w3q, idq = q(y2, dtype).double(), q(w3, dtype).double(), q(idn, dtype).double()
+    m2, v2 = y2q.mean(0), y2q.var(0, unbiased=False)
+    a = q(torch.relu((y2q - m2) / torch.sqrt(v2 + 1e-5) * g2.double() + b2.double()).float(), dtype).double()
+    y3 = a @ w3q.t()
+    m3, v3 = y3.mean(0), y3.var(0, unbiased=False)
+    ident = idq * isc.double() + ish.double() if ds else idq
+    want = torch.relu((y3 - m3) / torch.sqrt(v3 + 1e-5) * g3.double() + b3.double() + ident)
+    # ---- GPU: bn2 apply with column sums
+    y2g, w3g = y2.to(DEV).to(dtype), w3.to(DEV).to(dtype).contiguous()
+    st2 = torch.stack([y2g.double().sum(0), (y2g.double() ** 2).sum(0)], 1)[None].contiguous()     # double[1][K][2]
+    colsum = torch.zeros(4, K, device=DEV, dtype=torch.float64)
+    ag, _, _, _, _, _ = ops.bn_train_apply(y2g, st2, rows, g2.to(DEV), b2.to(DEV), replicas=1, out_sum=colsum)
+    np.testing.assert_allclose(colsum.sum(0).cpu().numpy(), ag.double().sum(0).cpu().numpy(), rtol=1e-6, atol=1e-6)
+    assert_close(ag, a.float(), dtype, f32=2e-5, bf16=2e-2, what="a")
+    gram = torch.zeros(K, 1, K, device=DEV)
+    x4 = ag.view(N, hw, hw, K)
+    ops.conv_wgrad(ops.conv_desc(N, hw, hw, K, K, 1, 1, 0), x4, x4, gram)
+    rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+    nbt = torch.zeros(1, device=DEV, dtype=torch.int64)
+    consts = ops.bn_gram_finalize(gram.view(K, K), colsum, rows, w3g, g3.to(DEV), b3.to(DEV), rm, rv, nbt)
+    # statistics of the UNROUNDED conv output of the GPU's own a
+    y3g = ag.double() @ w3g.double().t()
+    mg, vg = y3g.mean(0), y3g.var(0, unbiased=False)
+    np.testing.assert_allclose(consts[2].cpu().numpy(), mg.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(consts[3].cpu().numpy(), (1.0 / torch.sqrt(vg + 1e-5)).cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * mg.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * vg * rows / (rows - 1)).cpu().numpy(), rtol=2e-5)
+    assert int(nbt) == 1
+    # ---- conv3 with the join in its epilogue, in place on the identity
+    z = idn.to(DEV).to(dtype).view(N, hw, hw, Co).contiguous()
+    ops.conv_igemm(ops.conv_desc(N, hw, hw, K, Co, 1, 1, 0), x4, w3g.view(Co, 1, K), z, bias=consts[1], flags=EPI_ACCUMULATE | EPI_RELU,
+                   out_scale=consts[0], id_scale=isc.to(DEV) if ds else None, id_shift=ish.to(DEV) if ds else None)
+    assert_close(z.view(rows, Co), want.float(), dtype, f32=5e-5, bf16=3e-2, what="join")

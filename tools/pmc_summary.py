@@ -8,16 +8,16 @@ import sys
 
 
 def tag_of(name):
-    m = re.search(r"conv_igemm_dlds_kernelI([tf])Li(\d+)ELi\d+ELi\d+ELi\d+ELi(\d+)ELb([01])E", name)
+    m = re.search(r"conv_igemm_dlds_kernelI([tf])Li(\d+)ELi\d+ELi\d+ELi\d+ELi(\d+)EL[bi]([012])E", name)
     if not m:
-        m2 = re.search(r"conv_igemm_dlds_kernel<(unsigned short|float), (\d+), \d+, \d+, \d+, (\d+), (true|false)>", name)
+        m2 = re.search(r"conv_igemm_dlds_kernel<(unsigned short|float), (\d+), \d+, \d+, \d+, (\d+), (true|false|0|1|2)[,>]", name)
         if not m2:
             if "conv_wgrad" in name:
                 return "conv_wgrad<%s>" % ("bf16" if ("It" in name or "unsigned short" in name) else "f32")
             return None
-        t, ct, ptl, b = m2.group(1) == "unsigned short", int(m2.group(2)), int(m2.group(3)), m2.group(4) == "true"
+        t, ct, ptl, b = m2.group(1) == "unsigned short", int(m2.group(2)), int(m2.group(3)), m2.group(4) in ("true", "1", "2")
     else:
-        t, ct, ptl, b = m.group(1) == "t", int(m.group(2)), int(m.group(3)), m.group(4) == "1"
+        t, ct, ptl, b = m.group(1) == "t", int(m.group(2)), int(m.group(3)), m.group(4) in ("1", "2")
     return "conv_igemm<%s,%dch x %dpx,%s>" % ("bf16" if t else "f32", ct, ptl, "bwd" if b else "fwd")
 
 

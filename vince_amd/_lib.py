@@ -24,14 +24,15 @@ class BnReduce(ctypes.Structure):
 
 class ConvEpi(ctypes.Structure):
     _fields_ = [("flags", c_int32), ("bias", c_void_p), ("stats", c_void_p), ("acc_mask", c_void_p),
-                ("bnred", BnReduce), ("in_scale", c_void_p), ("in_shift", c_void_p), ("replicas", c_int32)]
+                ("bnred", BnReduce), ("in_scale", c_void_p), ("in_shift", c_void_p), ("replicas", c_int32),
+                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p)]
 
 
 class BnTrain(ctypes.Structure):
     _fields_ = [("stats", c_void_p), ("replicas", c_int32), ("count", ctypes.c_int64), ("gamma", c_void_p), ("beta", c_void_p),
                 ("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p),
                 ("momentum", c_float), ("eps", c_float), ("scale", c_void_p), ("shift", c_void_p),
-                ("save_mean", c_void_p), ("save_invstd", c_void_p)]
+                ("save_mean", c_void_p), ("save_invstd", c_void_p), ("out_sum", c_void_p), ("out_sum_replicas", c_int32)]
 
 
 class InfoNCEDesc(ctypes.Structure):
@@ -60,6 +61,9 @@ PROTOTYPES = {
                                c_int64, c_int32, c_int, c_void_p]),
     "vince_bn_train_apply": (c_int, [c_int, c_void_p, P(BnTrain), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_int32, c_int, c_void_p]),
+    "vince_bn_gram_finalize": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
     "vince_bn_bwd_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "vince_bn_bwd_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

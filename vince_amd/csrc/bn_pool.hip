@@ -157,21 +157,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
         }
         __syncthreads();
     }
-    if (col >= w.cpr) return;
-    float sc[CH], sh[CH], isc[CH], ish[CH];
+    const bool want_sum = fin.out_sum != nullptr;   // uniform: per-channel sums of the stored values (vince_bn_gram_finalize)
+    const bool active = col < w.cpr;
+    if (!active && !want_sum) return;
+    float sc[CH], sh[CH], isc[CH], ish[CH], osum[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
         const int cl = (threadIdx.x % w.tpc) * CH + e;
-        sc[e] = fin.stats ? cst[0][cl] : scale[col * CH + e];
-        sh[e] = fin.stats ? cst[1][cl] : shift[col * CH + e];
-        isc[e] = ids ? ids[col * CH + e] : 1.f;
-        ish[e] = ids ? idt[col * CH + e] : 0.f;
+        sc[e] = !active ? 0.f : (fin.stats ? cst[0][cl] : scale[col * CH + e]);
+        sh[e] = !active ? 0.f : (fin.stats ? cst[1][cl] : shift[col * CH + e]);
+        isc[e] = (ids && active) ? ids[col * CH + e] : 1.f;
+        ish[e] = (ids && active) ? idt[col * CH + e] : 0.f;
+        osum[e] = 0.f;
     }
     const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + threadIdx.x / w.tpc;
     const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
     // 4 rows per trip with all loads issued first: more bytes in flight per wave (the kernel is a pure HBM stream)
     constexpr int U = 4;
-    for (int64_t rb = r0; rb < r1; rb += (int64_t)U * w.rpp) {
+    for (int64_t rb = r0; active && rb < r1; rb += (int64_t)U * w.rpp) {
         uint4 yv[U], iv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -207,8 +210,110 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
                 for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
             }
-            *(uint4*)(out + off) = Chunk<T>::pack(f);
+            const uint4 pv = Chunk<T>::pack(f);
+            *(uint4*)(out + off) = pv;
+            if (want_sum) {   // sum what a reader of `out` will see (the rounded values)
+                float q[CH];
+                Chunk<T>::unpack(pv, q);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) osum[e] += q[e];
+            }
         }
+    }
+    if (want_sum) {
+        // threads that share a chunk column (same threadIdx.x % tpc) fold through LDS; one fp64 atomic per channel per workgroup
+        __syncthreads();                                  // (the constants in cst[] were copied to registers above)
+        float* red = &cst[0][0];                          // [256][CH] floats fit: cst is [2][256 * CH]
+#pragma unroll
+        for (int e = 0; e < CH; ++e) red[threadIdx.x * CH + e] = osum[e];
+        __syncthreads();
+        const int nch = w.tpc * CH;
+        for (int cl = threadIdx.x; cl < nch; cl += 256) {
+            const int tc = cl / CH, e = cl % CH, c = (blockIdx.x * w.tpc + tc) * CH + e;
+            if (c >= C) continue;
+            float sacc = 0.f;
+            for (int r = 0; r < w.rpp; ++r) sacc += red[(r * w.tpc + tc) * CH + e];
+            const int rep = fin.out_sum_replicas > 0 ? (int)(blockIdx.y % (unsigned)fin.out_sum_replicas) : 0;
+            unsafeAtomicAdd(fin.out_sum + (size_t)rep * C + c, (double)sacc);
+        }
+    }
+}
+
+// BatchNorm constants of y = W a from the Gram matrix of a (include/vince_hip.h: vince_bn_gram_finalize):
+//   mean_y[c] = w_c . mean_a,   E[y^2][c] = w_c^T (G / count) w_c,   var = E[y^2] - mean_y^2   (fp64 from the fp32 Gram sums).
+// One wavefront per output channel, GF_NC = 4 channels per workgroup (Co / 4 workgroups: enough of them to matter on 256 CUs).
+// The workgroup first pulls G into LDS with every load in flight at once (K <= GF_LDS_K: 64 KB; longer reductions read G from
+// L2), then lane l owns the columns k2 = l, l + 64, ..., walks the rows k and keeps p[k2] = sum_k w[k] G[k][k2]; the
+// contraction with w[k2] and the fold over lanes happen once at the end.
+constexpr int GF_NC = 4, GF_LDS_K = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void bn_gram_finalize_kernel(const float* __restrict__ gram, const double* __restrict__ colsum,
+                                                               int R, double count, const T* __restrict__ W, int K, int Co,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* running_mean, float* running_var, int64_t* nbt,
+                                                               float momentum, float eps, float* scale, float* shift,
+                                                               float* save_mean, float* save_invstd) {
+    __shared__ double mean_a[512];
+    __shared__ float wl[GF_NC][512];
+    __shared__ __attribute__((aligned(16))) float gs[GF_LDS_K * GF_LDS_K];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool staged = K <= GF_LDS_K;
+    if (staged) {
+        const int n4 = K * K / 4;                                  // K is a multiple of 4
+        for (int i = tid; i < n4; i += 256) ((float4*)gs)[i] = ((const float4*)gram)[i];
+    }
+    for (int k = tid; k < K; k += 256) {
+        double sk = 0;
+        for (int r = 0; r < R; ++r) sk += colsum[(size_t)r * K + k];
+        mean_a[k] = sk / count;
+    }
+    for (int i = tid; i < GF_NC * K; i += 256) {
+        const int cc = blockIdx.x * GF_NC + i / K, k = i % K;
+        float v = 0.f;
+        if (cc < Co) {
+            if constexpr (sizeof(T) == 4) v = ((const float*)W)[(size_t)cc * K + k];
+            else v = bf16_to_f32(((const bf16_t*)W)[(size_t)cc * K + k]);
+        }
+        wl[i / K][k] = v;
+    }
+    __syncthreads();
+    const float* __restrict__ G = staged ? gs : gram;
+    const float* wrow = wl[wave];
+    double q = 0, mu = 0;
+    for (int k2 = lane; k2 < K; k2 += 64) {
+        double p0 = 0, p1 = 0;                                      // two chains: the fp64 adds are dependent
+        for (int k = 0; k < K; k += 4) {
+            p0 += (double)wrow[k] * (double)G[(size_t)k * K + k2];
+            p1 += (double)wrow[k + 1] * (double)G[(size_t)(k + 1) * K + k2];
+            p0 += (double)wrow[k + 2] * (double)G[(size_t)(k + 2) * K + k2];
+            p1 += (double)wrow[k + 3] * (double)G[(size_t)(k + 3) * K + k2];
+        }
+        const double w2 = (double)wrow[k2];
+        q += (p0 + p1) * w2;
+        mu += w2 * mean_a[k2];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        q += __shfl_xor(q, o, 64);
+        mu += __shfl_xor(mu, o, 64);
+    }
+    const int c = blockIdx.x * GF_NC + wave;
+    if (lane == 0 && c < Co) {
+        double var = q / count - mu * mu;
+        if (var < 0) var = 0;
+        const float mean = (float)mu;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scv = gamma[c] * invstd;
+        scale[c] = scv;
+        shift[c] = beta[c] - mean * scv;
+        if (save_mean) save_mean[c] = mean;
+        if (save_invstd) save_invstd[c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1 ? var * count / (count - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+        if (c == 0 && nbt) *nbt += 1;
     }
 }
 
@@ -753,6 +858,29 @@ extern "C" int vince_bn_train_apply(int dtype, const void* y, const vince_bn_tra
     else
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, nullptr,
                            nullptr, (const bf16_t*)identity, id_scale, id_shift, (bf16_t*)out, mask_out, rows, C, relu, w, fin);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_bn_gram_finalize(int dtype, const float* gram, const double* colsum, int32_t colsum_replicas, int64_t count,
+                                      const void* w, int32_t K, int32_t Co, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                      float eps, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+    DTYPE_OK("vince_bn_gram_finalize");
+    VINCE_CHECK_ARG(gram && colsum && w && gamma && beta && scale && shift && count > 0 && colsum_replicas > 0, VINCE_E_ARG,
+                    "vince_bn_gram_finalize: bad arguments");
+    VINCE_CHECK_ARG(K > 0 && K <= 512 && Co > 0 && K % CH_OF(dtype) == 0, VINCE_E_SHAPE,
+                    "vince_bn_gram_finalize: K=%d (1..512, multiple of %d), Co=%d", K, CH_OF(dtype), Co);
+    VINCE_CHECK_ARG(!running_mean == !running_var, VINCE_E_ARG, "vince_bn_gram_finalize: running_mean and running_var come together");
+    const dim3 grid((Co + GF_NC - 1) / GF_NC);
+    if (dtype == VINCE_F32)
+        hipLaunchKernelGGL(bn_gram_finalize_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, gram, colsum, colsum_replicas,
+                           (double)count, (const float*)w, K, Co, gamma, beta, running_mean, running_var, num_batches_tracked,
+                           momentum, eps, scale, shift, save_mean, save_invstd);
+    else
+        hipLaunchKernelGGL(bn_gram_finalize_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, gram, colsum, colsum_replicas,
+                           (double)count, (const bf16_t*)w, K, Co, gamma, beta, running_mean, running_var, num_batches_tracked,
+                           momentum, eps, scale, shift, save_mean, save_invstd);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

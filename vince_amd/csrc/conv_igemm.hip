@@ -72,11 +72,15 @@ struct Smem {
     static constexpr int BYTES = MAIN > EPI ? MAIN : EPI;
 };
 
-template <typename T, int CT, int CRS, bool BWD, int PTL = PT, int UBM = 4>
+// MODE: 0 = forward (bias / ReLU / statistics), 1 = gradient epilogues (residual-gradient join through acc_mask, fused BatchNorm-
+// backward reduction), 2 = forward residual join with known BatchNorm constants (out_scale / bias / id_scale / id_shift / ReLU,
+// in place).  Separate instantiations keep each one's per-thread constant arrays -- and so its registers -- to what it uses.
+template <typename T, int CT, int CRS, int MODE, int PTL = PT, int UBM = 4>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char* smem, f32x16_t (&acc)[CT / 64][PTL / 64],
                                               uint32_t tile, int p0, int c0, int tid, int lane, int wave, int wp, int wc) {
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64, PI = PTL / 64;
+    constexpr bool BWD = MODE == 1, JOIN = MODE == 2;
     const vince_conv_desc& d = p.d;
     // ---- epilogue: accumulators -> LDS [pixel][channel] as T -> coalesced 16-byte stores --------------------
 #pragma unroll
@@ -107,6 +111,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     float bias_v[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) bias_v[e] = (p.e.bias && cvalid && blockIdx.y == 0) ? p.e.bias[cbase + e] : 0.f;
+    // residual join with known BatchNorm constants (MODE 2): conv * osc + bias + (old * isc + ish)
+    float osc_v[CH], isc_v[CH], ish_v[CH];
+    const bool id_affine = JOIN && p.e.id_scale != nullptr;
+    if constexpr (JOIN) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            osc_v[e] = (p.e.out_scale && cvalid) ? p.e.out_scale[cbase + e] : 1.f;
+            isc_v[e] = (id_affine && cvalid) ? p.e.id_scale[cbase + e] : 1.f;
+            ish_v[e] = (id_affine && cvalid) ? p.e.id_shift[cbase + e] : 0.f;
+        }
+    }
     float ssum[CH], ssq[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) ssum[e] = ssq[e] = 0.f;
@@ -115,7 +130,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     const int flags = p.e.flags;
     // BWD (compile time): the gradient epilogues -- residual join (ACCUMULATE, acc_mask) and the fused BatchNorm-backward
     // reduction (bnred).  Forward launches take the lean instantiation.
-    const bool accum = BWD && (flags & VINCE_EPI_ACCUMULATE) != 0;
+    const bool accum = (BWD || JOIN) && (flags & VINCE_EPI_ACCUMULATE) != 0;
     const bool touch = p.e.bias || accum || (flags & VINCE_EPI_RELU);
     const T* __restrict__ br_y = BWD ? (const T*)p.e.bnred.y : nullptr;
     float br_mu[CH], br_is[CH], br_sc[CH], br_sh[CH];
@@ -150,6 +165,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
                 opix = ((size_t)n * d.OH + (ho * d.osh + d.oh0)) * d.OW + (wo * d.osw + d.ow0);
             }
             off[u] = opix * d.Co + cbase;
+            if constexpr (JOIN) {
+                if (ok[u] && accum) oldv[u] = *(const uint4*)(out + off[u]);
+            }
             if constexpr (BWD) {
                 ab[u] = bb[u] = 0xffu;
                 if (ok[u]) {
@@ -172,8 +190,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
             if (touch) {
                 float f[CH];
                 Chunk<T>::unpack(v, f);
+                if constexpr (JOIN) {
 #pragma unroll
-                for (int e = 0; e < CH; ++e) f[e] += bias_v[e];
+                    for (int e = 0; e < CH; ++e) f[e] = f[e] * osc_v[e] + bias_v[e];
+                    if (accum) {
+                        float o[CH];
+                        Chunk<T>::unpack(oldv[u], o);
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) f[e] += o[e] * isc_v[e] + ish_v[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) f[e] += bias_v[e];
+                }
                 if constexpr (BWD) {
                     if (accum) {
                         float o[CH];
@@ -258,7 +287,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     }
 }
 
-template <typename T, int CT, int KC, bool BWD>
+template <typename T, int CT, int KC, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64;          // 32-channel MFMA tiles per wave
@@ -361,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         __syncthreads();
     }
 
-    conv_epilogue<T, CT, Smem<T, CT, KC>::CRS, BWD>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
+    conv_epilogue<T, CT, Smem<T, CT, KC>::CRS, MODE>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
 
@@ -392,7 +421,7 @@ struct SmemD {
 // PTL = pixels per workgroup tile (128 or 256).  The L2 -> LDS fill rate of a CU (measured ~19 B/clk with every CU
 // streaming) caps a 128x128 tile at ~700 TFLOP/s chip-wide: 256 B of operands per K element feed 32768 FLOP.  The
 // 256-pixel tile moves 25 % fewer bytes per FLOP (each wave owns 128 pixels x CT/2 channels).
-template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, bool BWD, bool XF = false>
+template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, int MODE, bool XF = false>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64, PI = PTL / 64;
@@ -595,7 +624,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     wait_vmcnt<0>();
     __syncthreads();
     // rows in flight per thread in the epilogue: the 128-VGPR (4 workgroups/CU) configuration has no room for more than 2
-    conv_epilogue<T, CT, S::CRS, BWD, PTL, (MINW >= 4 ? 2 : 4)>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
+    conv_epilogue<T, CT, S::CRS, MODE, PTL, (MINW >= 4 ? 2 : 4)>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
 __global__ void relu_inplace_kernel(float* x, size_t n4) {
@@ -605,8 +634,9 @@ __global__ void relu_inplace_kernel(float* x, size_t n4) {
     }
 }
 
-template <typename T, int CT, bool BWD>
+template <typename T, int CT, int MODE>
 int launch(ConvParams& p, hipStream_t stream) {
+    constexpr bool BWD = MODE != 0;   // (anything but the lean forward epilogue)
     static int dlds_min_k = getenv("VINCE_DLDS_MIN_K") ? atoi(getenv("VINCE_DLDS_MIN_K")) : 0;
     const int k_elems = p.total_chunks * (16 / (int)sizeof(T));
     // VINCE_DLDS_CFG=4 forces the 128-pixel tile everywhere (measurement aid); the default (5) adds the 256-pixel tile
@@ -631,10 +661,10 @@ int launch(ConvParams& p, hipStream_t stream) {
                 p.variant = 1;
                 if (xf) {
                     if constexpr (!BWD)
-                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, false, true>), dim3(p.ptiles * p.ctiles),
+                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, 0, true>), dim3(p.ptiles * p.ctiles),
                                            dim3(256), 0, stream, p);
                 } else {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
                                        stream, p);
                 }
             }
@@ -646,10 +676,10 @@ int launch(ConvParams& p, hipStream_t stream) {
                 p.variant = 1;
                 if (xf) {
                     if constexpr (!BWD)
-                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, false, true>), dim3(p.ptiles * p.ctiles),
+                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, 0, true>), dim3(p.ptiles * p.ctiles),
                                            dim3(256), 0, stream, p);
                 } else {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
                                        stream, p);
                 }
             }
@@ -672,16 +702,16 @@ int launch(ConvParams& p, hipStream_t stream) {
                 splits = (p.nkt + p.kt_per_split - 1) / p.kt_per_split;
                 const size_t n = (size_t)p.M * p.d.Co;
                 if (int zrc = vince_zero_async(p.out, n * sizeof(float), stream)) return zrc;
-                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, BWD>), dim3(p.ptiles * p.ctiles, splits), dim3(256), 0,
+                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE>), dim3(p.ptiles * p.ctiles, splits), dim3(256), 0,
                                    stream, p);
                 if (relu) hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)min((size_t)1024, (n / 4 + 255) / 256)), dim3(256), 0,
                                              stream, (float*)p.out, n / 4);
             } else if (xf) {
                 if constexpr (!BWD)
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, false, true>), dim3(p.ptiles * p.ctiles), dim3(256),
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, 0, true>), dim3(p.ptiles * p.ctiles), dim3(256),
                                        0, stream, p);
             } else {
-                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, BWD>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
             }
         }
         VINCE_CHECK_LAUNCH();
@@ -692,10 +722,10 @@ int launch(ConvParams& p, hipStream_t stream) {
     p.variant = 2;
     if (k_elems >= 1024) {
         p.nkt = (p.total_chunks + 7) / 8;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 8, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 8, (MODE == 2 ? 2 : 1)>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
     } else {
         p.nkt = (p.total_chunks + 3) / 4;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 4, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 4, (MODE == 2 ? 2 : 1)>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
     }
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
@@ -713,6 +743,9 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     VINCE_CHECK_ARG(!e.bnred.y || (e.bnred.mean && e.bnred.invstd && e.bnred.sums && !e.stats), VINCE_E_ARG,
                     "vince_conv_igemm: bnred needs y, mean, invstd and sums, and excludes stats");
     VINCE_CHECK_ARG(!e.in_scale == !e.in_shift, VINCE_E_ARG, "vince_conv_igemm: in_scale and in_shift come together");
+    VINCE_CHECK_ARG(!e.id_scale == !e.id_shift, VINCE_E_ARG, "vince_conv_igemm: id_scale and id_shift come together");
+    VINCE_CHECK_ARG((!e.out_scale && !e.id_scale) || ((e.flags & VINCE_EPI_ACCUMULATE) && !e.acc_mask && !e.bnred.y && !e.stats), VINCE_E_ARG,
+                    "vince_conv_igemm: out_scale / id_scale need VINCE_EPI_ACCUMULATE and exclude acc_mask, bnred and stats");
     VINCE_CHECK_ARG(!e.in_scale || (dd->Ci <= 512 && dd->Cs == 0 && !(e.flags & VINCE_EPI_ACCUMULATE) && !e.bnred.y), VINCE_E_UNSUPPORTED,
                     "vince_conv_igemm: operand transform: Ci <= 512, no packed row taps, forward epilogue only");
     VINCE_CHECK_ARG(!e.bnred.mask_scale == !e.bnred.mask_shift, VINCE_E_ARG,
@@ -798,12 +831,15 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     }
     int rc;
     const bool bwd = (e.flags & VINCE_EPI_ACCUMULATE) || e.bnred.y;   // gradient epilogue instantiation
+    const bool join = e.out_scale || e.id_scale;   // forward residual join with known BatchNorm constants
     if (dtype == VINCE_F32) {
-        if (bwd) rc = narrow ? launch<float, 64, true>(p, s) : launch<float, 128, true>(p, s);
-        else rc = narrow ? launch<float, 64, false>(p, s) : launch<float, 128, false>(p, s);
+        if (join) rc = narrow ? launch<float, 64, 2>(p, s) : launch<float, 128, 2>(p, s);
+        else if (bwd) rc = narrow ? launch<float, 64, 1>(p, s) : launch<float, 128, 1>(p, s);
+        else rc = narrow ? launch<float, 64, 0>(p, s) : launch<float, 128, 0>(p, s);
     } else {
-        if (bwd) rc = narrow ? launch<bf16_t, 64, true>(p, s) : launch<bf16_t, 128, true>(p, s);
-        else rc = narrow ? launch<bf16_t, 64, false>(p, s) : launch<bf16_t, 128, false>(p, s);
+        if (join) rc = narrow ? launch<bf16_t, 64, 2>(p, s) : launch<bf16_t, 128, 2>(p, s);
+        else if (bwd) rc = narrow ? launch<bf16_t, 64, 1>(p, s) : launch<bf16_t, 128, 1>(p, s);
+        else rc = narrow ? launch<bf16_t, 64, 0>(p, s) : launch<bf16_t, 128, 0>(p, s);
     }
     if (tok) {
         // one tag per kernel symbol: [dtype][64ch | 128ch] x [128px | 256px][fwd | bwd epilogue]; the register-staged

@@ -42,9 +42,12 @@ struct Blk {
     ConvL cd;
     BnL bd;
     size_t x_in, y[3], a[2], yd, z, zmask;   // byte offsets in workspace (zmask: 1 byte per 16-B chunk of z)
+    size_t gram, colsum;                      // Gram-statistics scratch of conv3's input (byte offsets; NONE: not eligible)
 };
 
 constexpr size_t NONE = (size_t)-1;
+// Gram-statistics residual join: conv3 reductions up to this length; replicas of the column sums
+constexpr int GRAM_MAX_K = 128, GRAM_R = 4;
 
 }  // namespace
 
@@ -65,6 +68,7 @@ struct vince_trunk {
     std::vector<int> bnC;
     size_t off_x0, off_ystem, off_amax, off_p0, off_stats, off_sums, off_consts, off_g[3], off_dy[3];
     size_t n_stats_doubles, n_consts_floats, max_act, ws_bytes, wc_bytes, off_prep_table;
+    size_t off_gram = 0, gram_bytes = 0;      // Gram matrices + column sums of the eligible blocks (zeroed per forward)
     std::vector<vince_prep_entry> prep_table[2];   // last uploaded batched weight-prep descriptors (training / folded)
     void* prep_table_dev[2] = {nullptr, nullptr};
     size_t off_fold;      // fold constants (scale, bias per BN channel + ones/zeros) inside a weight cache
@@ -301,6 +305,17 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     t->off_stats = P.ws; P.ws = align_up(P.ws + P.nd * sizeof(double));
     t->off_sums = P.ws; P.ws = align_up(P.ws + P.nd * sizeof(double));
     t->off_consts = P.ws; P.ws = align_up(P.ws + P.nf * sizeof(float));
+    // Gram-statistics scratch (no-grad train-mode forwards, see gram_join_fwd): per eligible bottleneck block a float[w][w]
+    // Gram matrix of conv3's input and double[GRAM_R][w] column sums
+    t->off_gram = P.ws;
+    for (Blk& b : t->blocks) {
+        b.gram = b.colsum = NONE;
+        if (b.nconv == 3 && b.c[2].Ci <= GRAM_MAX_K) {
+            b.gram = P.ws; P.ws = align_up(P.ws + (size_t)b.c[2].Ci * b.c[2].Ci * sizeof(float));
+            b.colsum = P.ws; P.ws = align_up(P.ws + (size_t)GRAM_R * b.c[2].Ci * sizeof(double));
+        }
+    }
+    t->gram_bytes = P.ws - t->off_gram;
     for (int i = 0; i < 3; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     for (int i = 0; i < 3; ++i) { t->off_dy[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     t->off_dyd = P.ws; P.ws = align_up(P.ws + t->max_act);
@@ -414,13 +429,14 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
 
 // out = relu(bn(y) [+ identity affine]); in train mode the BatchNorm's finalize is fused into the same launch
 int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const void* idn, const float* ids, const float* idt,
-                 void* out, uint8_t* mask_out, float* const* bn_running, int64_t* const* bn_nbt, int train_bn) {
+                 void* out, uint8_t* mask_out, float* const* bn_running, int64_t* const* bn_nbt, int train_bn,
+                 double* out_sum = nullptr) {
     const int64_t rows = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
     static const bool fuse_fin = !(getenv("VINCE_FUSE_FINALIZE") && atoi(getenv("VINCE_FUSE_FINALIZE")) == 0);
     if (!train_bn)
         return vince_bn_apply(c.dtype, at(c.ws, y_off), c.consts(bn, 0), c.consts(bn, 1), idn, ids, idt, out, mask_out, rows,
                               cv.Co, 1, c.stream);
-    if (!fuse_fin) {   // measurement aid: the two launches of the unfused path
+    if (!fuse_fin && !out_sum) {   // measurement aid: the two launches of the unfused path
         RC(vince_bn_finalize(c.stats(bn), rows, bn.C, c.params[bn.gamma], c.params[bn.beta], bn_running[2 * bn.index],
                              bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr, 0.1f, 1e-5f, 1,
                              c.consts(bn, 0), c.consts(bn, 1), c.consts(bn, 2), c.consts(bn, 3), c.stream));
@@ -443,6 +459,8 @@ int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const voi
     bt.shift = c.consts(bn, 1);
     bt.save_mean = c.consts(bn, 2);
     bt.save_invstd = c.consts(bn, 3);
+    bt.out_sum = out_sum;
+    bt.out_sum_replicas = GRAM_R;
     return vince_bn_train_apply(c.dtype, at(c.ws, y_off), &bt, idn, ids, idt, out, mask_out, rows, cv.Co, 1, c.stream);
 }
 
@@ -699,18 +717,32 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_wg, hipEventDisableTiming));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_done, hipEventDisableTiming));
     }
-    for (const Blk& b : t->blocks) {
-        size_t in = b.x_in;
+    // Gram-statistics residual join (no-grad train-mode forwards: the key encoder, forward + InfoNCE): for a bottleneck's
+    // conv3 = 1x1 with a short reduction, the batch statistics of bn3 follow from the Gram matrix of conv3's INPUT
+    // (vince_bn_gram_finalize), so they are known BEFORE conv3 runs and its epilogue applies bn3 + identity + ReLU in place on
+    // the identity tensor -- y3 is neither written nor re-read and conv3 carries no statistics epilogue (28 -> 21 tensor
+    // passes per block).  Backward needs y3, so grad-enabled forwards keep the separate passes.  VINCE_GRAM_JOIN=0: off.
+    const bool gram_on = !(getenv("VINCE_GRAM_JOIN") && atoi(getenv("VINCE_GRAM_JOIN")) == 0) && train_bn && !save && !fuse_xf &&
+                         !ds_side && !vince_profile_enabled();
+    if (gram_on && t->gram_bytes)
+        RC(vince_zero_async(at(workspace, t->off_gram), t->gram_bytes, stream));
+    size_t cur = t->off_p0;   // where the running block input lives (gram blocks update it in place, so b.x_in may be stale)
+    for (size_t bi = 0; bi < t->blocks.size(); ++bi) {
+        const Blk& b = t->blocks[bi];
+        const size_t x_in = cur;
+        size_t in = x_in;
+        const bool gram_blk = gram_on && b.gram != NONE && bi + 1 < t->blocks.size();
         if (b.has_ds && ds_side) {
             Ctx cd = c;
             cd.stream = (void*)t->ds_stream;
             VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_start, (hipStream_t)stream));
             VINCE_CHECK_HIP(hipStreamWaitEvent(t->ds_stream, t->ev_ds_start, 0));
-            RC(conv_bn_fwd(cd, b.cd, b.bd, b.x_in, b.yd, bn_running, bn_nbt, train_bn, true));
+            RC(conv_bn_fwd(cd, b.cd, b.bd, x_in, b.yd, bn_running, bn_nbt, train_bn, true));
             VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_done, t->ds_stream));
         }
         const BnL* pending = nullptr;   // BatchNorm + ReLU deferred into the next conv's operand path (no-grad forwards)
-        for (int ci = 0; ci < b.nconv; ++ci) {
+        const int nplain = gram_blk ? b.nconv - 1 : b.nconv;   // convs that run with their own statistics epilogue
+        for (int ci = 0; ci < nplain; ++ci) {
             const bool defer = fuse_xf && ci < b.nconv - 1 && b.c[ci].Co <= 512 &&
                                (xf_mode == 1 || (xf_mode == 2 && b.c[ci + 1].k == 1) || (xf_mode == 3 && b.c[ci + 1].k == 3));
             RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, defer, nullptr, pending));
@@ -720,23 +752,55 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
                     pending = &b.b[ci];
                     in = b.y[ci];
                 } else {
+                    // (the pass that writes conv3's input also sums it per channel when the Gram path follows)
+                    double* osum = (gram_blk && ci == b.nconv - 2) ? (double*)at(workspace, b.colsum) : nullptr;
                     RC(bn_apply_fwd(c, b.c[ci], b.b[ci], b.y[ci], nullptr, nullptr, nullptr, at(workspace, b.a[ci]), nullptr,
-                                    bn_running, bn_nbt, train_bn));
+                                    bn_running, bn_nbt, train_bn, osum));
                     in = b.a[ci];
                 }
             }
         }
         const int L = b.nconv - 1;
         uint8_t* zmask = (uint8_t*)at(workspace, b.zmask);
+        if (gram_blk) {
+            const ConvL& cv = b.c[L];
+            const BnL& bn = b.b[L];
+            const int64_t rows = (int64_t)N * cv.Ho * cv.Wo;
+            // Gram matrix of conv3's input through the weight-gradient kernel (in = dy = a): sum over pixels of a a^T
+            vince_conv_desc dg = fwd_desc(t, cv);
+            dg.Co = cv.Ci;
+            RC(vince_conv_wgrad(&dg, c.dtype, at(workspace, in), at(workspace, in), (float*)at(workspace, b.gram), cv.Ci, 0, stream));
+            RC(vince_bn_gram_finalize(c.dtype, (const float*)at(workspace, b.gram), (const double*)at(workspace, b.colsum), GRAM_R,
+                                      rows, at((void*)wcache, cv.wk), cv.Ci, cv.Co, params[bn.gamma], params[bn.beta],
+                                      bn_running[2 * bn.index], bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr,
+                                      0.1f, 1e-5f, c.consts(bn, 0), c.consts(bn, 1), c.consts(bn, 2), c.consts(bn, 3), stream));
+            vince_conv_epi e;
+            memset(&e, 0, sizeof(e));
+            e.flags = VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU;
+            e.out_scale = c.consts(bn, 0);
+            e.bias = c.consts(bn, 1);
+            size_t out = x_in;                 // identity blocks: the join lands on the block input, in place
+            if (b.has_ds) {                    // stage entry: on the downsample conv's raw output, read through its BatchNorm affine
+                RC(conv_bn_fwd(c, b.cd, b.bd, x_in, b.yd, bn_running, bn_nbt, train_bn, true));
+                e.id_scale = c.consts(b.bd, 0);
+                e.id_shift = c.consts(b.bd, 1);
+                out = b.yd;
+            }
+            const vince_conv_desc d3 = fwd_desc(t, cv);
+            RC(vince_conv_igemm(&d3, c.dtype, at(workspace, in), at((void*)wcache, cv.wk), at(workspace, out), &e, stream));
+            cur = out;
+            continue;
+        }
         if (b.has_ds) {   // the downsample BatchNorm enters the join as an affine of its conv output: finalised on its own
             if (ds_side) VINCE_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, t->ev_ds_done, 0));
-            else RC(conv_bn_fwd(c, b.cd, b.bd, b.x_in, b.yd, bn_running, bn_nbt, train_bn, true));
+            else RC(conv_bn_fwd(c, b.cd, b.bd, x_in, b.yd, bn_running, bn_nbt, train_bn, true));
             RC(bn_apply_fwd(c, b.c[L], b.b[L], b.y[L], at(workspace, b.yd), c.consts(b.bd, 0), c.consts(b.bd, 1),
                             at(workspace, b.z), zmask, bn_running, bn_nbt, train_bn));
         } else {
-            RC(bn_apply_fwd(c, b.c[L], b.b[L], b.y[L], at(workspace, b.x_in), nullptr, nullptr, at(workspace, b.z), zmask,
+            RC(bn_apply_fwd(c, b.c[L], b.b[L], b.y[L], at(workspace, x_in), nullptr, nullptr, at(workspace, b.z), zmask,
                             bn_running, bn_nbt, train_bn));
         }
+        cur = b.z;
     }
     RC(vince_avgpool_fwd(c.dtype, at(workspace, t->blocks.back().z), pooled, N, t->outH * t->outW, t->outC, stream));
     return VINCE_OK;

@@ -116,9 +116,9 @@ def bn_reduce_arg(y, mean, invstd, sums, mask_bits=None, mask_scale=None, mask_s
 
 
 def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None, replicas=0, in_scale=None,
-               in_shift=None):
+               in_shift=None, out_scale=None, id_scale=None, id_shift=None):
     """vince_conv_igemm with the epilogue options of vince_conv_epi."""
-    require_gpu(x, w, out, bias, stats, acc_mask, in_scale, in_shift)
+    require_gpu(x, w, out, bias, stats, acc_mask, in_scale, in_shift, out_scale, id_scale, id_shift)
     e = ConvEpi()
     e.flags = flags
     e.bias = None if bias is None else bias.data_ptr()
@@ -129,6 +129,9 @@ def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, b
     e.replicas = replicas
     e.in_scale = None if in_scale is None else in_scale.data_ptr()   # operand transform relu(x * scale + shift)
     e.in_shift = None if in_shift is None else in_shift.data_ptr()
+    e.out_scale = None if out_scale is None else out_scale.data_ptr()   # residual join with known BatchNorm constants
+    e.id_scale = None if id_scale is None else id_scale.data_ptr()
+    e.id_shift = None if id_shift is None else id_shift.data_ptr()
     check(lib().vince_conv_igemm(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(w), _ptr(out), ctypes.byref(e),
                                  stream_ptr()))
     return out
@@ -212,9 +215,10 @@ def bn_apply(y, scale, shift, identity=None, id_scale=None, id_shift=None, relu=
 
 
 def bn_train_apply(y, stats, count, gamma, beta, running_mean=None, running_var=None, nbt=None, identity=None, id_scale=None,
-                   id_shift=None, relu=True, want_mask=False, replicas=0, momentum=0.1, eps=1e-5):
-    """Train-mode finalize + apply in one launch.  Returns (out, mask or None, scale, shift, mean, invstd)."""
-    require_gpu(y, stats, gamma, beta, running_mean, running_var, nbt, identity, id_scale, id_shift)
+                   id_shift=None, relu=True, want_mask=False, replicas=0, momentum=0.1, eps=1e-5, out_sum=None):
+    """Train-mode finalize + apply in one launch.  Returns (out, mask or None, scale, shift, mean, invstd).
+    out_sum: optional zeroed double[R][C] -- per-channel sums of the stored output are accumulated into it."""
+    require_gpu(y, stats, gamma, beta, running_mean, running_var, nbt, identity, id_scale, id_shift, out_sum)
     C = y.shape[-1]
     ch = 4 if y.dtype == torch.float32 else 8
     out = torch.empty_like(y)
@@ -228,9 +232,23 @@ def bn_train_apply(y, stats, count, gamma, beta, running_mean=None, running_var=
     bt.num_batches_tracked = None if nbt is None else nbt.data_ptr()
     bt.momentum, bt.eps = momentum, eps
     bt.scale, bt.shift, bt.save_mean, bt.save_invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    if out_sum is not None:
+        bt.out_sum, bt.out_sum_replicas = out_sum.data_ptr(), out_sum.shape[0]
     check(lib().vince_bn_train_apply(dtype_code(y), _ptr(y), ctypes.byref(bt), _ptr(identity), _ptr(id_scale), _ptr(id_shift),
                                      _ptr(out), _ptr(mask), y.numel() // C, C, int(relu), stream_ptr()))
     return out, mask, scale, shift, mean, invstd
+
+
+def bn_gram_finalize(gram, colsum, count, w, gamma, beta, running_mean=None, running_var=None, nbt=None, momentum=0.1, eps=1e-5):
+    """BatchNorm constants of the 1x1 conv y = w a from the Gram matrix of a (vince_bn_gram_finalize).
+    gram float[K][K], colsum double[R][K], w [Co][K] in the compute dtype.  Returns consts [4][Co]: scale, shift, mean, invstd."""
+    require_gpu(gram, colsum, w, gamma, beta, running_mean, running_var, nbt)
+    Co, K = w.shape[0], w.shape[-1]
+    consts = torch.empty(4, Co, device=w.device, dtype=torch.float32)
+    check(lib().vince_bn_gram_finalize(dtype_code(w), _ptr(gram), _ptr(colsum), colsum.shape[0], count, _ptr(w), K, Co,
+                                       _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(nbt), momentum, eps,
+                                       _ptr(consts[0]), _ptr(consts[1]), _ptr(consts[2]), _ptr(consts[3]), stream_ptr()))
+    return consts
 
 
 def bn_bwd_reduce(dz, y, mean, invstd, mask_src=None, mask_bits=None, mask_scale=None, mask_shift=None, replicas=0):
