@@ -146,6 +146,16 @@ typedef struct vince_conv_epi {
 int vince_conv_igemm(const vince_conv_desc* d, int dtype, const void* in, const void* w, void* out,
                      const vince_conv_epi* epi, void* stream);
 
+/* The bottleneck's last 1x1 convolution (resnet.py:123) with its BatchNorm, the residual join and the ReLU (resnet.py:125-133) in
+ * registers, for BatchNorm constants known beforehand (vince_bn_gram_finalize):
+ *   out[p][co] = [relu]( out_scale[co] * sum_k w[co][k] x[p][k] + out_shift[co] + (id_scale ? identity * id_scale + id_shift : identity) )
+ * x [rows][K], w [Co][K], identity / out [rows][Co] (out may alias identity), bf16, K = 64 or 128, Co multiple of 256.
+ * A persistent streaming kernel (csrc/conv_xjoin.hip): weights resident in LDS, input tiles by a loader wavefront, outputs
+ * straight from the accumulators -- the HBM-bound replacement of vince_conv_igemm's join epilogue for layer1 / layer2. */
+int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
+                           const float* out_scale, const float* out_shift, const void* identity, const float* id_scale,
+                           const float* id_shift, void* out, int relu, void* stream);
+
 /* Weight gradient (wgrad) of the same generalised conv, reduction over output pixels:
  *   dw[co, wt(a,b), ci] += sum_{n,ho,wo} dy[n,ho,wo,co] * in[n, ho*sh+dh0+a*dhs, wo*sw+dw0+b*dws, ci]
  * dw is float[Co][WT][Ci_dw] accumulated with fp32 atomics (zero it first); only ci < Ci_dw is written

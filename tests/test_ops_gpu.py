@@ -615,3 +615,38 @@ def test_gram_statistics_join_vs_separate_passes(dtype, N, hw, K, Co, ds):
     ops.conv_igemm(ops.conv_desc(N, hw, hw, K, Co, 1, 1, 0), x4, w3g.view(Co, 1, K), z, bias=consts[1], flags=EPI_ACCUMULATE | EPI_RELU,
                    out_scale=consts[0], id_scale=isc.to(DEV) if ds else None, id_shift=ish.to(DEV) if ds else None)
     assert_close(z.view(rows, Co), want.float(), dtype, f32=5e-5, bf16=3e-2, what="join")
+
+
+@pytest.mark.parametrize("rows,K,Co,ds", [(4 * 14 * 14, 64, 256, False), (1000, 64, 256, True), (3 * 9 * 9, 128, 512, True),
+                                          (128 * 40 + 5, 128, 512, False), (37, 64, 512, False)])
+def test_conv_expand_join_streaming_kernel(rows, K, Co, ds):
+    """vince_conv_expand_join (csrc/conv_xjoin.hip): relu(scale * (x W^T) + shift + identity') against fp64 on the same bf16
+    operands, in place on the identity; ragged row counts, both K, one and two channel groups, identity read through the
+    downsample BatchNorm's affine; and against vince_conv_igemm's join epilogue (bit-equal up to the last bf16 rounding)."""
+    ops = _ops()
+    from vince_amd._lib import EPI_ACCUMULATE, EPI_RELU
+    x = rnd(rows, K, seed=1).clamp_(min=0)
+    w = rnd(Co, K, seed=2) * (2.0 / Co) ** 0.5
+    idn = rnd(rows, Co, seed=3)
+    sc, sh = torch.rand(Co, generator=torch.Generator().manual_seed(4)) + 0.5, rnd(Co, seed=5) * 0.3
+    isc, ish = torch.rand(Co, generator=torch.Generator().manual_seed(6)) + 0.5, rnd(Co, seed=7) * 0.2
+    xq, wq, iq = q(x, torch.bfloat16).double(), q(w, torch.bfloat16).double(), q(idn, torch.bfloat16).double()
+    ident = iq * isc.double() + ish.double() if ds else iq
+    want = torch.relu((xq @ wq.t()) * sc.double() + sh.double() + ident)
+    xg, wg = x.to(DEV).bfloat16(), w.to(DEV).bfloat16().contiguous()
+    z = idn.to(DEV).bfloat16().contiguous()
+    guard = torch.full((4096,), 7.0, device=DEV).bfloat16()          # (allocated right behind z most of the time: tail writes show)
+    ops.conv_expand_join(xg, wg, sc.to(DEV), sh.to(DEV), z, id_scale=isc.to(DEV) if ds else None, id_shift=ish.to(DEV) if ds else None)
+    assert_close(z, want.float(), torch.bfloat16, bf16=1e-2, what="expand join")
+    assert float((guard.float() - 7.0).abs().max()) == 0.0
+    z2 = idn.to(DEV).bfloat16().view(1, rows, 1, Co).contiguous()
+    ops.conv_igemm(ops.conv_desc(1, rows, 1, K, Co, 1, 1, 0), xg.view(1, rows, 1, K), wg.view(Co, 1, K), z2, bias=sh.to(DEV),
+                   flags=EPI_ACCUMULATE | EPI_RELU, out_scale=sc.to(DEV), id_scale=isc.to(DEV) if ds else None,
+                   id_shift=ish.to(DEV) if ds else None)
+    # the streaming kernel applies scale / shift to the fp32 accumulator, the igemm epilogue to its bf16-rounded copy
+    assert_close(z, z2.view(rows, Co).float(), torch.bfloat16, bf16=1.5e-2, what="vs igemm join")
+    # not in place
+    out = torch.empty_like(z)
+    ops.conv_expand_join(xg, wg, sc.to(DEV), sh.to(DEV), idn.to(DEV).bfloat16().contiguous(), out=out,
+                         id_scale=isc.to(DEV) if ds else None, id_shift=ish.to(DEV) if ds else None)
+    assert torch.equal(out, z)

@@ -1,0 +1,36 @@
+"""Times vince_conv_expand_join against vince_conv_igemm's join epilogue on the layer1 / layer2 shapes (B=256, bf16)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from vince_amd import ops
+from vince_amd._lib import EPI_ACCUMULATE, EPI_RELU
+dev = "cuda"
+
+
+def t(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000 / n
+
+
+for name, hw, K in [("l1", 56, 64), ("l2", 28, 128)]:
+    N, Co = 256, 4 * K
+    rows = N * hw * hw
+    x = torch.randn(rows, K, device=dev).clamp_(min=0).bfloat16()
+    w = (torch.randn(Co, K, device=dev) * 0.05).bfloat16()
+    z = torch.randn(rows, Co, device=dev).bfloat16()
+    sc, sh = torch.rand(Co, device=dev) + 0.5, torch.randn(Co, device=dev)
+    a = t(lambda: ops.conv_expand_join(x, w, sc, sh, z))
+    d = ops.conv_desc(N, hw, hw, K, Co, 1, 1, 0)
+    b = t(lambda: ops.conv_igemm(d, x.view(N, hw, hw, K), w.view(Co, 1, K), z.view(N, hw, hw, Co), bias=sh,
+                                 flags=EPI_ACCUMULATE | EPI_RELU, out_scale=sc))
+    nbytes = rows * (K + 2 * Co) * 2
+    print("%s rows=%d K=%d Co=%d: expand_join %.1f us (%.2f TB/s) | igemm join %.1f us (%.2f TB/s)" % (
+        name, rows, K, Co, a, nbytes / a / 1e6, b, nbytes / b / 1e6))

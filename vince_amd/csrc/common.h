@@ -199,6 +199,7 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     else static_assert(N == 0, "add the vmcnt literal");
 }
 

@@ -1,0 +1,281 @@
+// "Expand + join" kernel: the last 1x1 convolution of a bottleneck (resnet.py:123, Co = 4 * Ci) with the block's closing
+// BatchNorm, residual join and ReLU (resnet.py:125-133) in its epilogue, for the case where the BatchNorm constants are known
+// before the convolution runs (vince_bn_gram_finalize):
+//
+//     out[p][co] = relu( scale[co] * sum_k W[co][k] x[p][k] + shift[co] + identity'[p][co] )
+//     identity'  = id_scale ? identity * id_scale[co] + id_shift[co] : identity          (out may alias identity)
+//
+// This is a pure HBM stream -- K = 64 / 128, so 2 * K FLOP per output element against >= 4 bytes moved -- and is built as one:
+//   * persistent workgroups, one per CU, each owning a fixed group of 256 output channels whose weights stay in LDS
+//     (32 KB at K = 64, 64 KB at K = 128) for the lifetime of the launch;
+//   * a dedicated LOADER wavefront streams the 128-pixel x K input tiles HBM -> LDS by LDS-DMA into a ring (its vmcnt holds
+//     nothing but those loads, so counted waits are exact), ahead of the eight CONSUMER wavefronts;
+//   * each consumer owns 64 pixels x 64 channels as 2 x 2 MFMA 32x32x16 tiles; the accumulator layout (lane = pixel, register
+//     quad = 4 consecutive channels, lane halves interleaved) is turned into whole 16-byte channel chunks per lane with
+//     v_permlane32_swap, so identity loads and output stores go straight between registers and HBM -- no LDS transposition, no
+//     barrier in the epilogue, and (the statistics come from the Gram matrix) no reduction;
+//   * the identity chunks of a tile are requested before its MFMA loop and the stores of tile t drain while tile t + 1 computes.
+#include "common.h"
+
+namespace {
+
+constexpr int XJ_PX = 128;          // pixels per tile (2 consumer rows of 64)
+constexpr int XJ_CG = 256;          // channels per workgroup (4 consumer columns of 64)
+constexpr int XJ_CONSUMERS = 8;
+constexpr int XJ_THREADS = (XJ_CONSUMERS + 1) * 64;
+
+struct XjParams {
+    const void* x;
+    const void* w;
+    const void* identity;
+    void* out;
+    const float* out_scale;
+    const float* out_shift;
+    const float* id_scale;
+    const float* id_shift;
+    uint32_t rows, Co, x_bytes, w_bytes;
+    int ptiles, cgroups, relu;
+};
+
+template <int K, int STAGES>
+struct XjSmem {
+    static constexpr int NKT = K / 32;                      // 64-byte K blocks per row
+    static constexpr int WB = NKT * XJ_CG * 64;             // resident weights
+    static constexpr int XB = NKT * XJ_PX * 64;             // one input tile
+    static constexpr int TAB = 4 * XJ_CG * 4;               // scale, shift, id_scale, id_shift of this channel group
+    static constexpr int BYTES = WB + STAGES * XB + TAB;
+};
+
+template <int K, int STAGES, bool ID_AFFINE>
+__global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p) {
+    using S = XjSmem<K, STAGES>;
+    constexpr int NKT = S::NKT;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES];
+    unsigned char* const wsm = smem;
+    unsigned char* const xsm = smem + S::WB;
+    float* const tab = (float*)(smem + S::WB + STAGES * S::XB);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = blockIdx.x % p.cgroups;                  // fixed for the lifetime of the workgroup (grid % cgroups == 0)
+    const int c0 = cg * XJ_CG;
+    const int first = blockIdx.x / p.cgroups, step = gridDim.x / p.cgroups;
+    const int ntiles = first < p.ptiles ? (p.ptiles - first + step - 1) / step : 0;   // pixel tiles first, first + step, ...
+
+    const v4i_t rsrc_x = make_rsrc(p.x, p.x_bytes);
+    const v4i_t rsrc_w = make_rsrc(p.w, p.w_bytes);
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    constexpr uint32_t OOB = 0x80000000u;
+
+    // lane -> (row dr of a 16-row x 64-byte DMA piece, slot); the slot holds logical K chunk slot ^ ((row >> 2) & 3), the
+    // XOR swizzle that keeps the ds_read_b128 fragment reads of 32 consecutive rows off each other's banks
+    const int dr = lane >> 2, dslot = lane & 3;
+    const int dchunk = dslot ^ ((dr >> 2) & 3);
+
+    // (tab: id_scale / id_shift rows only matter to the ID_AFFINE instantiation)
+    // ---- resident weights + constant table (every wavefront helps, once) -------------------------------------------------
+    {
+        constexpr int PIECES = NKT * XJ_CG / 16;            // 1 KB pieces
+        for (int pc = wave; pc < PIECES; pc += XJ_CONSUMERS + 1) {
+            const int kt = pc / (XJ_CG / 16), rb = (pc % (XJ_CG / 16)) * 16;
+            const uint32_t co = (uint32_t)(c0 + rb + dr);
+            const uint32_t off = co < p.Co ? (co * (uint32_t)K + (uint32_t)(kt * 32 + dchunk * 8)) * 2u : OOB;
+            lds_dma16(__builtin_amdgcn_readfirstlane(smem_base + kt * (XJ_CG * 64) + rb * 64), off, rsrc_w);
+        }
+        for (int i = tid; i < XJ_CG; i += XJ_THREADS) {
+            const int c = c0 + i;
+            const bool ok = (uint32_t)c < p.Co;
+            tab[i] = ok ? p.out_scale[c] : 0.f;
+            tab[XJ_CG + i] = ok ? p.out_shift[c] : 0.f;
+            tab[2 * XJ_CG + i] = (ok && p.id_scale) ? p.id_scale[c] : 1.f;
+            tab[3 * XJ_CG + i] = (ok && p.id_scale) ? p.id_shift[c] : 0.f;
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+    }
+
+    constexpr int X_PIECES = NKT * XJ_PX / 16;              // DMA instructions per input tile (16 at K = 64, 32 at K = 128)
+    if (wave == XJ_CONSUMERS) {
+        // =============================== loader ===============================
+        // invariant at barrier B(t): tile t has landed; tiles t+1 .. t+STAGES-2 are in flight; the ring stage of tile t-1 is free
+        // once the barrier releases (every consumer finished tile t-1's MFMA loop before arriving).
+        auto issue_x = [&](int t) {
+            if (t >= ntiles) return;
+            const uint32_t p0 = (uint32_t)(first + t * step) * XJ_PX;
+            const uint32_t sbase = smem_base + S::WB + (uint32_t)(t % STAGES) * S::XB;
+#pragma unroll
+            for (int pc = 0; pc < X_PIECES; ++pc) {
+                const int kt = pc / (XJ_PX / 16), rb = (pc % (XJ_PX / 16)) * 16;
+                const uint32_t m = p0 + rb + dr;
+                const uint32_t off = m < p.rows ? (m * (uint32_t)K + (uint32_t)(kt * 32 + dchunk * 8)) * 2u : OOB;
+                lds_dma16(__builtin_amdgcn_readfirstlane(sbase + kt * (XJ_PX * 64) + rb * 64), off, rsrc_x);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < STAGES - 1; ++t) issue_x(t);
+        for (int t = 0; t < ntiles; ++t) {
+            // with 3 stages tile t+1 (X_PIECES instructions, issued after tile t's) may stay in flight across the barrier
+            if (STAGES == 3 && t + 1 < ntiles) wait_vmcnt<X_PIECES>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                   // B(t)
+            issue_x(t + STAGES - 1);                        // into the stage tile t-1 occupied
+        }
+        return;
+    }
+
+    // =============================== consumers ===============================
+    // Work unit = one 32-pixel column block of the wavefront's 64 x 64 tile (i = 0, 1): 32 accumulator registers and four
+    // 16-byte identity chunks.  The identity chunks of unit u + 1 are requested BEFORE unit u's epilogue issues its stores:
+    // vector memory operations retire in order, so waiting for those loads later never waits for the younger stores, which
+    // drain in the background while the next unit computes.
+    const int wp = wave >> 2, wc = wave & 3;                // 64-pixel half, 64-channel quarter
+    const int sw = ((lane & 31) >> 2) & 3, khalf = lane >> 5;
+    const int row_off = (lane & 31) * 64;
+    const bf16_t* __restrict__ idn = (const bf16_t*)p.identity;
+    bf16_t* __restrict__ out = (bf16_t*)p.out;
+    const unsigned char* const wfrag = wsm + (wc * 64) * 64 + row_off;
+    const uint32_t lane_px = (uint32_t)(wp * 64 + (lane & 31));
+    const size_t ch_off = (size_t)(c0 + wc * 64 + khalf * 8);
+
+    // lane's pixel of unit (t, i) and the element offset of its first chunk; chunks (j, gp) follow at + 32 j + 16 gp
+    auto unit_off = [&](int t, int i, bool& ok) -> size_t {
+        const uint32_t pix = (uint32_t)(first + t * step) * XJ_PX + lane_px + 32u * (uint32_t)i;
+        ok = t < ntiles && pix < p.rows;
+        return (size_t)pix * p.Co + ch_off;
+    };
+    auto load_ids = [&](uint4 (&dst)[2][2], int t, int i) {
+        bool ok;
+        const size_t off = unit_off(t, i, ok);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) dst[j][gp] = ok ? *(const uint4*)(idn + off + j * 32 + gp * 16) : make_uint4(0, 0, 0, 0);
+    };
+    auto run_unit = [&](const uint4 (&ids)[2][2], int t, int i) {
+        const unsigned char* xfrag = xsm + (t % STAGES) * S::XB + (wp * 64 + i * 32) * 64 + row_off;
+        f32x16_t acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int slot = ((s2 * 2 + khalf) ^ sw) * 16;
+                const uint4 xf = *(const uint4*)(xfrag + kt * (XJ_PX * 64) + slot);
+                bf16x8_t bv;
+                __builtin_memcpy(&bv, &xf, 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint4 wf = *(const uint4*)(wfrag + kt * (XJ_CG * 64) + j * 32 * 64 + slot);
+                    bf16x8_t av;
+                    __builtin_memcpy(&av, &wf, 16);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        bool ok;
+        const size_t off = unit_off(t, i, ok);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                // quads g0 = 2 gp (registers 8 gp .. +3) and g1 = 2 gp + 1 (8 gp + 4 .. +7): after the swap the low half-wave
+                // holds chunk g0 whole (its own 4 channels + the high half's 4), the high half-wave chunk g1 = 2 gp + khalf
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][8 * gp + e]),
+                                                                    __float_as_uint(acc[j][8 * gp + 4 + e]), false, false);
+                    v[e] = __uint_as_float(r[0]);
+                    v[4 + e] = __uint_as_float(r[1]);
+                }
+                int tb = wc * 64 + j * 32 + (2 * gp + khalf) * 8;
+                asm volatile("" : "+v"(tb));                // keep the table reads here: hoisted out of the tile loop they would
+                                                            // pin 64-128 registers for the lifetime of the wavefront
+                float idf[8];
+                Chunk<bf16_t>::unpack(ids[j][gp], idf);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 a = *(const float4*)(tab + tb + 4 * h), b = *(const float4*)(tab + XJ_CG + tb + 4 * h);
+                    float4 c = make_float4(1.f, 1.f, 1.f, 1.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (ID_AFFINE) {
+                        c = *(const float4*)(tab + 2 * XJ_CG + tb + 4 * h);
+                        d = *(const float4*)(tab + 3 * XJ_CG + tb + 4 * h);
+                    }
+                    v[4 * h + 0] = v[4 * h + 0] * a.x + b.x + (ID_AFFINE ? idf[4 * h + 0] * c.x + d.x : idf[4 * h + 0]);
+                    v[4 * h + 1] = v[4 * h + 1] * a.y + b.y + (ID_AFFINE ? idf[4 * h + 1] * c.y + d.y : idf[4 * h + 1]);
+                    v[4 * h + 2] = v[4 * h + 2] * a.z + b.z + (ID_AFFINE ? idf[4 * h + 2] * c.z + d.z : idf[4 * h + 2]);
+                    v[4 * h + 3] = v[4 * h + 3] * a.w + b.w + (ID_AFFINE ? idf[4 * h + 3] * c.w + d.w : idf[4 * h + 3]);
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (ok) *(uint4*)(out + off + j * 32 + gp * 16) = Chunk<bf16_t>::pack(v);
+            }
+    };
+
+    // identity chunks one whole tile ahead (two units = 8 chunks per lane in flight beside the tile being computed)
+    uint4 idA[2][2][2], idB[2][2][2];
+    load_ids(idA[0], 0, 0);
+    load_ids(idA[1], 0, 1);
+    for (int t = 0; t < ntiles; t += 2) {
+        load_ids(idB[0], t + 1, 0);
+        load_ids(idB[1], t + 1, 1);
+        __builtin_amdgcn_s_barrier();                       // B(t): the loader has seen tile t land
+        run_unit(idA[0], t, 0);
+        run_unit(idA[1], t, 1);
+        if (t + 1 >= ntiles) break;                         // (uniform)
+        load_ids(idA[0], t + 2, 0);
+        load_ids(idA[1], t + 2, 1);
+        __builtin_amdgcn_s_barrier();                       // B(t + 1)
+        run_unit(idB[0], t + 1, 0);
+        run_unit(idB[1], t + 1, 1);
+    }
+}
+
+}  // namespace
+
+extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
+                                      const float* out_scale, const float* out_shift, const void* identity,
+                                      const float* id_scale, const float* id_shift, void* out, int relu, void* stream) {
+    VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_expand_join: bf16 only (fp32 runs vince_conv_igemm's join epilogue)");
+    VINCE_CHECK_ARG(x && w && out_scale && out_shift && identity && out && rows > 0, VINCE_E_ARG, "vince_conv_expand_join: null pointer");
+    VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_join: K=%d (64 or 128)", K);
+    VINCE_CHECK_ARG(Co > 0 && Co % XJ_CG == 0, VINCE_E_SHAPE, "vince_conv_expand_join: Co=%d must be a multiple of %d", Co, XJ_CG);
+    VINCE_CHECK_ARG(!id_scale == !id_shift, VINCE_E_ARG, "vince_conv_expand_join: id_scale and id_shift come together");
+    VINCE_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)identity | (uintptr_t)out) & 15) == 0, VINCE_E_ALIGN,
+                    "vince_conv_expand_join: pointers must be 16-byte aligned");
+    const unsigned long long xb = (unsigned long long)rows * K * 2, wb = (unsigned long long)Co * K * 2;
+    VINCE_CHECK_ARG(xb < 0x7ff00000ull && rows < (1ll << 31), VINCE_E_UNSUPPORTED, "vince_conv_expand_join: input beyond the 31-bit buffer offsets");
+    XjParams p;
+    p.x = x; p.w = w; p.identity = identity; p.out = out;
+    p.out_scale = out_scale; p.out_shift = out_shift; p.id_scale = id_scale; p.id_shift = id_shift;
+    p.rows = (uint32_t)rows; p.Co = (uint32_t)Co; p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
+    p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
+    p.cgroups = Co / XJ_CG;
+    p.relu = relu;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        VINCE_CHECK_HIP(hipGetDevice(&dev));
+        VINCE_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    static const int wg_per_cu = getenv("VINCE_XJ_WGS") ? atoi(getenv("VINCE_XJ_WGS")) : 1;   // (measurement aid)
+    long grid = (long)n_cu * wg_per_cu;
+    const long items = (long)p.ptiles * p.cgroups;
+    if (grid > items) grid = items;
+    grid = grid / p.cgroups * p.cgroups;                    // every workgroup keeps one channel group
+    if (grid < p.cgroups) grid = p.cgroups;
+#define VINCE_XJ_LAUNCH(KK, SS, AA) \
+    hipLaunchKernelGGL((conv_xjoin_kernel<KK, SS, AA>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p)
+    if (K == 64) { if (id_scale) VINCE_XJ_LAUNCH(64, 3, true); else VINCE_XJ_LAUNCH(64, 3, false); }
+    else { if (id_scale) VINCE_XJ_LAUNCH(128, 2, true); else VINCE_XJ_LAUNCH(128, 2, false); }
+#undef VINCE_XJ_LAUNCH
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}

@@ -786,8 +786,16 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
                 e.id_shift = c.consts(b.bd, 1);
                 out = b.yd;
             }
-            const vince_conv_desc d3 = fwd_desc(t, cv);
-            RC(vince_conv_igemm(&d3, c.dtype, at(workspace, in), at((void*)wcache, cv.wk), at(workspace, out), &e, stream));
+            // bf16 at K = 64 / 128: the persistent streaming kernel (csrc/conv_xjoin.hip); otherwise the implicit-GEMM kernel's join
+            // epilogue (fp32, or VINCE_XJOIN=0 as a cross-check)
+            static const bool xjoin_env = !(getenv("VINCE_XJOIN") && atoi(getenv("VINCE_XJOIN")) == 0);
+            if (xjoin_env && c.dtype == VINCE_BF16 && (cv.Ci == 64 || cv.Ci == 128) && cv.Co % 256 == 0) {
+                RC(vince_conv_expand_join(c.dtype, at(workspace, in), at((void*)wcache, cv.wk), rows, cv.Ci, cv.Co, e.out_scale, e.bias,
+                                          at(workspace, out), e.id_scale, e.id_shift, at(workspace, out), 1, stream));
+            } else {
+                const vince_conv_desc d3 = fwd_desc(t, cv);
+                RC(vince_conv_igemm(&d3, c.dtype, at(workspace, in), at((void*)wcache, cv.wk), at(workspace, out), &e, stream));
+            }
             cur = out;
             continue;
         }
