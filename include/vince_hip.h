@@ -151,10 +151,13 @@ int vince_conv_igemm(const vince_conv_desc* d, int dtype, const void* in, const 
  *   out[p][co] = [relu]( out_scale[co] * sum_k w[co][k] x[p][k] + out_shift[co] + (id_scale ? identity * id_scale + id_shift : identity) )
  * x [rows][K], w [Co][K], identity / out [rows][Co] (out may alias identity), bf16, K = 64 or 128, Co multiple of 256.
  * A persistent streaming kernel (csrc/conv_xjoin.hip): weights resident in LDS, input tiles by a loader wavefront, outputs
- * straight from the accumulators -- the HBM-bound replacement of vince_conv_igemm's join epilogue for layer1 / layer2. */
+ * straight from the accumulators -- the HBM-bound replacement of vince_conv_igemm's join epilogue for layer1 / layer2.
+ * Training forwards also pass y_raw (the convolution's own output rounded to bf16, [rows][Co] -- what BatchNorm backward
+ * reads) and mask_out (one byte per 16-byte chunk of out, bit e = pre-ReLU value e > 0, as vince_bn_apply writes it); both or
+ * neither, and then out must not alias identity. */
 int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                            const float* out_scale, const float* out_shift, const void* identity, const float* id_scale,
-                           const float* id_shift, void* out, int relu, void* stream);
+                           const float* id_shift, void* out, void* y_raw, uint8_t* mask_out, int relu, void* stream);
 
 /* Weight gradient (wgrad) of the same generalised conv, reduction over output pixels:
  *   dw[co, wt(a,b), ci] += sum_{n,ho,wo} dy[n,ho,wo,co] * in[n, ho*sh+dh0+a*dhs, wo*sw+dw0+b*dws, ci]

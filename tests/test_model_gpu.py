@@ -604,6 +604,7 @@ def test_nograd_forward_fuses_bn_into_consumers(arch, embed, dtype, monkeypatch)
     _, model = build(arch, embed, dtype, 13)
     model.train()
     x = vo.structured_frames(6, 96, 96, seed=91).to(DEV) + 0.3 * vo.gaussian_frames(6, 96, 96, 92).to(DEV)
+    monkeypatch.setenv("VINCE_GRAM_JOIN", "0")   # (the Gram-statistics join rounds conv3's output differently; its own tests cover it)
     monkeypatch.setenv("VINCE_XF", "1")
     with torch.no_grad():
         a = model.get_embeddings({"data": x})
@@ -786,6 +787,37 @@ def test_gram_statistics_join_equals_separate_passes_in_the_model(monkeypatch, d
         p = "%s_224_train_" % arch
         assert rel(outs["1"]["embeddings"], g[p + "embeddings"]) < 5e-4
         assert rel(outs["1"]["extracted_features"], g[p + "extracted"]) < 5e-4
+
+
+def test_gram_statistics_join_in_the_training_forward_equals_separate_passes(monkeypatch):
+    """Grad-enabled bf16 forwards run layer1 / layer2's conv3 + bn3 + join through the streaming kernel with the Gram
+    statistics (VINCE_GRAM_TRAIN, default on); backward then reads the y3 / mask / mean / invstd that kernel and the Gram
+    finalize left.  Loss-side outputs and gradients against the separate-pass arrangement."""
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VINCE_GRAM_TRAIN", mode)
+        _, model = build("ResNet50", 128, "bf16", 11)
+        model.train()
+        x = vo.structured_frames(8, 128, 128, seed=77).to(DEV)
+        o = model.get_embeddings({"data": x})
+        w = torch.randn(8, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
+        model.zero_grad()
+        (o["embeddings"] * w).sum().backward()
+        named = dict(model.named_parameters())
+        res[mode] = {"emb": o["embeddings"].detach().float().cpu(),
+                     "grads": {n: named[n].grad.detach().float().cpu().clone() for n in (
+                         "feature_extractor.model.layer4.2.conv3.weight", "feature_extractor.model.layer2.1.conv3.weight",
+                         "feature_extractor.model.layer2.1.bn3.weight", "feature_extractor.model.layer1.0.conv3.weight",
+                         "feature_extractor.model.layer1.0.downsample.0.weight", "feature_extractor.model.layer1.1.bn2.bias",
+                         "feature_extractor.model.conv1.weight")}}
+    assert rel(res["1"]["emb"], res["0"]["emb"]) < 0.2      # (bf16 trunk, 8 frames: element-wise noise of the order of DESIGN section 3)
+    cos = torch.nn.functional.cosine_similarity(res["1"]["emb"], res["0"]["emb"], dim=1)
+    assert float(cos.min()) > 0.99
+    for n, g1 in res["1"]["grads"].items():
+        g0 = res["0"]["grads"][n]
+        c = float(torch.nn.functional.cosine_similarity(g1.flatten().double(), g0.flatten().double(), dim=0))
+        ratio = float(g1.norm() / g0.norm())
+        assert c > 0.97 and 0.9 < ratio < 1.1, (n, c, ratio)
 
 
 def test_two_ranks_on_one_gpu_stay_identical():

@@ -650,3 +650,16 @@ def test_conv_expand_join_streaming_kernel(rows, K, Co, ds):
     ops.conv_expand_join(xg, wg, sc.to(DEV), sh.to(DEV), idn.to(DEV).bfloat16().contiguous(), out=out,
                          id_scale=isc.to(DEV) if ds else None, id_shift=ish.to(DEV) if ds else None)
     assert torch.equal(out, z)
+    # the training forward's extra outputs: the raw convolution output (bf16) and the ReLU mask bytes of `out`
+    yraw = torch.empty_like(z)
+    mask = torch.zeros(rows * Co // 8, device=DEV, dtype=torch.uint8)
+    out2 = torch.empty_like(z)
+    ops.conv_expand_join(xg, wg, sc.to(DEV), sh.to(DEV), idn.to(DEV).bfloat16().contiguous(), out=out2, y_raw=yraw, mask_out=mask,
+                         id_scale=isc.to(DEV) if ds else None, id_shift=ish.to(DEV) if ds else None)
+    assert torch.equal(out2, z)
+    assert_close(yraw, (xq @ wq.t()).float(), torch.bfloat16, bf16=1e-2, what="raw conv output")
+    bits = ((mask.view(rows, Co // 8, 1).int() >> torch.arange(8, device=DEV).view(1, 1, 8)) & 1).view(rows, Co).bool()
+    pre = (xq @ wq.t()) * sc.double() + sh.double() + ident                      # pre-ReLU value, fp64
+    sure = pre.abs() > 2e-2 * pre.abs().max()                                    # away from the rounding band around zero
+    assert torch.equal(bits.cpu()[sure], (pre > 0)[sure])
+    assert torch.equal(bits, out2 > 0) or float((bits != (out2 > 0)).float().mean()) < 1e-3   # mask == (relu output > 0) up to -0 / tiny

@@ -31,6 +31,11 @@ for name, hw, K in [("l1", 56, 64), ("l2", 28, 128)]:
     d = ops.conv_desc(N, hw, hw, K, Co, 1, 1, 0)
     b = t(lambda: ops.conv_igemm(d, x.view(N, hw, hw, K), w.view(Co, 1, K), z.view(N, hw, hw, Co), bias=sh,
                                  flags=EPI_ACCUMULATE | EPI_RELU, out_scale=sc))
+    zin = torch.randn(rows, Co, device=dev).bfloat16()
+    zout, yraw = torch.empty_like(zin), torch.empty_like(zin)
+    mask = torch.empty(rows * Co // 8, device=dev, dtype=torch.uint8)
+    c = t(lambda: ops.conv_expand_join(x, w, sc, sh, zin, out=zout, y_raw=yraw, mask_out=mask))
+    print("   training forward (y_raw + mask too): %.1f us (%.2f TB/s)" % (c, rows * (K + 3 * Co + Co / 16) * 2 / c / 1e6))
     nbytes = rows * (K + 2 * Co) * 2
     print("%s rows=%d K=%d Co=%d: expand_join %.1f us (%.2f TB/s) | igemm join %.1f us (%.2f TB/s)" % (
         name, rows, K, Co, a, nbytes / a / 1e6, b, nbytes / b / 1e6))

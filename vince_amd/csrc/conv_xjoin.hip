@@ -29,6 +29,8 @@ struct XjParams {
     const void* w;
     const void* identity;
     void* out;
+    void* y_raw;          // optional: the convolution's own output, rounded to bf16 (what BatchNorm backward reads)
+    uint8_t* mask_out;    // optional: one byte per 16-byte chunk of out, bit e = pre-ReLU value e > 0 (as vince_bn_apply writes)
     const float* out_scale;
     const float* out_shift;
     const float* id_scale;
@@ -43,10 +45,17 @@ struct XjSmem {
     static constexpr int WB = NKT * XJ_CG * 64;             // resident weights
     static constexpr int XB = NKT * XJ_PX * 64;             // one input tile
     static constexpr int TAB = 4 * XJ_CG * 4;               // scale, shift, id_scale, id_shift of this channel group
-    static constexpr int BYTES = WB + STAGES * XB + TAB;
+    // per-consumer transposition buffer for the stores: 32 pixels x CHW channels.  A 16-byte store per lane with lane = pixel
+    // reaches memory as 32-byte pieces of 32 different rows, and partial-line WRITES are what this chip's L2 charges for
+    // (measured: ~18 us per million 32-byte write requests, reads nearly free); through the buffer 8 (4) consecutive lanes write
+    // one whole 128-byte line (64-byte half line where LDS is short: K = 128 keeps 64 KB of weights and a 64 KB ring).
+    static constexpr int CHW = K == 64 ? 64 : 32;
+    static constexpr int TBUF = 32 * CHW * 2;
+    static constexpr int OFF_T = WB + STAGES * XB + TAB;
+    static constexpr int BYTES = OFF_T + XJ_CONSUMERS * TBUF;
 };
 
-template <int K, int STAGES, bool ID_AFFINE>
+template <int K, int STAGES, bool ID_AFFINE, bool SAVE>
 __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p) {
     using S = XjSmem<K, STAGES>;
     constexpr int NKT = S::NKT;
@@ -133,6 +142,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
     const int row_off = (lane & 31) * 64;
     const bf16_t* __restrict__ idn = (const bf16_t*)p.identity;
     bf16_t* __restrict__ out = (bf16_t*)p.out;
+    bf16_t* __restrict__ yraw = (bf16_t*)p.y_raw;
     const unsigned char* const wfrag = wsm + (wc * 64) * 64 + row_off;
     const uint32_t lane_px = (uint32_t)(wp * 64 + (lane & 31));
     const size_t ch_off = (size_t)(c0 + wc * 64 + khalf * 8);
@@ -150,6 +160,51 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) dst[j][gp] = ok ? *(const uint4*)(idn + off + j * 32 + gp * 16) : make_uint4(0, 0, 0, 0);
+    };
+    unsigned char* const tbuf = smem + S::OFF_T + wave * S::TBUF;
+    constexpr int CHW = S::CHW, CPR = CHW / 8;              // channels / 16-byte chunks per buffer row
+    constexpr int NPASS = 64 / CHW;                         // buffer passes per unit (1: whole 64-channel rows, 2: per MFMA tile j)
+    constexpr int LPR = CPR;                                // lanes that share a pixel row when storing
+    constexpr int NST = 32 / (64 / LPR);                    // store instructions per pass
+    // one pass: chunks pk[jj][gp] (lane = pixel) -> buffer -> (lane group = pixel row) -> global; optional mask bytes
+    auto stage_store = [&](const uint4 (&pk)[2][2], int pass, bf16_t* __restrict__ dst, uint8_t* __restrict__ mdst, uint32_t pix0) {
+        const int row = lane & 31;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int jj = 0; jj < 2 / NPASS; ++jj)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const int j = NPASS == 1 ? jj : pass;
+                const int cpos = (NPASS == 1 ? j * 4 : 0) + 2 * gp + khalf;
+                const int swz = NPASS == 1 ? (row & 7) : ((row >> 1) & 3);
+                *(uint4*)(tbuf + row * (CHW * 2) + ((cpos ^ swz) * 16)) = pk[j][gp];
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int sidx = 0; sidx < NST; ++sidx) {
+            const int prow = lane / LPR + (64 / LPR) * sidx, c = lane % LPR;
+            const int swz = NPASS == 1 ? (prow & 7) : ((prow >> 1) & 3);
+            const uint4 val = *(const uint4*)(tbuf + prow * (CHW * 2) + ((c ^ swz) * 16));
+            const uint32_t pix = pix0 + (uint32_t)prow;
+            if (pix < p.rows) {
+                const size_t off = (size_t)pix * p.Co + (size_t)(c0 + wc * 64 + (NPASS == 1 ? 0 : pass * 32) + c * 8);
+                *(uint4*)(dst + off) = val;
+                if (mdst) {                                 // bit e = stored value e > 0 (== pre-ReLU value > 0)
+                    const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t lo16 = wv[e] & 0xffffu, hi16 = wv[e] >> 16;
+                        bits |= ((lo16 != 0 && !(lo16 & 0x8000u)) ? 1u : 0u) << (2 * e);
+                        bits |= ((hi16 != 0 && !(hi16 & 0x8000u)) ? 1u : 0u) << (2 * e + 1);
+                    }
+                    mdst[off / 8] = (uint8_t)bits;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
     };
     auto run_unit = [&](const uint4 (&ids)[2][2], int t, int i) {
         const unsigned char* xfrag = xsm + (t % STAGES) * S::XB + (wp * 64 + i * 32) * 64 + row_off;
@@ -175,8 +230,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                 }
             }
         }
-        bool ok;
-        const size_t off = unit_off(t, i, ok);
+        uint4 opk[2][2], rpk[2][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -191,6 +245,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                     v[e] = __uint_as_float(r[0]);
                     v[4 + e] = __uint_as_float(r[1]);
                 }
+                if constexpr (SAVE) rpk[j][gp] = Chunk<bf16_t>::pack(v);
                 int tb = wc * 64 + j * 32 + (2 * gp + khalf) * 8;
                 asm volatile("" : "+v"(tb));                // keep the table reads here: hoisted out of the tile loop they would
                                                             // pin 64-128 registers for the lifetime of the wavefront
@@ -213,8 +268,16 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (ok) *(uint4*)(out + off + j * 32 + gp * 16) = Chunk<bf16_t>::pack(v);
+                opk[j][gp] = Chunk<bf16_t>::pack(v);
             }
+        if (t < ntiles) {                                   // (uniform)
+            const uint32_t pix0 = (uint32_t)(first + t * step) * XJ_PX + (uint32_t)(wp * 64 + i * 32);
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                stage_store(opk, pass, out, SAVE ? p.mask_out : nullptr, pix0);
+                if constexpr (SAVE) stage_store(rpk, pass, yraw, nullptr, pix0);
+            }
+        }
     };
 
     // identity chunks one whole tile ahead (two units = 8 chunks per lane in flight beside the tile being computed)
@@ -240,18 +303,22 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
 
 extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                                       const float* out_scale, const float* out_shift, const void* identity,
-                                      const float* id_scale, const float* id_shift, void* out, int relu, void* stream) {
+                                      const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
+                                      int relu, void* stream) {
     VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_expand_join: bf16 only (fp32 runs vince_conv_igemm's join epilogue)");
     VINCE_CHECK_ARG(x && w && out_scale && out_shift && identity && out && rows > 0, VINCE_E_ARG, "vince_conv_expand_join: null pointer");
     VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_join: K=%d (64 or 128)", K);
     VINCE_CHECK_ARG(Co > 0 && Co % XJ_CG == 0, VINCE_E_SHAPE, "vince_conv_expand_join: Co=%d must be a multiple of %d", Co, XJ_CG);
     VINCE_CHECK_ARG(!id_scale == !id_shift, VINCE_E_ARG, "vince_conv_expand_join: id_scale and id_shift come together");
+    VINCE_CHECK_ARG(!y_raw == !mask_out, VINCE_E_ARG, "vince_conv_expand_join: y_raw and mask_out come together (the training forward)");
+    VINCE_CHECK_ARG(!y_raw || (out != identity && (((uintptr_t)y_raw & 15) | ((uintptr_t)mask_out & 7)) == 0), VINCE_E_ARG,
+                    "vince_conv_expand_join: saving needs out != identity, y_raw 16-byte and mask_out 8-byte aligned");
     VINCE_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)identity | (uintptr_t)out) & 15) == 0, VINCE_E_ALIGN,
                     "vince_conv_expand_join: pointers must be 16-byte aligned");
     const unsigned long long xb = (unsigned long long)rows * K * 2, wb = (unsigned long long)Co * K * 2;
     VINCE_CHECK_ARG(xb < 0x7ff00000ull && rows < (1ll << 31), VINCE_E_UNSUPPORTED, "vince_conv_expand_join: input beyond the 31-bit buffer offsets");
     XjParams p;
-    p.x = x; p.w = w; p.identity = identity; p.out = out;
+    p.x = x; p.w = w; p.identity = identity; p.out = out; p.y_raw = y_raw; p.mask_out = mask_out;
     p.out_scale = out_scale; p.out_shift = out_shift; p.id_scale = id_scale; p.id_shift = id_shift;
     p.rows = (uint32_t)rows; p.Co = (uint32_t)Co; p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
     p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
@@ -271,10 +338,15 @@ extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, i
     if (grid > items) grid = items;
     grid = grid / p.cgroups * p.cgroups;                    // every workgroup keeps one channel group
     if (grid < p.cgroups) grid = p.cgroups;
-#define VINCE_XJ_LAUNCH(KK, SS, AA) \
-    hipLaunchKernelGGL((conv_xjoin_kernel<KK, SS, AA>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p)
-    if (K == 64) { if (id_scale) VINCE_XJ_LAUNCH(64, 3, true); else VINCE_XJ_LAUNCH(64, 3, false); }
-    else { if (id_scale) VINCE_XJ_LAUNCH(128, 2, true); else VINCE_XJ_LAUNCH(128, 2, false); }
+#define VINCE_XJ_LAUNCH(KK, SS, AA, SV) \
+    hipLaunchKernelGGL((conv_xjoin_kernel<KK, SS, AA, SV>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p)
+#define VINCE_XJ_PICK(KK, SS)                                                                             \
+    do {                                                                                                  \
+        if (y_raw) { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, true); else VINCE_XJ_LAUNCH(KK, SS, false, true); }   \
+        else { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, false); else VINCE_XJ_LAUNCH(KK, SS, false, false); }       \
+    } while (0)
+    if (K == 64) VINCE_XJ_PICK(64, 3); else VINCE_XJ_PICK(128, 2);
+#undef VINCE_XJ_PICK
 #undef VINCE_XJ_LAUNCH
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;

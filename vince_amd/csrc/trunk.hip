@@ -722,8 +722,15 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // (vince_bn_gram_finalize), so they are known BEFORE conv3 runs and its epilogue applies bn3 + identity + ReLU in place on
     // the identity tensor -- y3 is neither written nor re-read and conv3 carries no statistics epilogue (28 -> 21 tensor
     // passes per block).  Backward needs y3, so grad-enabled forwards keep the separate passes.  VINCE_GRAM_JOIN=0: off.
-    const bool gram_on = !(getenv("VINCE_GRAM_JOIN") && atoi(getenv("VINCE_GRAM_JOIN")) == 0) && train_bn && !save && !fuse_xf &&
-                         !ds_side && !vince_profile_enabled();
+    const bool gram_env = !(getenv("VINCE_GRAM_JOIN") && atoi(getenv("VINCE_GRAM_JOIN")) == 0);
+    const bool gram_nograd = gram_env && train_bn && !save && !fuse_xf && !ds_side;
+    // Grad-enabled forwards take the same route where the streaming kernel applies (bf16, K = 64 / 128): it writes the block
+    // output AND what backward reads -- conv3's raw output and the ReLU mask bytes -- so the join pass, its re-read of y3 and
+    // conv3's statistics epilogue go (17 -> 13 tensor passes for conv3 + join).  VINCE_GRAM_TRAIN=0: separate passes.
+    static const bool xjoin_env = !(getenv("VINCE_XJOIN") && atoi(getenv("VINCE_XJOIN")) == 0);
+    const bool gram_train = gram_env && xjoin_env && !(getenv("VINCE_GRAM_TRAIN") && atoi(getenv("VINCE_GRAM_TRAIN")) == 0) &&
+                            train_bn && save && !ds_side && c.dtype == VINCE_BF16;
+    const bool gram_on = gram_nograd || gram_train;
     if (gram_on && t->gram_bytes)
         RC(vince_zero_async(at(workspace, t->off_gram), t->gram_bytes, stream));
     size_t cur = t->off_p0;   // where the running block input lives (gram blocks update it in place, so b.x_in may be stale)
@@ -731,7 +738,9 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
         const Blk& b = t->blocks[bi];
         const size_t x_in = cur;
         size_t in = x_in;
-        const bool gram_blk = gram_on && b.gram != NONE && bi + 1 < t->blocks.size();
+        const bool xj_ok = xjoin_env && c.dtype == VINCE_BF16 && b.nconv == 3 && (b.c[2].Ci == 64 || b.c[2].Ci == 128) &&
+                           b.c[2].Co % 256 == 0;
+        const bool gram_blk = b.gram != NONE && ((gram_nograd && bi + 1 < t->blocks.size()) || (gram_train && xj_ok));
         if (b.has_ds && ds_side) {
             Ctx cd = c;
             cd.stream = (void*)t->ds_stream;
@@ -779,19 +788,20 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             e.flags = VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU;
             e.out_scale = c.consts(bn, 0);
             e.bias = c.consts(bn, 1);
-            size_t out = x_in;                 // identity blocks: the join lands on the block input, in place
+            size_t idn = x_in, out = x_in;     // no-grad, identity blocks: the join lands on the block input, in place
             if (b.has_ds) {                    // stage entry: on the downsample conv's raw output, read through its BatchNorm affine
                 RC(conv_bn_fwd(c, b.cd, b.bd, x_in, b.yd, bn_running, bn_nbt, train_bn, true));
                 e.id_scale = c.consts(b.bd, 0);
                 e.id_shift = c.consts(b.bd, 1);
-                out = b.yd;
+                idn = out = b.yd;
             }
+            if (save) out = b.z;               // backward reads the identity tensors again: nothing in place
             // bf16 at K = 64 / 128: the persistent streaming kernel (csrc/conv_xjoin.hip); otherwise the implicit-GEMM kernel's join
-            // epilogue (fp32, or VINCE_XJOIN=0 as a cross-check)
-            static const bool xjoin_env = !(getenv("VINCE_XJOIN") && atoi(getenv("VINCE_XJOIN")) == 0);
-            if (xjoin_env && c.dtype == VINCE_BF16 && (cv.Ci == 64 || cv.Ci == 128) && cv.Co % 256 == 0) {
+            // epilogue (fp32, or VINCE_XJOIN=0 as a cross-check; no-grad forwards only)
+            if (xj_ok) {
                 RC(vince_conv_expand_join(c.dtype, at(workspace, in), at((void*)wcache, cv.wk), rows, cv.Ci, cv.Co, e.out_scale, e.bias,
-                                          at(workspace, out), e.id_scale, e.id_shift, at(workspace, out), 1, stream));
+                                          at(workspace, idn), e.id_scale, e.id_shift, at(workspace, out),
+                                          save ? at(workspace, b.y[L]) : nullptr, save ? zmask : nullptr, 1, stream));
             } else {
                 const vince_conv_desc d3 = fwd_desc(t, cv);
                 RC(vince_conv_igemm(&d3, c.dtype, at(workspace, in), at((void*)wcache, cv.wk), at(workspace, out), &e, stream));

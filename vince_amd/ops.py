@@ -137,14 +137,17 @@ def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, b
     return out
 
 
-def conv_expand_join(x, w, out_scale, out_shift, identity, out=None, id_scale=None, id_shift=None, relu=True):
+def conv_expand_join(x, w, out_scale, out_shift, identity, out=None, id_scale=None, id_shift=None, relu=True, y_raw=None,
+                     mask_out=None):
     """relu(out_scale * (x @ w.T) + out_shift + identity') in one streaming launch (vince_conv_expand_join); x [rows, K],
-    w [Co, K], identity [rows, Co]; out defaults to in place on identity."""
-    require_gpu(x, w, out_scale, out_shift, identity, out, id_scale, id_shift)
+    w [Co, K], identity [rows, Co]; out defaults to in place on identity.  y_raw / mask_out: the training forward's extra
+    outputs (the raw convolution output and the ReLU mask bytes)."""
+    require_gpu(x, w, out_scale, out_shift, identity, out, id_scale, id_shift, y_raw, mask_out)
     out = identity if out is None else out
     rows, K = x.numel() // x.shape[-1], x.shape[-1]
     check(lib().vince_conv_expand_join(dtype_code(x), _ptr(x), _ptr(w), rows, K, w.shape[0], _ptr(out_scale), _ptr(out_shift),
-                                       _ptr(identity), _ptr(id_scale), _ptr(id_shift), _ptr(out), int(relu), stream_ptr()))
+                                       _ptr(identity), _ptr(id_scale), _ptr(id_shift), _ptr(out), _ptr(y_raw), _ptr(mask_out),
+                                       int(relu), stream_ptr()))
     return out
 
 
