@@ -293,12 +293,16 @@ def test_full_size_backward_serialised_vs_overlapped_streams(tmp_path, dtype):
     run is held tightly and the bf16 run to bf16 noise."""
     sampled = ["feature_extractor.model.layer1.0.downsample.0.weight", "feature_extractor.model.layer2.0.downsample.0.weight",
                "feature_extractor.model.layer3.2.conv2.weight", "feature_extractor.model.conv1.weight"]
-    a = _dump(tmp_path, "ser", dtype, {"VINCE_WGRAD_STREAM": "0", "VINCE_DS_STREAM": "0", "VINCE_OVERLAP_KEY": "0"}, sampled)
-    b = _dump(tmp_path, "ovl", dtype, {}, sampled)
+    # bf16: the key encoder's Gram-statistics join sums with fp32 atomics -- 1e-7 on bn3's constants from run to run, which bf16
+    # rounding and this ill-conditioned start amplify to percents in early-layer gradients; off here so that what is left is
+    # the stream arrangement alone (the fp32 run keeps it on)
+    common = {"VINCE_GRAM_JOIN": "0"} if dtype == "bf16" else {}
+    a = _dump(tmp_path, "ser", dtype, dict(common, VINCE_WGRAD_STREAM="0", VINCE_DS_STREAM="0", VINCE_OVERLAP_KEY="0"), sampled)
+    b = _dump(tmp_path, "ovl", dtype, common, sampled)
     # (fp32 atomics of the weight-gradient kernel also feed the Gram statistics: run-to-run 1e-7 on bn3's constants, which a
     # bf16 trunk turns into rounding flips)
-    assert float(a["loss"]) == pytest.approx(float(b["loss"]), rel=1e-6 if dtype == "fp32" else 2e-5)
-    np.testing.assert_allclose(a["embeddings"], b["embeddings"], rtol=0, atol=1e-6 if dtype == "fp32" else 2e-2)
+    assert float(a["loss"]) == pytest.approx(float(b["loss"]), rel=1e-6)
+    np.testing.assert_allclose(a["embeddings"], b["embeddings"], rtol=0, atol=1e-6)
     assert list(a["grad_names"]) == list(b["grad_names"])
     worst = float(np.abs(a["grad_checksums"][:, 2] / b["grad_checksums"][:, 2] - 1).max())
     print("serialised vs overlapped (%s): worst sum|g| ratio error %.2e" % (dtype, worst))
