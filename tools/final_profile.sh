@@ -2,8 +2,12 @@
 # GPU box: the round's evidence set.  bench.py full line, rocprofv3 kernel stats of the same command, HBM traffic PMC passes.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+VINCE_PROFILE_DUMP=$O/layers.csv timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 20 python tools/bench_brief.py $O/bench.json bench
+# per-layer roofline table of every conv launch of the instrumented steps (bench.py --profile-steps, default 3)
+timeout 60 python tools/layer_roofline.py $O/layers.csv 3 > $O/layer_roofline.txt 2>&1
+# the no-grad forward alone (the forward + InfoNCE leg's trunk)
+bash tools/fwd_kstats.sh VINCE_GRAM_JOIN=1 VINCE_GRAM_JOIN=0 > $O/fwd_ms.txt 2>&1; cp gpurun_out/r2/fwd_kstats_1.txt $O/fwd_kernel_stats.txt; cp gpurun_out/r2/fwd_kstats_2.txt $O/fwd_kernel_stats_separate_passes.txt
 timeout 600 rocprofv3 --kernel-trace -d $O/kt -o kt -- python bench.py --no-extras > $O/kt.log 2>&1
 DB=$(find $O/kt -name '*.db' | head -1); timeout 60 python tools/rocpd_stats.py $DB 45 > $O/kernel_stats.txt 2>&1; rm -rf $O/kt
 # the same with every stream serialised (one kernel at a time, like the instrumented steps behind bench.py's `roofline`): the

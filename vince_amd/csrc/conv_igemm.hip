@@ -711,7 +711,14 @@ int launch(ConvParams& p, hipStream_t stream) {
                     hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, 0, true>), dim3(p.ptiles * p.ctiles), dim3(256),
                                        0, stream, p);
             } else {
-                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                // reductions at least VINCE_S3_MIN_K long take a 3-stage ring (two K tiles in flight, 3 workgroups per CU) instead
+                // of 2 stages / 4 workgroups
+                // default 2048: layer4's 3x3 (K = 4608) 92.6 -> 85 us, 2048 -> 512 50 -> 44 us; shorter reductions lose
+                static const int s3_min_k = getenv("VINCE_S3_MIN_K") ? atoi(getenv("VINCE_S3_MIN_K")) : 2048;
+                if (s3_min_k > 0 && k_elems >= s3_min_k)
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                else
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
             }
         }
         VINCE_CHECK_LAUNCH();
