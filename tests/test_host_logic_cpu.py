@@ -156,3 +156,46 @@ def test_loader_output_to_batch_dict_layouts():
     assert torch.equal(s["imagenet_labels"], labels.repeat_interleave(F))
     one = VinceSolver.process_imagenet_data(([views[0], views[1]], labels), 1)
     assert one["data"] is views[0] and one["queue_data"] is views[1] and one["batch_size"] == B
+
+
+def test_gradient_buckets_cover_the_flat_buffer_for_resnet50():
+    """the four all-reduce buckets (layer4 + heads first, then layer3, layer2, stem + layer1) tile
+    [0, n_train) of the flat gradient buffer exactly -- no gap, no overlap -- and come in the order backward finishes them."""
+    from vince_amd import dp
+    from vince_amd.config import make_args
+    from vince_amd.models.vince_model import VinceModel
+    from vince_amd.solvers.vince_solver import ARCH_LAYERS
+    for arch, embed in (("ResNet50", 128), ("ResNet18", 64)):
+        model = VinceModel(make_args(backbone=arch, vince_embedding_size=embed))
+        plan = dp.bucket_plan(model, ARCH_LAYERS[arch])
+        spans = sorted((a, b) for _, a, b in plan)
+        assert spans[0][0] == 0 and spans[-1][1] == model._n_train
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+        assert [blk for blk, _, _ in plan][-1] is None and plan[0][2] == model._n_train      # heads ride with layer4, stem last
+        blocks = [blk for blk, _, _ in plan[:-1]]
+        assert blocks == sorted(blocks, reverse=True)                                          # deepest stage first
+        if arch == "ResNet50":
+            sizes_mb = [(b - a) * 4 / 1e6 for _, a, b in plan]
+            # the RCCL message sizes DESIGN.md section 8 quotes (fp32 payload)
+            assert abs(sum(sizes_mb) - model._n_train * 4 / 1e6) < 1e-6 and 100 < sum(sizes_mb) < 125
+
+
+def test_bench_synthetic_batches_are_seeded_per_rank():
+    """rank r of `world` draws batch i from Generator(1000 + i * world + r)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vince_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    world = 4
+    for rank in (0, 3):
+        pool = bench.PooledFrames(2, 8, 8, 1, "cpu", pool=3, rank=rank, world=world)
+        for i, item in enumerate(pool.items):
+            g = torch.Generator().manual_seed(1000 + i * world + rank)
+            want = torch.randn(2, 3, 8, 8, generator=g)
+            assert torch.equal(item["data"], want)
+    o = type("O", (), dict(backbone="ResNet50", size=224, batch=256, queue=65536, embed=128, temperature=0.2, dtype="bf16", mode="moco"))
+    assert bench.workload_label(o, 1).startswith("BASELINE config 3:") and bench.workload_label(o, 8).startswith("BASELINE config 4")
+    o.backbone, o.queue, o.embed, o.temperature, o.dtype = "ResNet18", 4096, 64, 0.07, "fp32"
+    assert bench.workload_label(o, 1).startswith("BASELINE config 2:")
+    o.batch = 64
+    assert bench.workload_label(o, 1).startswith("not a BASELINE configuration")

@@ -830,6 +830,33 @@ def test_gram_statistics_join_in_the_training_forward_equals_separate_passes(mon
             assert c_new > c_old - 0.05, (n, c_new, c_old)
 
 
+def test_bench_multi_rank_launch_contract_on_one_gpu():
+    """The driver's N > 1 launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) with four
+    ranks sharing this GPU through gloo (VINCE_BENCH_ONE_GPU=1): rendezvous from the environment, bucketed gradient
+    all-reduce, key all-gather, max-over-ranks timing -- and exactly ONE JSON line, printed by rank 0, for the whole job."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VINCE_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
+           "--backbone", "ResNet18", "--batch", "16", "--size", "64", "--queue", "512", "--embed", "64", "--no-extras"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp4" and d["config"]["frames_per_step"] == 128
+    assert d["config"]["workload"].startswith("not a BASELINE configuration")
+    assert np.isfinite(d["config"]["final_loss"])
+
+
 def test_two_ranks_on_one_gpu_stay_identical():
     """The multi-rank path on GPU hardware: two data-parallel ranks of the full solver share this one GPU through the
     gloo backend (NCCL refuses two ranks per device) -- parameter / queue broadcast, bucketed gradient all-reduce behind

@@ -432,6 +432,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     constexpr int XROWS = PTL / RPP, WROWS = CT / RPP;
     constexpr int PER_STAGE = XROWS + WROWS;       // DMA instructions per thread per stage
     constexpr int SWSH = KC == 8 ? 1 : 2, SWMASK = KC - 1;   // slot swizzle = (row >> SWSH) & SWMASK
+    constexpr bool ILV = CT == 128 && STAGES == 3 && !XF;    // DMA issue interleaved with the MFMAs (see issue_piece)
     __shared__ __attribute__((aligned(16))) unsigned char smem[XF ? S::BYTES_XF : S::BYTES0];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -556,12 +557,23 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
             else if (buf == 1) vmask[1] = m;
             else vmask[STAGES - 1] = m;
         }
+        if constexpr (!ILV) {
+            const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
+            const uint32_t ws = xs + S::XB;
+#pragma unroll
+            for (int e = 0; e < XROWS; ++e) lds_dma16(xs + e * 4096, offx[e], rsrc_x);
+#pragma unroll
+            for (int e = 0; e < WROWS; ++e) lds_dma16(ws + e * 4096, offw[e], rsrc_w);
+        }
+    };
+    // ILV (the 3-stage, 128-channel configurations: long reductions): the PER_STAGE DMA instructions of the tile being prefetched
+    // are issued one at a time BETWEEN the MFMAs of the current tile instead of in front of them -- a piece costs ~100-185 issue
+    // cycles (cdna guide) that then hide under the matrix pipe.  Measured: 3x3 layers of layer2/3/4 -3..8 %; the 2-stage
+    // short-reduction configurations lose 2-5 % and keep the up-front issue.
+    auto issue_piece = [&](int piece, int buf) {
         const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
-        const uint32_t ws = xs + S::XB;
-#pragma unroll
-        for (int e = 0; e < XROWS; ++e) lds_dma16(xs + e * 4096, offx[e], rsrc_x);
-#pragma unroll
-        for (int e = 0; e < WROWS; ++e) lds_dma16(ws + e * 4096, offw[e], rsrc_w);
+        if (piece < XROWS) lds_dma16(xs + piece * 4096, offx[piece < XROWS ? piece : 0], rsrc_x);
+        else lds_dma16(xs + S::XB + (piece - XROWS) * 4096, offw[piece >= XROWS ? piece - XROWS : 0], rsrc_w);
     };
 
     f32x16_t acc[CJ][PI];
@@ -577,7 +589,13 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     const int kt1 = p.kt_per_split > 0 ? min(p.nkt, kt0 + p.kt_per_split) : p.nkt;
     // prologue: STAGES-1 tiles in flight (tiles past the end are issued as all-zero fills so the counts stay uniform)
 #pragma unroll
-    for (int st = 0; st < STAGES - 1; ++st) issue_tile(kt0 + st, st);
+    for (int st = 0; st < STAGES - 1; ++st) {
+        issue_tile(kt0 + st, st);
+        if constexpr (ILV) {
+#pragma unroll
+            for (int pc = 0; pc < PER_STAGE; ++pc) issue_piece(pc, st);
+        }
+    }
     wait_vmcnt<(STAGES - 2) * PER_STAGE>();
     if constexpr (XF) {
         __syncthreads();                 // the scale / shift table is complete
@@ -605,11 +623,36 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
 #pragma unroll
                 for (int i = 0; i < PI; ++i) asm volatile("" ::"v"(xf[i].x), "v"(xf[i].w));
             } else {
+                if constexpr (ILV) {
+                    constexpr int NM = (KC / 2) * CJ * PI;                   // MFMA groups per K tile
+                    constexpr int EVERY = NM / PER_STAGE > 0 ? NM / PER_STAGE : 1;
 #pragma unroll
-                for (int j = 0; j < CJ; ++j)
+                    for (int j = 0; j < CJ; ++j)
 #pragma unroll
-                    for (int i = 0; i < PI; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+                        for (int i = 0; i < PI; ++i) {
+                            Mma<T>::run(wf[j], xf[i], acc[j][i]);
+                            const int m = (s * CJ + j) * PI + i;
+                            if (!(p.ablate & 1) && m % EVERY == 0 && m / EVERY < PER_STAGE) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_piece(m / EVERY, nbuf);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                        for (int i = 0; i < PI; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
+                }
             }
+        }
+        if constexpr (ILV) {   // pieces the MFMA count of a tile could not carry
+            constexpr int NM = (KC / 2) * CJ * PI;
+            constexpr int EVERY = NM / PER_STAGE > 0 ? NM / PER_STAGE : 1;
+            constexpr int DONE = (NM + EVERY - 1) / EVERY < PER_STAGE ? (NM + EVERY - 1) / EVERY : PER_STAGE;
+#pragma unroll
+            for (int pc = DONE; pc < PER_STAGE; ++pc)
+                if (!(p.ablate & 1)) issue_piece(pc, nbuf);
         }
         // tile kt+1 must have landed (this wave's share; the barrier extends it to all waves); the STAGES-2 younger
         // tiles stay in flight across the barrier
