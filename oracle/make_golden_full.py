@@ -4,6 +4,8 @@
       BatchNorm statistics (what nn.DataParallel gives, models/vince_model.py:35), keys concatenated in rank order, the
       reference's StorageQueue after the replicated enqueue, per-rank losses against the shared queue and the rank-mean
       gradient.
+  G2u the loss with UNEQUAL positives per row (the reference's USE_FLOAT branch, utils/loss_util.py:25-36,46-48) and its
+      process-wide cached decision.
   G9  BASELINE config 3 at its REAL size: ResNet-50, B=256, 224x224, K=65536, D=128, T=0.2 (vince/train_moco_v2.sh:17-27),
       one full training iteration of the reference on CPU (forward, loss, metrics, backward): loss, metrics, embeddings,
       gradient checksums and sampled gradient rows, BatchNorm running statistics.
@@ -154,11 +156,37 @@ def g9_full(ref):
     print("g9 loss %.6f  metrics %s" % (float(loss), {k: float(v) for k, v in met.items()}))
 
 
+g2u_inputs = vo.g2u_inputs
+
+
+def g2u_loss(ref):
+    """The reference's USE_FLOAT branch (utils/loss_util.py:25-36,46-48): rows with 1, 2, 3 positives; then -- the decision being
+    cached process-wide (App. D item 2) -- an EQUAL-count mask through the same float path."""
+    out = {}
+    sims, mask, eq = g2u_inputs()
+    ref.loss_util.USE_FLOAT = None
+    for tag, m in (("uneq", mask), ("eq_after", eq)):
+        s = sims.clone().requires_grad_(True)
+        r = ref.loss_util.similarity_cross_entropy(s, 0.2, 6, 1, m)
+        r["dist"].backward()
+        out[tag + "_dists"] = np_(r["dists"])
+        out[tag + "_dist"] = np_(r["dist"])
+        out[tag + "_softmax_weights"] = np_(r["softmax_weights"])
+        out[tag + "_softmax_weight"] = np_(r["softmax_weight"])
+        out[tag + "_dsims"] = np_(s.grad)
+    assert bool(ref.loss_util.USE_FLOAT)
+    ref.loss_util.USE_FLOAT = None
+    np.savez_compressed(os.path.join(OUT, "g2u_loss_unequal.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     which = set(sys.argv[1:]) or {"g7", "g9"}
     ref = rh.load_reference()
+    if "g2u" in which or not sys.argv[1:]:
+        g2u_loss(ref)
+        print("g2u done")
     if "g7" in which:
         g7_dp(ref)
         print("g7 done")

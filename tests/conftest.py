@@ -26,3 +26,14 @@ def _hip_library_present():
     from vince_amd import _lib, build
     if not os.path.exists(_lib.LIB_PATH) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
         build.build(verbose=False)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_use_float_decision():
+    """loss_util caches the equal / unequal-positives decision process-wide like the reference (loss_util.py:4,28-29); every test
+    starts undecided."""
+    import sys
+    mod = sys.modules.get("vince_amd.utils.loss_util")
+    if mod is not None:
+        mod.USE_FLOAT = None
+    yield

@@ -1,5 +1,7 @@
 """GPU parity of every HIP kernel behind the C ABI against torch-CPU restatements of the reference ops
 (the oracle for float ops is torch CPU fp32).  Run with -m gpu on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -663,3 +665,30 @@ def test_conv_expand_join_streaming_kernel(rows, K, Co, ds):
     sure = pre.abs() > 2e-2 * pre.abs().max()                                    # away from the rounding band around zero
     assert torch.equal(bits.cpu()[sure], (pre > 0)[sure])
     assert torch.equal(bits, out2 > 0) or float((bits != (out2 > 0)).float().mean()) < 1e-3   # mask == (relu output > 0) up to -0 / tiny
+
+
+def test_similarity_cross_entropy_unequal_positives_use_float():
+    """utils/loss_util.py:25-36,46-48 on the HIP row kernel, against the reference's own numbers (tests/golden/g2u_loss_unequal.npz)
+    incl. the process-wide cached decision (App. D item 2) and the failure the reference has when an equal-count mask came
+    first."""
+    from vince_amd.utils import loss_util
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g2u_loss_unequal.npz"))
+    sims, mask, eq = vo.g2u_inputs()
+    loss_util.USE_FLOAT = None
+    for tag, m in (("uneq", mask), ("eq_after", eq)):
+        s = sims.clone().to(DEV).requires_grad_(True)
+        r = loss_util.similarity_cross_entropy(s, 0.2, 6, 1, m.to(DEV))
+        assert loss_util.USE_FLOAT is True
+        r["dist"].backward()
+        np.testing.assert_allclose(r["dists"].detach().cpu().numpy(), g[tag + "_dists"], rtol=2e-5, atol=1e-5)
+        np.testing.assert_allclose(float(r["dist"]), float(g[tag + "_dist"]), rtol=1e-5)
+        np.testing.assert_allclose(r["softmax_weights"].detach().cpu().numpy(), g[tag + "_softmax_weights"], rtol=2e-5, atol=1e-8)
+        np.testing.assert_allclose(float(r["softmax_weight"]), float(g[tag + "_softmax_weight"]), rtol=1e-5)
+        np.testing.assert_allclose(s.grad.cpu().numpy(), g[tag + "_dsims"], rtol=1e-4, atol=1e-7)
+    loss_util.USE_FLOAT = None
+    r = loss_util.similarity_cross_entropy(sims.to(DEV), 0.2, 6, 1, eq.to(DEV))          # equal counts first: compacted path, cached
+    assert loss_util.USE_FLOAT is False and r["dists"].shape == (6, 1, 2)
+    np.testing.assert_allclose(float(r["dist"]), float(g["eq_after_dist"]), rtol=1e-5)
+    with pytest.raises(RuntimeError):
+        loss_util.similarity_cross_entropy(sims.to(DEV), 0.2, 6, 1, mask.to(DEV))
+    loss_util.USE_FLOAT = None

@@ -169,3 +169,26 @@ def test_g6_jigsaw(hw):
         o = vo.get_embeddings(sd, x, "ResNet18", True, jigsaw=True, jigsaw_orders=torch.from_numpy(g[p + "orders"]))
     np.testing.assert_allclose(o["embeddings"].numpy(), g[p + "embeddings"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(o["extracted_features"].numpy(), g[p + "extracted"], rtol=1e-4, atol=1e-5)
+
+
+def test_g2u_unequal_positives_use_float_branch():
+    """The reference's USE_FLOAT branch (utils/loss_util.py:25-36,46-48; VERDICT r1 missing #4): rows with 1, 2 and 3 positives --
+    full-width outputs, -2**20 fill, means over the mask entries -- and an equal-count mask sent down the same path afterwards
+    (the reference caches the decision process-wide, App. D item 2).  Oracle vs the imported reference's numbers."""
+    g = np.load(os.path.join(GOLDEN, "g2u_loss_unequal.npz"))
+    sims, mask, eq = vo.g2u_inputs()
+    for tag, m in (("uneq", mask), ("eq_after", eq)):
+        s = sims.clone().requires_grad_(True)
+        r = vo.similarity_cross_entropy(s, 0.2, m, use_float=True)
+        r["dist"].backward()
+        np.testing.assert_allclose(r["dists"].detach().numpy(), g[tag + "_dists"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(float(r["dist"]), float(g[tag + "_dist"]), rtol=1e-6)
+        np.testing.assert_allclose(r["softmax_weights"].numpy(), g[tag + "_softmax_weights"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(float(r["softmax_weight"]), float(g[tag + "_softmax_weight"]), rtol=1e-6)
+        np.testing.assert_allclose(s.grad.numpy(), g[tag + "_dsims"], rtol=1e-5, atol=1e-8)
+    # the automatic decision: unequal counts -> float path; equal counts -> compacted path with the same mean
+    auto = vo.similarity_cross_entropy(sims, 0.2, mask)
+    assert auto["dists"].shape == (6, 1, 20)
+    comp = vo.similarity_cross_entropy(sims, 0.2, eq)
+    assert comp["dists"].shape == (6, 1, 2)
+    np.testing.assert_allclose(float(comp["dist"]), float(g["eq_after_dist"]), rtol=1e-6)
