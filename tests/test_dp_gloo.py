@@ -144,6 +144,28 @@ def test_bucketed_gradient_allreduce_sums_every_element_once():
     assert torch.equal(out[0], want) and torch.equal(out[1], want)
 
 
+def _reduce_bf16_case(rank, world):
+    from vince_amd import dp
+    n = 1000
+    g = torch.Generator().manual_seed(5 + rank)
+    grad = torch.randn(n, generator=g)
+    model = types.SimpleNamespace(_flat=torch.zeros(n), _flat_grad=grad.clone(), _n_train=n,
+                                  _stage_offsets={"layer1": 100, "layer2": 300, "layer3": 500, "layer4": 800}, _bucket_events=None)
+    red = dp.GradientReducer(model, (2, 2, 2, 2), payload="bf16")
+    red.reduce_after_backward()
+    return grad, model._flat_grad.clone()
+
+
+def test_bucketed_gradient_allreduce_bf16_payload_opt_in():
+    """`dp_grad_payload="bf16"`: buckets travel as bfloat16 and land back in the fp32 buffer; every element
+    summed once, to bf16 accuracy, identically on both ranks."""
+    out = run2(_reduce_bf16_case)
+    want = out[0][0] + out[1][0]
+    assert torch.equal(out[0][1], out[1][1])
+    assert float((out[0][1] - want).abs().max()) <= 2e-2 * float(want.abs().max())
+    assert float((out[0][1] - want).abs().max()) > 0          # (it really went through bf16)
+
+
 def _coin_case(rank, world):
     """with one process per GPU every rank must pick the same jigsaw side each step."""
     import random

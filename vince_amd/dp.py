@@ -49,10 +49,16 @@ def bucket_plan(model, arch_layers):
 class GradientReducer:
     """Bucketed all-reduce of VinceModel's flat gradient buffer, overlapped with the rest of backward."""
 
-    def __init__(self, model, arch_layers, comm_stream=None):
+    def __init__(self, model, arch_layers, comm_stream=None, payload=None):
         """comm_stream: the stream the bucket all-reduces are enqueued on (each waits for its bucket's event there).  The
         solver passes its key-encoder stream, which is idle during backward: one stream fewer competing for the runtime's
-        four hardware queues."""
+        four hardware queues.
+        payload: "fp32" (default) or "bf16" (`args.dp_grad_payload` / VINCE_DP_GRAD_BF16=1): the buckets travel as bfloat16 --
+        51 instead of 112 MB per step at ResNet-50 -- and are summed back into the fp32 gradient buffer; an opt-in for links
+        where the all-reduce does not hide under backward (the sum of `world` bf16-rounded gradients, so not the reference's
+        arithmetic: off by default)."""
+        import os
+        self.payload = payload or ("bf16" if os.environ.get("VINCE_DP_GRAD_BF16") == "1" else "fp32")
         self.model = model
         self.plan = bucket_plan(model, arch_layers)
         self.on_gpu = model._flat.is_cuda
@@ -68,9 +74,18 @@ class GradientReducer:
         """Call right after loss.backward(): enqueues the bucket all-reduces (each waits for its own event) and makes
         the compute stream wait for all of them."""
         grad = self.model._flat_grad
+
+        def reduce_bucket(a, b):
+            if self.payload == "bf16":
+                buf = grad[a:b].to(torch.bfloat16)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                grad[a:b].copy_(buf)
+            else:
+                dist.all_reduce(grad[a:b], op=dist.ReduceOp.SUM)
+
         if not self.on_gpu:
             for _, a, b in self.plan:
-                dist.all_reduce(grad[a:b], op=dist.ReduceOp.SUM)
+                reduce_bucket(a, b)
             return
         cur = torch.cuda.current_stream()
         tail_event = torch.cuda.Event()
@@ -78,7 +93,7 @@ class GradientReducer:
         with torch.cuda.stream(self.comm_stream):
             for (blk, a, b), ev in zip(self.plan, self.events):
                 self.comm_stream.wait_event(ev if blk is not None else tail_event)
-                dist.all_reduce(grad[a:b], op=dist.ReduceOp.SUM)
+                reduce_bucket(a, b)
             self.done.record(self.comm_stream)
         cur.wait_event(self.done)
 

@@ -100,7 +100,8 @@ class VinceSolver(BaseSolver):
                     with torch.cuda.device(self.model.device):
                         self._key_stream = torch.cuda.Stream()
                     comm = self._key_stream
-            self.reducer = dp.GradientReducer(self.model, ARCH_LAYERS[self.model.feature_extractor.arch], comm_stream=comm)
+            self.reducer = dp.GradientReducer(self.model, ARCH_LAYERS[self.model.feature_extractor.arch], comm_stream=comm,
+                                              payload=getattr(self.args, "dp_grad_payload", None))
             self.optimizer.grad_scale = 1.0 / w
         self.print_optimizer()
 
