@@ -159,6 +159,13 @@ int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows
                            const float* out_scale, const float* out_shift, const void* identity, const float* id_scale,
                            const float* id_shift, void* out, void* y_raw, uint8_t* mask_out, int relu, void* stream);
 
+/* The same streaming structure for an expand convolution on its own: out[p][co] = sum_k w[co][k] x[p][k] (bf16, K = 64 / 128,
+ * Co multiple of 256, stride 1) with the BatchNorm statistics of the STORED values accumulated into stats
+ * (double[replicas][Co][2], zeroed by the caller; optional) -- what vince_conv_igemm(stats) computes for the same layer, as a
+ * persistent HBM stream whose statistics live in registers for the whole launch. */
+int vince_conv_expand_stats(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co, void* out,
+                            double* stats, int32_t replicas, void* stream);
+
 /* Weight gradient (wgrad) of the same generalised conv, reduction over output pixels:
  *   dw[co, wt(a,b), ci] += sum_{n,ho,wo} dy[n,ho,wo,co] * in[n, ho*sh+dh0+a*dhs, wo*sw+dw0+b*dws, ci]
  * dw is float[Co][WT][Ci_dw] accumulated with fp32 atomics (zero it first); only ci < Ci_dw is written

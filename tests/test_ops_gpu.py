@@ -692,3 +692,24 @@ def test_similarity_cross_entropy_unequal_positives_use_float():
     with pytest.raises(RuntimeError):
         loss_util.similarity_cross_entropy(sims.to(DEV), 0.2, 6, 1, mask.to(DEV))
     loss_util.USE_FLOAT = None
+
+
+@pytest.mark.parametrize("rows,K,Co", [(4 * 14 * 14, 64, 256), (128 * 9 + 77, 64, 512), (3 * 28 * 28, 128, 512), (50, 128, 256)])
+def test_conv_expand_stats_streaming_kernel(rows, K, Co):
+    """vince_conv_expand_stats: the expand convolution on its own through the streaming kernel -- output equal to
+    vince_conv_igemm's, statistics equal to the sums over the stored output (what the BatchNorm finalize consumes)."""
+    ops = _ops()
+    x = rnd(rows, K, seed=11).clamp_(min=0).to(DEV).bfloat16()
+    w = (rnd(Co, K, seed=12) * (2.0 / Co) ** 0.5).to(DEV).bfloat16().contiguous()
+    out = torch.full((rows, Co), 3.0, device=DEV).bfloat16()
+    stats = torch.zeros(4, Co, 2, device=DEV, dtype=torch.float64)
+    ops.conv_expand_stats(x, w, out, stats=stats, replicas=4)
+    ref = torch.empty(1, rows, 1, Co, device=DEV, dtype=torch.bfloat16)
+    ops.conv_igemm(ops.conv_desc(1, rows, 1, K, Co, 1, 1, 0), x.view(1, rows, 1, K), w.view(Co, 1, K), ref)
+    assert_close(out, ref.view(rows, Co).float(), torch.bfloat16, bf16=1e-5, what="expand conv output")
+    o = out.double()
+    st = stats.sum(0)
+    np.testing.assert_allclose(st[:, 0].cpu().numpy(), o.sum(0).cpu().numpy(), rtol=2e-6, atol=1e-3)
+    np.testing.assert_allclose(st[:, 1].cpu().numpy(), (o * o).sum(0).cpu().numpy(), rtol=2e-6, atol=1e-3)
+    want = x.double() @ w.double().t()
+    assert_close(out, want.float(), torch.bfloat16, bf16=1e-2, what="vs fp64")

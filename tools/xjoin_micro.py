@@ -27,8 +27,8 @@ for name, hw, K in [("l1", 56, 64), ("l2", 28, 128)]:
     w = (torch.randn(Co, K, device=dev) * 0.05).bfloat16()
     z = torch.randn(rows, Co, device=dev).bfloat16()
     sc, sh = torch.rand(Co, device=dev) + 0.5, torch.randn(Co, device=dev)
-    a = t(lambda: ops.conv_expand_join(x, w, sc, sh, z))
     d = ops.conv_desc(N, hw, hw, K, Co, 1, 1, 0)
+    a = t(lambda: ops.conv_expand_join(x, w, sc, sh, z))
     b = t(lambda: ops.conv_igemm(d, x.view(N, hw, hw, K), w.view(Co, 1, K), z.view(N, hw, hw, Co), bias=sh,
                                  flags=EPI_ACCUMULATE | EPI_RELU, out_scale=sc))
     zin = torch.randn(rows, Co, device=dev).bfloat16()
@@ -36,6 +36,11 @@ for name, hw, K in [("l1", 56, 64), ("l2", 28, 128)]:
     mask = torch.empty(rows * Co // 8, device=dev, dtype=torch.uint8)
     c = t(lambda: ops.conv_expand_join(x, w, sc, sh, zin, out=zout, y_raw=yraw, mask_out=mask))
     print("   training forward (y_raw + mask too): %.1f us (%.2f TB/s)" % (c, rows * (K + 3 * Co + Co / 16) * 2 / c / 1e6))
+    yo = torch.empty(rows, Co, device=dev, dtype=torch.bfloat16)
+    st = torch.zeros(16, Co, 2, device=dev, dtype=torch.float64)
+    e = t(lambda: ops.conv_expand_stats(x, w, yo, stats=st, replicas=16))
+    f = t(lambda: ops.conv_igemm(d, x.view(N, hw, hw, K), w.view(Co, 1, K), yo.view(N, hw, hw, Co), stats=st, replicas=16))
+    print("   plain expand conv + statistics: streaming %.1f us (%.2f TB/s) | igemm %.1f us" % (e, rows * (K + Co) * 2 / e / 1e6, f))
     nbytes = rows * (K + 2 * Co) * 2
     print("%s rows=%d K=%d Co=%d: expand_join %.1f us (%.2f TB/s) | igemm join %.1f us (%.2f TB/s)" % (
         name, rows, K, Co, a, nbytes / a / 1e6, b, nbytes / b / 1e6))

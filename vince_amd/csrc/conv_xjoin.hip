@@ -15,6 +15,8 @@
 //     v_permlane32_swap, so identity loads and output stores go straight between registers and HBM -- no LDS transposition, no
 //     barrier in the epilogue, and (the statistics come from the Gram matrix) no reduction;
 //   * the identity chunks of a tile are requested before its MFMA loop and the stores of tile t drain while tile t + 1 computes.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -35,8 +37,9 @@ struct XjParams {
     const float* out_shift;
     const float* id_scale;
     const float* id_shift;
+    double* stats;        // PLAIN mode: double[replicas][Co][2] per-channel (sum, sum of squares) of the stored output
     uint32_t rows, Co, x_bytes, w_bytes;
-    int ptiles, cgroups, relu;
+    int ptiles, cgroups, relu, replicas;
 };
 
 template <int K, int STAGES>
@@ -55,7 +58,12 @@ struct XjSmem {
     static constexpr int BYTES = OFF_T + XJ_CONSUMERS * TBUF;
 };
 
-template <int K, int STAGES, bool ID_AFFINE, bool SAVE>
+// PLAIN: the same streaming structure for an expand convolution on its own (resnet.py:123 without the join: grad-enabled
+// forwards, the stride-1 downsample conv of layer1): out = the raw convolution output, no identity, no constants; the BatchNorm
+// statistics of the stored values are kept per lane -- after the transposition a lane owns the same 8 channels for the whole
+// launch -- and leave as one fp64 atomic per channel per wavefront at the end (the implicit-GEMM epilogue pays a shuffle + LDS
+// reduction and 2 x 128 atomics per 128-pixel tile: 24 % of the layer1 expand conv).
+template <int K, int STAGES, bool ID_AFFINE, bool SAVE, bool PLAIN = false>
 __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p) {
     using S = XjSmem<K, STAGES>;
     constexpr int NKT = S::NKT;
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             const uint32_t off = co < p.Co ? (co * (uint32_t)K + (uint32_t)(kt * 32 + dchunk * 8)) * 2u : OOB;
             lds_dma16(__builtin_amdgcn_readfirstlane(smem_base + kt * (XJ_CG * 64) + rb * 64), off, rsrc_w);
         }
-        for (int i = tid; i < XJ_CG; i += XJ_THREADS) {
+        for (int i = tid; !PLAIN && i < XJ_CG; i += XJ_THREADS) {
             const int c = c0 + i;
             const bool ok = (uint32_t)c < p.Co;
             tab[i] = ok ? p.out_scale[c] : 0.f;
@@ -154,6 +162,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         return (size_t)pix * p.Co + ch_off;
     };
     auto load_ids = [&](uint4 (&dst)[2][2], int t, int i) {
+        if constexpr (PLAIN) return;
         bool ok;
         const size_t off = unit_off(t, i, ok);
 #pragma unroll
@@ -167,6 +176,11 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
     constexpr int LPR = CPR;                                // lanes that share a pixel row when storing
     constexpr int NST = 32 / (64 / LPR);                    // store instructions per pass
     // one pass: chunks pk[jj][gp] (lane = pixel) -> buffer -> (lane group = pixel row) -> global; optional mask bytes
+    float ssum[NPASS][8], ssq[NPASS][8];                   // PLAIN: statistics of this lane's channels (chunk lane % LPR of each pass)
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssum[q][e] = ssq[q][e] = 0.f;
     auto stage_store = [&](const uint4 (&pk)[2][2], int pass, bf16_t* __restrict__ dst, uint8_t* __restrict__ mdst, uint32_t pix0) {
         const int row = lane & 31;
         asm volatile("" ::: "memory");
@@ -190,6 +204,12 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             if (pix < p.rows) {
                 const size_t off = (size_t)pix * p.Co + (size_t)(c0 + wc * 64 + (NPASS == 1 ? 0 : pass * 32) + c * 8);
                 *(uint4*)(dst + off) = val;
+                if constexpr (PLAIN) {
+                    float f[8];
+                    Chunk<bf16_t>::unpack(val, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ssum[pass][e] += f[e]; ssq[pass][e] += f[e] * f[e]; }
+                }
                 if (mdst) {                                 // bit e = stored value e > 0 (== pre-ReLU value > 0)
                     const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
                     uint32_t bits = 0;
@@ -246,6 +266,10 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                     v[4 + e] = __uint_as_float(r[1]);
                 }
                 if constexpr (SAVE) rpk[j][gp] = Chunk<bf16_t>::pack(v);
+                if constexpr (PLAIN) {
+                    opk[j][gp] = Chunk<bf16_t>::pack(v);
+                    continue;
+                }
                 int tb = wc * 64 + j * 32 + (2 * gp + khalf) * 8;
                 asm volatile("" : "+v"(tb));                // keep the table reads here: hoisted out of the tile loop they would
                                                             // pin 64-128 registers for the lifetime of the wavefront
@@ -297,9 +321,67 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         run_unit(idB[0], t + 1, 0);
         run_unit(idB[1], t + 1, 1);
     }
+    if constexpr (PLAIN) {
+        if (p.stats) {
+            // lanes l, l + LPR, l + 2 LPR, ... hold the same channels: fold them, then one fp64 atomic per channel and wavefront
+#pragma unroll
+            for (int q = 0; q < NPASS; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int o = LPR; o < 64; o <<= 1) {
+                        ssum[q][e] += __shfl_xor(ssum[q][e], o, 64);
+                        ssq[q][e] += __shfl_xor(ssq[q][e], o, 64);
+                    }
+            if (lane < LPR) {
+                double* dst = p.stats + (size_t)(blockIdx.x % (unsigned)p.replicas) * p.Co * 2;
+#pragma unroll
+                for (int q = 0; q < NPASS; ++q)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int ch = c0 + wc * 64 + (NPASS == 1 ? 0 : q * 32) + lane * 8 + e;
+                        unsafeAtomicAdd(dst + (size_t)ch * 2, (double)ssum[q][e]);
+                        unsafeAtomicAdd(dst + (size_t)ch * 2 + 1, (double)ssq[q][e]);
+                    }
+            }
+        }
+    }
 }
 
 }  // namespace
+
+extern "C" int vince_conv_expand_stats(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co, void* out,
+                                       double* stats, int32_t replicas, void* stream) {
+    VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_expand_stats: bf16 only");
+    VINCE_CHECK_ARG(x && w && out && rows > 0, VINCE_E_ARG, "vince_conv_expand_stats: null pointer");
+    VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_stats: K=%d (64 or 128)", K);
+    VINCE_CHECK_ARG(Co > 0 && Co % XJ_CG == 0, VINCE_E_SHAPE, "vince_conv_expand_stats: Co=%d must be a multiple of %d", Co, XJ_CG);
+    VINCE_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) == 0, VINCE_E_ALIGN, "vince_conv_expand_stats: pointers must be 16-byte aligned");
+    const unsigned long long xb = (unsigned long long)rows * K * 2, wb = (unsigned long long)Co * K * 2;
+    VINCE_CHECK_ARG(xb < 0x7ff00000ull && rows < (1ll << 31), VINCE_E_UNSUPPORTED, "vince_conv_expand_stats: input beyond the 31-bit buffer offsets");
+    if (replicas <= 0 || replicas > VINCE_STATS_REPLICAS) replicas = VINCE_STATS_REPLICAS;
+    XjParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.w = w; p.out = out; p.stats = stats; p.replicas = replicas;
+    p.rows = (uint32_t)rows; p.Co = (uint32_t)Co; p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
+    p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
+    p.cgroups = Co / XJ_CG;
+    int dev = 0, n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n_cu = prop.multiProcessorCount;
+    long grid = n_cu;
+    const long items = (long)p.ptiles * p.cgroups;
+    if (grid > items) grid = items;
+    grid = grid / p.cgroups * p.cgroups;
+    if (grid < p.cgroups) grid = p.cgroups;
+    if (K == 64)
+        hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((conv_xjoin_kernel<128, 2, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
 
 extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                                       const float* out_scale, const float* out_shift, const void* identity,

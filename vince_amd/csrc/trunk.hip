@@ -417,7 +417,18 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
         e.in_scale = c.consts(*xf_bn, 0);
         e.in_shift = c.consts(*xf_bn, 1);
     }
-    RC(vince_conv_igemm(&d, c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), &e, c.stream));
+    // layer1's expand convolutions (64 -> 256, stride 1: conv3 of every block and the downsample conv) are pure HBM streams that
+    // write 4x what they read: the persistent streaming kernel runs them at 4.2 TB/s (122 us) against the implicit-GEMM
+    // kernel's 3.1 (166 us), statistics in registers for the whole launch.  At K = 128 (layer2) it does not win (half-line
+    // stores, two channel groups re-reading the input): VINCE_XSTATS_MAX_K=128 to try, 0 = off.
+    static const int xstats_max_k = getenv("VINCE_XSTATS_MAX_K") ? atoi(getenv("VINCE_XSTATS_MAX_K")) : 64;
+    if (!desc && !xf_bn && train_bn && c.dtype == VINCE_BF16 && cv.k == 1 && cv.stride == 1 && cv.Ci <= xstats_max_k &&
+        (cv.Ci == 64 || cv.Ci == 128) && cv.Co % 256 == 0) {
+        RC(vince_conv_expand_stats(c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), (int64_t)c.t->cfg.N * cv.Ho * cv.Wo, cv.Ci,
+                                   cv.Co, at(c.ws, y_off), e.stats, e.replicas, c.stream));
+    } else {
+        RC(vince_conv_igemm(&d, c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), &e, c.stream));
+    }
     if (finalize_now || !train_bn) {
         const int64_t count = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
         RC(vince_bn_finalize(c.stats(bn), count, bn.C, c.params[bn.gamma], c.params[bn.beta], bn_running[2 * bn.index],

@@ -151,6 +151,16 @@ def conv_expand_join(x, w, out_scale, out_shift, identity, out=None, id_scale=No
     return out
 
 
+def conv_expand_stats(x, w, out, stats=None, replicas=0):
+    """out = x @ w.T (bf16, K = 64 / 128, Co multiple of 256) through the streaming kernel, BatchNorm statistics of the stored
+    values into stats (double[R][Co][2], zeroed by the caller)."""
+    require_gpu(x, w, out, stats)
+    rows, K = x.numel() // x.shape[-1], x.shape[-1]
+    check(lib().vince_conv_expand_stats(dtype_code(x), _ptr(x), _ptr(w), rows, K, w.shape[0], _ptr(out), _ptr(stats), replicas,
+                                        stream_ptr()))
+    return out
+
+
 def conv_wgrad(desc, x, dy, dw, ci_dw=None, variant=0):
     require_gpu(x, dy, dw)
     if dw.dtype != torch.float32:
