@@ -166,6 +166,14 @@ int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows
 int vince_conv_expand_stats(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co, void* out,
                             double* stats, int32_t replicas, void* stream);
 
+/* And for the block-input gradient of a bottleneck (the input gradient of its conv1 = an expand-shaped 1x1 again: dx [rows][Co]
+ * from dy [rows][K] and W^T [Co][K], bf16, K = 64 / 128, Co multiple of 256) with vince_conv_igemm's gradient epilogues:
+ *   out = dgrad + (accumulate ? (acc_mask ? out_old gated by the mask bits : out_old) : 0)        in place, and
+ *   bnred->sums += (sum g', sum g' * xhat) of the stored out, g' = out gated by bnred->mask_bits, xhat = (bnred->y - mean) * invstd
+ * (mask_scale / mask_shift are not supported here). */
+int vince_conv_expand_dgrad(int dtype, const void* dy, const void* wt, int64_t rows, int32_t K, int32_t Co, void* out,
+                            int accumulate, const uint8_t* acc_mask, const vince_bn_reduce* bnred, int32_t replicas, void* stream);
+
 /* Weight gradient (wgrad) of the same generalised conv, reduction over output pixels:
  *   dw[co, wt(a,b), ci] += sum_{n,ho,wo} dy[n,ho,wo,co] * in[n, ho*sh+dh0+a*dhs, wo*sw+dw0+b*dws, ci]
  * dw is float[Co][WT][Ci_dw] accumulated with fp32 atomics (zero it first); only ci < Ci_dw is written

@@ -713,3 +713,48 @@ def test_conv_expand_stats_streaming_kernel(rows, K, Co):
     np.testing.assert_allclose(st[:, 1].cpu().numpy(), (o * o).sum(0).cpu().numpy(), rtol=2e-6, atol=1e-3)
     want = x.double() @ w.double().t()
     assert_close(out, want.float(), torch.bfloat16, bf16=1e-2, what="vs fp64")
+
+
+@pytest.mark.parametrize("rows,K,Co,mode", [(4 * 14 * 14, 64, 256, "mask+red"), (128 * 7 + 50, 64, 512, "plain"),
+                                            (3 * 28 * 28, 128, 512, "mask+red"), (2 * 56 * 56, 128, 256, "acc+red"), (90, 64, 256, "mask+red")])
+def test_conv_expand_dgrad_streaming_kernel(rows, K, Co, mode):
+    """vince_conv_expand_dgrad against vince_conv_igemm's gradient instantiation on the same operands: the residual-gradient join
+    through the mask bytes (or unmasked, or none) in place, and the fused BatchNorm-backward sums of the consumer BatchNorm."""
+    ops = _ops()
+    from vince_amd._lib import EPI_ACCUMULATE
+    dy = (rnd(rows, K, seed=21) * 0.1).to(DEV).bfloat16()
+    wt = (rnd(Co, K, seed=22) * (2.0 / Co) ** 0.5).to(DEV).bfloat16().contiguous()          # W^T: [Co][K]
+    old = rnd(rows, Co, seed=23).to(DEV).bfloat16()
+    ylo = rnd(rows, Co, seed=24).to(DEV).bfloat16()
+    g = torch.Generator().manual_seed(25)
+    amask = torch.randint(0, 256, (rows * Co // 8,), generator=g, dtype=torch.uint8).to(DEV)
+    lbits = torch.randint(0, 256, (rows * Co // 8,), generator=g, dtype=torch.uint8).to(DEV)
+    mean, invstd = rnd(Co, seed=26).to(DEV), (torch.rand(Co, generator=g) + 0.5).to(DEV)
+    accumulate = mode != "plain"
+    use_mask = mode == "mask+red"
+    use_red = mode != "plain"
+    res = {}
+    for which in ("stream", "igemm"):
+        out = old.clone()
+        sums = torch.zeros(4, Co, 2, device=DEV, dtype=torch.float64)
+        br = ops.bn_reduce_arg(ylo, mean, invstd, sums, mask_bits=lbits) if use_red else None
+        if which == "stream":
+            ops.conv_expand_dgrad(dy, wt, out, accumulate=accumulate, acc_mask=amask if use_mask else None, bnred=br, replicas=4)
+        else:
+            ops.conv_igemm(ops.conv_desc(1, rows, 1, K, Co, 1, 1, 0), dy.view(1, rows, 1, K), wt.view(Co, 1, K), out.view(1, rows, 1, Co),
+                           flags=EPI_ACCUMULATE if accumulate else 0, acc_mask=amask if use_mask else None, bnred=br, replicas=4)
+        res[which] = (out, sums.sum(0))
+    a, b = res["stream"], res["igemm"]
+    assert_close(a[0], b[0].float(), torch.bfloat16, bf16=8e-3, what="dx")          # (the join adds in fp32 in both; one bf16 rounding)
+    # fp64 reference of the join
+    bits = ((amask.view(rows, Co // 8, 1).int() >> torch.arange(8, device=DEV).view(1, 1, 8)) & 1).view(rows, Co).bool()
+    want = dy.double() @ wt.double().t()
+    if accumulate:
+        want = want + (torch.where(bits, old.double(), torch.zeros_like(old.double())) if use_mask else old.double())
+    assert_close(a[0], want.float(), torch.bfloat16, bf16=1e-2, what="dx vs fp64")
+    if use_red:
+        lb = ((lbits.view(rows, Co // 8, 1).int() >> torch.arange(8, device=DEV).view(1, 1, 8)) & 1).view(rows, Co).bool()
+        gg = torch.where(lb, a[0].double(), torch.zeros_like(a[0].double()))
+        xhat = (ylo.double() - mean.double()) * invstd.double()
+        np.testing.assert_allclose(a[1][:, 0].cpu().numpy(), gg.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(a[1][:, 1].cpu().numpy(), (gg * xhat).sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3)

@@ -44,3 +44,22 @@ for name, hw, K in [("l1", 56, 64), ("l2", 28, 128)]:
     nbytes = rows * (K + 2 * Co) * 2
     print("%s rows=%d K=%d Co=%d: expand_join %.1f us (%.2f TB/s) | igemm join %.1f us (%.2f TB/s)" % (
         name, rows, K, Co, a, nbytes / a / 1e6, b, nbytes / b / 1e6))
+
+# ---- the block-input gradient (expand-shaped dgrad + residual-gradient join + BatchNorm-backward sums)
+for name, hw, K, Co in [("l1 dgrad", 56, 64, 256), ("l2.0 dgrad", 56, 128, 256), ("l2 dgrad", 28, 128, 512)]:
+    N = 256
+    rows = N * hw * hw
+    dy = (torch.randn(rows, K, device=dev) * 0.1).bfloat16()
+    wt = (torch.randn(Co, K, device=dev) * 0.05).bfloat16()
+    out = torch.randn(rows, Co, device=dev).bfloat16()
+    ylo = torch.randn(rows, Co, device=dev).bfloat16()
+    amask = torch.randint(0, 256, (rows * Co // 8,), device=dev, dtype=torch.uint8)
+    mean, invstd = torch.randn(Co, device=dev), torch.rand(Co, device=dev) + 0.5
+    sums = torch.zeros(16, Co, 2, device=dev, dtype=torch.float64)
+    br = ops.bn_reduce_arg(ylo, mean, invstd, sums, mask_bits=amask)
+    a = t(lambda: ops.conv_expand_dgrad(dy, wt, out, accumulate=True, acc_mask=amask, bnred=br, replicas=16))
+    d = ops.conv_desc(N, hw, hw, K, Co, 1, 1, 0)
+    b = t(lambda: ops.conv_igemm(d, dy.view(N, hw, hw, K), wt.view(Co, 1, K), out.view(N, hw, hw, Co), flags=EPI_ACCUMULATE,
+                                 acc_mask=amask, bnred=br, replicas=16))
+    nbytes = rows * (K + 3 * Co + Co / 4) * 2
+    print("%s rows=%d K=%d Co=%d: streaming %.1f us (%.2f TB/s) | igemm %.1f us" % (name, rows, K, Co, a, nbytes / a / 1e6, b))

@@ -57,6 +57,8 @@ PROTOTYPES = {
     "vince_conv_expand_join": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vince_conv_expand_stats": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "vince_conv_expand_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_void_p, P(BnReduce),
+                                        c_int32, c_void_p]),
     "vince_conv_wgrad": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_void_p]),
     "vince_bn_finalize": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                   c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

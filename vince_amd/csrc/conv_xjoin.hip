@@ -38,6 +38,14 @@ struct XjParams {
     const float* id_scale;
     const float* id_shift;
     double* stats;        // PLAIN mode: double[replicas][Co][2] per-channel (sum, sum of squares) of the stored output
+    // DGRAD mode (the block-input gradient: out = conv + (acc_mask bit ? out : 0), plus the BatchNorm-backward sums of the
+    // BatchNorm that consumes `out`): see vince_conv_expand_dgrad
+    const uint8_t* acc_mask;
+    const void* br_y;
+    const uint8_t* br_bits;
+    const float* br_mean;
+    const float* br_invstd;
+    double* br_sums;
     uint32_t rows, Co, x_bytes, w_bytes;
     int ptiles, cgroups, relu, replicas;
 };
@@ -63,7 +71,12 @@ struct XjSmem {
 // statistics of the stored values are kept per lane -- after the transposition a lane owns the same 8 channels for the whole
 // launch -- and leave as one fp64 atomic per channel per wavefront at the end (the implicit-GEMM epilogue pays a shuffle + LDS
 // reduction and 2 x 128 atomics per 128-pixel tile: 24 % of the layer1 expand conv).
-template <int K, int STAGES, bool ID_AFFINE, bool SAVE, bool PLAIN = false>
+// DGRAD: the input gradient of a bottleneck's conv1 (the "expand" shape again: dx[p][4w] from dy[p][w]) with the epilogues of
+// vince_conv_igemm's gradient instantiation -- the residual-gradient join  out = dgrad + (acc_mask bit ? out_old : 0)  in place,
+// and the (sum g', sum g' xhat) reduction of the BatchNorm below that consumes `out` (g' = out gated by ITS ReLU bits, xhat from
+// its saved conv output) -- the join in the MFMA layout with out_old requested a unit ahead, the reduction after the
+// transposition where a lane owns the same 8 channels for the whole launch.
+template <int K, int STAGES, bool ID_AFFINE, bool SAVE, bool PLAIN = false, bool DGRAD = false>
 __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p) {
     using S = XjSmem<K, STAGES>;
     constexpr int NKT = S::NKT;
@@ -99,7 +112,13 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             const uint32_t off = co < p.Co ? (co * (uint32_t)K + (uint32_t)(kt * 32 + dchunk * 8)) * 2u : OOB;
             lds_dma16(__builtin_amdgcn_readfirstlane(smem_base + kt * (XJ_CG * 64) + rb * 64), off, rsrc_w);
         }
-        for (int i = tid; !PLAIN && i < XJ_CG; i += XJ_THREADS) {
+        for (int i = tid; DGRAD && i < XJ_CG; i += XJ_THREADS) {
+            const int c = c0 + i;
+            const bool ok = (uint32_t)c < p.Co && p.br_y != nullptr;
+            tab[i] = ok ? p.br_mean[c] : 0.f;
+            tab[XJ_CG + i] = ok ? p.br_invstd[c] : 0.f;
+        }
+        for (int i = tid; !PLAIN && !DGRAD && i < XJ_CG; i += XJ_THREADS) {
             const int c = c0 + i;
             const bool ok = (uint32_t)c < p.Co;
             tab[i] = ok ? p.out_scale[c] : 0.f;
@@ -165,6 +184,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         if constexpr (PLAIN) return;
         bool ok;
         const size_t off = unit_off(t, i, ok);
+        if constexpr (DGRAD) ok = ok && p.relu;            // (p.relu doubles as "accumulate" in DGRAD mode)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -181,6 +201,8 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
     for (int q = 0; q < NPASS; ++q)
 #pragma unroll
         for (int e = 0; e < 8; ++e) ssum[q][e] = ssq[q][e] = 0.f;
+    uint4 bry[NPASS][NST];                                  // DGRAD: the consumer BatchNorm's saved conv output at this lane's store
+    uint32_t brb[NPASS][NST];                               // positions (requested at the top of the unit) and its ReLU bits
     auto stage_store = [&](const uint4 (&pk)[2][2], int pass, bf16_t* __restrict__ dst, uint8_t* __restrict__ mdst, uint32_t pix0) {
         const int row = lane & 31;
         asm volatile("" ::: "memory");
@@ -210,6 +232,26 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { ssum[pass][e] += f[e]; ssq[pass][e] += f[e] * f[e]; }
                 }
+                if constexpr (DGRAD) {
+                    if (p.br_y) {                           // (uniform) sums of the STORED gradient, as vince_bn_bwd_reduce defines them
+                        float g[8], yy[8];
+                        Chunk<bf16_t>::unpack(val, g);
+                        Chunk<bf16_t>::unpack(bry[pass][sidx], yy);
+                        int tb = wc * 64 + (NPASS == 1 ? 0 : pass * 32) + c * 8;
+                        asm volatile("" : "+v"(tb));
+                        const float4 m0 = *(const float4*)(tab + tb), m1 = *(const float4*)(tab + tb + 4);
+                        const float4 i0 = *(const float4*)(tab + XJ_CG + tb), i1 = *(const float4*)(tab + XJ_CG + tb + 4);
+                        const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                        const float is[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+                        const uint32_t bb = brb[pass][sidx];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float ge = ((bb >> e) & 1u) ? g[e] : 0.f;
+                            ssum[pass][e] += ge;
+                            ssq[pass][e] += ge * (yy[e] - mu[e]) * is[e];
+                        }
+                    }
+                }
                 if (mdst) {                                 // bit e = stored value e > 0 (== pre-ReLU value > 0)
                     const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
                     uint32_t bits = 0;
@@ -227,6 +269,27 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         asm volatile("" ::: "memory");
     };
     auto run_unit = [&](const uint4 (&ids)[2][2], int t, int i) {
+        uint2 amask = make_uint2(0xffffffffu, 0xffffffffu);  // DGRAD: the 8 acc_mask bytes of this lane's pixel (64 channels)
+        if constexpr (DGRAD) {
+            const uint32_t pixu = (uint32_t)(first + t * step) * XJ_PX + (uint32_t)(wp * 64 + i * 32);
+            if (p.acc_mask) {
+                const uint32_t pix = pixu + (uint32_t)(lane & 31);
+                if (t < ntiles && pix < p.rows) amask = *(const uint2*)(p.acc_mask + ((size_t)pix * p.Co + (size_t)(c0 + wc * 64)) / 8);
+            }
+            if (p.br_y) {
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+                    for (int sidx = 0; sidx < NST; ++sidx) {
+                        const int prow = lane / LPR + (64 / LPR) * sidx, c = lane % LPR;
+                        const uint32_t pix = pixu + (uint32_t)prow;
+                        const size_t off = (size_t)pix * p.Co + (size_t)(c0 + wc * 64 + (NPASS == 1 ? 0 : pass * 32) + c * 8);
+                        const bool ok = t < ntiles && pix < p.rows;
+                        bry[pass][sidx] = ok ? *(const uint4*)((const bf16_t*)p.br_y + off) : make_uint4(0, 0, 0, 0);
+                        brb[pass][sidx] = (ok && p.br_bits) ? (uint32_t)p.br_bits[off / 8] : 0xffu;
+                    }
+            }
+        }
         const unsigned char* xfrag = xsm + (t % STAGES) * S::XB + (wp * 64 + i * 32) * 64 + row_off;
         f32x16_t acc[2];
 #pragma unroll
@@ -270,6 +333,16 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                     opk[j][gp] = Chunk<bf16_t>::pack(v);
                     continue;
                 }
+                if constexpr (DGRAD) {
+                    float o[8];
+                    Chunk<bf16_t>::unpack(ids[j][gp], o);
+                    const int bidx = 4 * j + 2 * gp + khalf;                     // this chunk's byte among the pixel's 8
+                    const uint32_t ab = ((bidx < 4 ? amask.x : amask.y) >> (8 * (bidx & 3))) & 0xffu;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += ((ab >> e) & 1u) ? o[e] : 0.f;
+                    opk[j][gp] = Chunk<bf16_t>::pack(v);
+                    continue;
+                }
                 int tb = wc * 64 + j * 32 + (2 * gp + khalf) * 8;
                 asm volatile("" : "+v"(tb));                // keep the table reads here: hoisted out of the tile loop they would
                                                             // pin 64-128 registers for the lifetime of the wavefront
@@ -304,6 +377,18 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         }
     };
 
+    if constexpr (DGRAD) {
+        // old gradient chunks one UNIT ahead (registers are shorter here: the reduction's operands live beside them)
+        uint4 oA[2][2], oB[2][2];
+        load_ids(oA, 0, 0);
+        for (int t = 0; t < ntiles; ++t) {
+            load_ids(oB, t, 1);
+            __builtin_amdgcn_s_barrier();                   // B(t)
+            run_unit(oA, t, 0);
+            load_ids(oA, t + 1, 0);
+            run_unit(oB, t, 1);
+        }
+    } else {
     // identity chunks one whole tile ahead (two units = 8 chunks per lane in flight beside the tile being computed)
     uint4 idA[2][2][2], idB[2][2][2];
     load_ids(idA[0], 0, 0);
@@ -321,8 +406,9 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         run_unit(idB[0], t + 1, 0);
         run_unit(idB[1], t + 1, 1);
     }
-    if constexpr (PLAIN) {
-        if (p.stats) {
+    }
+    if constexpr (PLAIN || DGRAD) {
+        if (DGRAD ? (p.br_y != nullptr) : (p.stats != nullptr)) {
             // lanes l, l + LPR, l + 2 LPR, ... hold the same channels: fold them, then one fp64 atomic per channel and wavefront
 #pragma unroll
             for (int q = 0; q < NPASS; ++q)
@@ -334,7 +420,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                         ssq[q][e] += __shfl_xor(ssq[q][e], o, 64);
                     }
             if (lane < LPR) {
-                double* dst = p.stats + (size_t)(blockIdx.x % (unsigned)p.replicas) * p.Co * 2;
+                double* dst = (DGRAD ? p.br_sums : p.stats) + (size_t)(blockIdx.x % (unsigned)p.replicas) * p.Co * 2;
 #pragma unroll
                 for (int q = 0; q < NPASS; ++q)
 #pragma unroll
@@ -379,6 +465,49 @@ extern "C" int vince_conv_expand_stats(int dtype, const void* x, const void* w, 
         hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL((conv_xjoin_kernel<128, 2, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_conv_expand_dgrad(int dtype, const void* dy, const void* wt, int64_t rows, int32_t K, int32_t Co, void* out,
+                                       int accumulate, const uint8_t* acc_mask, const vince_bn_reduce* bnred, int32_t replicas,
+                                       void* stream) {
+    VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_expand_dgrad: bf16 only");
+    VINCE_CHECK_ARG(dy && wt && out && rows > 0, VINCE_E_ARG, "vince_conv_expand_dgrad: null pointer");
+    VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_dgrad: K=%d (64 or 128)", K);
+    VINCE_CHECK_ARG(Co > 0 && Co % XJ_CG == 0, VINCE_E_SHAPE, "vince_conv_expand_dgrad: Co=%d must be a multiple of %d", Co, XJ_CG);
+    VINCE_CHECK_ARG(!acc_mask || accumulate, VINCE_E_ARG, "vince_conv_expand_dgrad: acc_mask needs accumulate");
+    VINCE_CHECK_ARG(!bnred || !bnred->y || (bnred->mean && bnred->invstd && bnred->sums && !bnred->mask_scale), VINCE_E_ARG,
+                    "vince_conv_expand_dgrad: bnred needs y, mean, invstd, sums (mask through mask_bits or none)");
+    VINCE_CHECK_ARG((((uintptr_t)dy | (uintptr_t)wt | (uintptr_t)out) & 15) == 0 && ((uintptr_t)acc_mask & 7) == 0, VINCE_E_ALIGN,
+                    "vince_conv_expand_dgrad: pointers must be 16-byte (acc_mask 8-byte) aligned");
+    const unsigned long long xb = (unsigned long long)rows * K * 2, wb = (unsigned long long)Co * K * 2;
+    VINCE_CHECK_ARG(xb < 0x7ff00000ull && rows < (1ll << 31), VINCE_E_UNSUPPORTED, "vince_conv_expand_dgrad: input beyond the 31-bit buffer offsets");
+    if (replicas <= 0 || replicas > VINCE_STATS_REPLICAS) replicas = VINCE_STATS_REPLICAS;
+    XjParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = dy; p.w = wt; p.out = out; p.identity = out; p.replicas = replicas;
+    p.relu = accumulate ? 1 : 0;
+    p.acc_mask = acc_mask;
+    if (bnred && bnred->y) {
+        p.br_y = bnred->y; p.br_bits = bnred->mask_bits; p.br_mean = bnred->mean; p.br_invstd = bnred->invstd; p.br_sums = bnred->sums;
+    }
+    p.rows = (uint32_t)rows; p.Co = (uint32_t)Co; p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
+    p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
+    p.cgroups = Co / XJ_CG;
+    int dev = 0, n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n_cu = prop.multiProcessorCount;
+    long grid = n_cu;
+    const long items = (long)p.ptiles * p.cgroups;
+    if (grid > items) grid = items;
+    grid = grid / p.cgroups * p.cgroups;
+    if (grid < p.cgroups) grid = p.cgroups;
+    if (K == 64)
+        hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, false, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((conv_xjoin_kernel<128, 2, false, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

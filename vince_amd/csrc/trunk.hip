@@ -477,6 +477,13 @@ int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const voi
 
 int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, const uint8_t* acc_mask = nullptr,
           const vince_bn_reduce* bnred = nullptr, int replicas = 0) {
+    // block-input gradients of layer1 / layer2 bottlenecks (conv1 = 1x1 stride 1, 4w -> w with w = 64 / 128): the expand shape
+    // again, through the persistent streaming kernel (299 vs 362 us, 306 vs 383 us, 177 vs 192 us).  VINCE_XDGRAD=0: off.
+    static const bool xdgrad_env = !(getenv("VINCE_XDGRAD") && atoi(getenv("VINCE_XDGRAD")) == 0);
+    if (xdgrad_env && accumulate && c.dtype == VINCE_BF16 && cv.k == 1 && cv.stride == 1 && (cv.Co == 64 || cv.Co == 128) &&
+        cv.Ci % 256 == 0 && !(bnred && bnred->mask_scale))
+        return vince_conv_expand_dgrad(c.dtype, dy, at((void*)c.wcache, cv.wt), (int64_t)c.t->cfg.N * cv.Hi * cv.Wi, cv.Co, cv.Ci, dx, 1,
+                                       acc_mask, bnred, replicas, c.stream);
     vince_conv_desc ds[4];
     const int n = dgrad_descs(c.t, cv, ds);
     const int classes = cv.stride * cv.stride;

@@ -161,6 +161,16 @@ def conv_expand_stats(x, w, out, stats=None, replicas=0):
     return out
 
 
+def conv_expand_dgrad(dy, wt, out, accumulate=False, acc_mask=None, bnred=None, replicas=0):
+    """out (+)= dy @ wt.T through the streaming kernel with the gradient epilogues (vince_conv_expand_dgrad); dy [rows, K],
+    wt [Co, K], out [rows, Co] in place."""
+    require_gpu(dy, wt, out, acc_mask)
+    rows, K = dy.numel() // dy.shape[-1], dy.shape[-1]
+    check(lib().vince_conv_expand_dgrad(dtype_code(dy), _ptr(dy), _ptr(wt), rows, K, wt.shape[0], _ptr(out), int(accumulate),
+                                        _ptr(acc_mask), ctypes.byref(bnred) if bnred is not None else None, replicas, stream_ptr()))
+    return out
+
+
 def conv_wgrad(desc, x, dy, dw, ci_dw=None, variant=0):
     require_gpu(x, dy, dw)
     if dw.dtype != torch.float32:
