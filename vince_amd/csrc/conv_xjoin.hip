@@ -436,6 +436,19 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
 
 }  // namespace
 
+// CU count of the current device, asked once (the property query is a host call worth ~100 us)
+static int xj_num_cu() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n_cu = prop.multiProcessorCount;
+    }
+    return n_cu;
+}
+
 extern "C" int vince_conv_expand_stats(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co, void* out,
                                        double* stats, int32_t replicas, void* stream) {
     VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_expand_stats: bf16 only");
@@ -452,11 +465,7 @@ extern "C" int vince_conv_expand_stats(int dtype, const void* x, const void* w, 
     p.rows = (uint32_t)rows; p.Co = (uint32_t)Co; p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
     p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
     p.cgroups = Co / XJ_CG;
-    int dev = 0, n_cu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        n_cu = prop.multiProcessorCount;
-    long grid = n_cu;
+    long grid = xj_num_cu();
     const long items = (long)p.ptiles * p.cgroups;
     if (grid > items) grid = items;
     grid = grid / p.cgroups * p.cgroups;
@@ -495,11 +504,7 @@ extern "C" int vince_conv_expand_dgrad(int dtype, const void* dy, const void* wt
     p.rows = (uint32_t)rows; p.Co = (uint32_t)Co; p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
     p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
     p.cgroups = Co / XJ_CG;
-    int dev = 0, n_cu = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        n_cu = prop.multiProcessorCount;
-    long grid = n_cu;
+    long grid = xj_num_cu();
     const long items = (long)p.ptiles * p.cgroups;
     if (grid > items) grid = items;
     grid = grid / p.cgroups * p.cgroups;
@@ -535,14 +540,7 @@ extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, i
     p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
     p.cgroups = Co / XJ_CG;
     p.relu = relu;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        VINCE_CHECK_HIP(hipGetDevice(&dev));
-        VINCE_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = xj_num_cu();
     static const int wg_per_cu = getenv("VINCE_XJ_WGS") ? atoi(getenv("VINCE_XJ_WGS")) : 1;   // (measurement aid)
     long grid = (long)n_cu * wg_per_cu;
     const long items = (long)p.ptiles * p.cgroups;
