@@ -137,6 +137,69 @@ def test_recipes_match_the_reference_class_list_and_draws_are_valid():
     assert t._draw_box(100, 400) == (0, 133, 100, 133) or t._draw_box(100, 400)[2:] == (100, 133)
 
 
+def test_g10_recipes_equal_the_reference_compose_lists():
+    """Golden set G10 (oracle/make_golden_recipes.py): op order and literal parameters of every Compose list in the
+    reference's utils/transforms.py, read from its syntax tree.  RECIPES must restate exactly those."""
+    import json
+    import os
+    from vince_amd import constants
+    from vince_amd.utils import transforms as T
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_recipes.json")))
+    ref_classes = {k for k, v in g.items() if "train" in v}
+    assert ref_classes == set(T.RECIPES)                                  # every class with a train recipe, and no other
+    default_ratio = (3.0 / 4.0, 4.0 / 3.0)                               # torchvision 0.5 RandomResizedCrop default
+    for name, recipe in T.RECIPES.items():
+        ops = [o for o in g[name]["train"] if o[0] != "ToPILImage"]
+        names = [o[0] for o in ops]
+        by = {o[0]: o for o in ops}
+        # ---- order: crop, colour ops, flip, ToTensor, Normalize, [blur]
+        want = ["RandomResizedCrop"]
+        if recipe.jitter is not None or recipe.gray_p > 0:
+            want += ["RandomGrayscale", "ColorJitter"] if recipe.gray_first else ["ColorJitter", "RandomGrayscale"]
+        want += ["RandomHorizontalFlip", "ToTensor", "Normalize"]
+        if recipe.blur_p > 0:
+            want += ["RandomApply"]
+        assert names == want, (name, names, want)
+        # ---- crop
+        _, args, kw = by["RandomResizedCrop"]
+        assert args == ["SIZE"] and tuple(kw["scale"]) == recipe.crop_scale
+        assert tuple(kw.get("ratio", default_ratio)) == recipe.crop_ratio
+        assert kw.get("interpolation", "BILINEAR") == "BILINEAR"             # BILINEAR is also torchvision's default
+        # ---- colour
+        if recipe.jitter is not None:
+            assert tuple(by["ColorJitter"][1]) == recipe.jitter and by["ColorJitter"][2] == {}
+            assert by["RandomGrayscale"][2] == {"p": recipe.gray_p}
+        else:
+            assert "ColorJitter" not in by and "RandomGrayscale" not in by and recipe.gray_p == 0
+        # ---- flip (torchvision default p = 0.5), ToTensor(scale=255), Normalize literals
+        assert by["RandomHorizontalFlip"][1:] == [[], {}] and recipe.flip_p == 0.5
+        assert by["ToTensor"][2] == {"scale": 255}
+        mean, std = by["Normalize"][2]["mean"], by["Normalize"][2]["std"]
+        # ToTensor(scale=255) keeps 0..255 floats / 255 -> the constants the layout kernel uses are mean * 255, std * 255
+        assert np.allclose(np.asarray(mean, np.float32) * 255, constants.IMAGENET_MEAN, rtol=0, atol=0)
+        assert np.allclose(np.asarray(std, np.float32) * 255, constants.IMAGENET_STD, rtol=0, atol=0)
+        # ---- blur: RandomApply([RandomGaussianBlur(size[0] // 10)], p) AFTER Normalize
+        if recipe.blur_p > 0:
+            _, (inner,), kw = by["RandomApply"]
+            assert kw == {"p": recipe.blur_p} and inner == [["RandomGaussianBlur", ["SIZE0//10"], {}]]
+    assert g["RandomGaussianBlur"]["defaults"] == {"sigma_range": [0.1, 2.0]}          # the draw in BatchTransform.draw
+    for size in (64, 100, 224):
+        ks = size // 10
+        assert T.blur_kernel_size(size) == (ks + 1 if ks % 2 == 0 else ks)
+    # ---- val: every class inherits BasicImagenetTransform's Resize(size / 0.875) + CenterCrop(size)
+    assert [k for k, v in g.items() if "val" in v] == ["BasicImagenetTransform"]
+    val = [o for o in g["BasicImagenetTransform"]["val"] if o[0] != "ToPILImage"]
+    assert [o[0] for o in val] == ["Resize", "CenterCrop", "ToTensor", "Normalize"]
+    assert val[0][1] == ["SIZE/0.875"] and val[0][2] == {"interpolation": "BILINEAR"} and val[1][1] == ["SIZE"]
+    for name in T.RECIPES:                                                # all reach BasicImagenetTransform through bases
+        k = name
+        while k != "BasicImagenetTransform":
+            (k,) = g[k]["bases"]
+    assert g["constants"]["IMAGENET_MEAN"] == {"values": [0.485, 0.456, 0.406], "times": 255.0}
+    assert np.array_equal(np.asarray(g["constants"]["IMAGENET_MEAN"]["values"], np.float32) * 255, constants.IMAGENET_MEAN)
+    assert np.array_equal(np.asarray(g["constants"]["IMAGENET_STD"]["values"], np.float32) * 255, constants.IMAGENET_STD)
+
+
 def _g8():
     import os
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_augment_pillow.npz"))
