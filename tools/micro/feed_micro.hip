@@ -55,6 +55,57 @@ double run(const void* src, uint32_t bytes, unsigned* sink, int iters) {
     return ms;
 }
 
+
+// Gather pattern of the implicit-GEMM operand fetch: every wave instruction brings ROWB-byte pieces of 1024/ROWB different
+// rows (row stride `stride` bytes, like Ci * 2 of an NHWC activation), K steps walk along the row.  ROWB = 64 -> half cache
+// lines (the other half comes with the next K step); ROWB = 128 -> whole lines.  Same bytes per iteration either way.
+template <int ROWB, int PIECES>
+__global__ __launch_bounds__(256, 4) void gather_kernel(const void* src, uint32_t src_bytes, uint32_t stride, int ksteps, int iters, unsigned* sink) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PIECES * 4096];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const v4i_t rsrc = make_rsrc(src, src_bytes);
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    constexpr int LPR = ROWB / 16, RPW = 64 / LPR;            // lanes per row, rows per wave instruction
+    const uint32_t rows_per_iter = PIECES * 4 * RPW;
+    uint32_t acc = 0;
+    uint32_t row0 = (blockIdx.x * 7919u) % 4096u;
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+        const int ks = it % ksteps;
+        if (ks == 0) row0 = (row0 + rows_per_iter * 13u);
+#pragma unroll
+        for (int pc = 0; pc < PIECES; ++pc) {
+            const uint32_t row = row0 + (pc * 4 + wave) * RPW + lane / LPR;
+            const uint32_t off = (row * stride + ks * ROWB + (lane % LPR) * 16) % src_bytes;
+            lds_dma16(__builtin_amdgcn_readfirstlane(smem_base + (buf * PIECES * 4 + pc * 4 + wave) * 1024), off, rsrc);
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+        acc += *(const uint32_t*)(smem + buf * PIECES * 4096 + tid * 4);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int ROWB, int PIECES>
+void run_gather(const void* src, uint32_t bytes, unsigned* sink, uint32_t stride, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int ksteps = stride / ROWB;
+    hipLaunchKernelGGL((gather_kernel<ROWB, PIECES>), dim3(1024), dim3(256), 0, 0, src, bytes, stride, ksteps, 50, sink);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((gather_kernel<ROWB, PIECES>), dim3(1024), dim3(256), 0, 0, src, bytes, stride, ksteps, iters, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double bytes_per_cu = 4.0 * iters * PIECES * 4096.0;
+    const double clk = ms * 1e-3 * 2.4e9;
+    printf("gather: %3d-byte row pieces, row stride %5u B, %d KB per workgroup-iteration: %.2f ms, %.1f B/clk/CU (%.1f TB/s chip)\n",
+           ROWB, stride, PIECES * 4, ms, bytes_per_cu / clk, bytes_per_cu * 256 / (ms * 1e-3) / 1e12);
+}
+
 int main() {
     const uint32_t bytes = 1u << 20;
     void* src; unsigned* sink;
@@ -69,5 +120,18 @@ int main() {
     run<0, 6>(src, bytes, sink, iters);
     run<4, 4>(src, bytes, sink, iters);
     run<8, 0>(src, bytes, sink, iters);
+    {
+        const uint32_t big = 256u << 20;   // 256 MB: rows come from L2 / Infinity Cache / HBM like an activation tensor
+        void* act; hipMalloc(&act, big); hipMemset(act, 1, big);
+        for (uint32_t stride : {512u, 2048u, 4608u}) {
+            run_gather<64, 4>(act, big, sink, stride, iters);
+            run_gather<128, 4>(act, big, sink, stride, iters);
+            run_gather<64, 6>(act, big, sink, stride, iters);
+            run_gather<128, 6>(act, big, sink, stride, iters);
+        }
+        // L2-resident rows (weights-like): 1 MB region
+        run_gather<64, 4>(src, bytes, sink, 512, iters);
+        run_gather<128, 4>(src, bytes, sink, 512, iters);
+    }
     return 0;
 }

@@ -51,7 +51,7 @@ def build(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
+    if jobs or not os.path.exists(LIB) or any(_newer(o, LIB) for o in objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 

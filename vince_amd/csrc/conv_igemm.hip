@@ -43,6 +43,18 @@ struct ConvParams {
 
 constexpr int PT = 128;   // pixels per workgroup tile
 
+// Wavefront priority around an MFMA cluster (VINCE_MFMA_PRIO, build-time): with equal priorities the SIMD's arbiter interleaves the
+// MFMAs of its resident wavefronts, which locks them into the same phase (all in their MFMA cluster, then all in their
+// LDS / barrier phase); a raised priority lets one wavefront run its cluster through while the other fetches.
+#ifndef VINCE_MFMA_PRIO
+#define VINCE_MFMA_PRIO 0
+#endif
+template <int ON> __device__ __forceinline__ void mfma_prio() {
+#if VINCE_MFMA_PRIO
+    if constexpr (ON) __builtin_amdgcn_s_setprio(VINCE_MFMA_PRIO); else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     __device__ static inline void run(const uint4& a, const uint4& b, f32x16_t& c) {
@@ -228,7 +240,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
                     *(uint4*)(out + off[u]) = v;
                 }
             } else {
-                *(uint4*)(out + off[u]) = v;
+                if (!(p.ablate & 32)) *(uint4*)(out + off[u]) = v;   // ablate 32: measurement aid, no output stores
             }
             if (p.e.stats) {
                 float f[CH];
@@ -421,8 +433,9 @@ struct SmemD {
 // PTL = pixels per workgroup tile (128 or 256).  The L2 -> LDS fill rate of a CU (measured ~19 B/clk with every CU
 // streaming) caps a 128x128 tile at ~700 TFLOP/s chip-wide: 256 B of operands per K element feed 32768 FLOP.  The
 // 256-pixel tile moves 25 % fewer bytes per FLOP (each wave owns 128 pixels x CT/2 channels).
-template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, int MODE, bool XF = false>
+template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, int MODE, bool XF = false, bool ROT = false>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvParams p) {
+    static_assert(!(XF && ROT), "the rotated main loop has no operand transform");
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64, PI = PTL / 64;
     using S = SmemD<T, CT, KC, STAGES, PTL>;
@@ -435,6 +448,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     constexpr bool ILV = CT == 128 && STAGES == 3 && !XF;    // DMA issue interleaved with the MFMAs (see issue_piece)
     __shared__ __attribute__((aligned(16))) unsigned char smem[XF ? S::BYTES_XF : S::BYTES0];
 
+    if (p.ablate & 64) return;   // measurement aid: launch + workgroup dispatch only
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave & 1, wp = wave >> 1;
@@ -586,7 +600,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
 
     // split-K (tiny-M GEMMs: the projection MLP): this workgroup reduces K tiles [kt0, kt1) only
     const int kt0 = p.kt_per_split > 0 ? (int)blockIdx.y * p.kt_per_split : 0;
-    const int kt1 = p.kt_per_split > 0 ? min(p.nkt, kt0 + p.kt_per_split) : p.nkt;
+    const int kt1 = (p.ablate & 16) ? kt0 : (p.kt_per_split > 0 ? min(p.nkt, kt0 + p.kt_per_split) : p.nkt);   // ablate 16: no main loop
     // prologue: STAGES-1 tiles in flight (tiles past the end are issued as all-zero fills so the counts stay uniform)
 #pragma unroll
     for (int st = 0; st < STAGES - 1; ++st) {
@@ -605,6 +619,84 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     const int sw = ((lane & 31) >> SWSH) & SWMASK, khalf = lane >> 5;
     const int row_off = (lane & 31) * KB;
     int buf = 0, nbuf = STAGES - 1;
+    if constexpr (ROT) {
+        // ROTATED main loop.  A K tile is NP = KC/2 MFMA phases (16 reduction elements each).  The fragments of phase s+1 are
+        // read from LDS BEFORE the MFMAs of phase s are issued, and the rotation carries across the tile boundary: the last
+        // phase's MFMAs are issued AFTER the barrier that publishes the next tile, right behind the reads of that tile's first
+        // fragments -- so every LDS round trip (and the barrier skew) hides under 8..16 MFMAs of the same wavefront instead
+        // of relying on another resident workgroup.  Measured critical path of the plain loop on the 256x128 tile: ~850
+        // cycles of ds_read latency + barrier per K tile next to 512 cycles of MFMA, not overlapped within a wavefront.
+        //   iteration kt:  [reads F1(kt)] [MFMA F0(kt) + DMA pieces of tile kt+S-1] [vmcnt, barrier] [reads F0(kt+1)] [MFMA F1(kt) + rest]
+        // DMA pieces issued before the wait (PB of them) stay in flight across it; the buffer they overwrite (tile kt-1's) was
+        // released by the previous iteration's barrier, which every wavefront reaches with its fragment reads complete.
+        constexpr int NP = KC / 2;
+        static_assert(NP % 2 == 0, "two fragment sets alternate by phase parity");
+        constexpr int NMP = CJ * PI;                                  // MFMAs per phase
+        constexpr int NM = NP * NMP;
+        constexpr int EVERY = ILV ? (NM / PER_STAGE > 0 ? NM / PER_STAGE : 1) : 1;
+        // pieces that ride on the MFMAs of phases 0 .. NP-2 (before the wait); the last phase carries the rest, after it
+        constexpr int PB_RAW = ILV ? ((NP - 1) * NMP + EVERY - 1) / EVERY : PER_STAGE;
+        constexpr int PB = PB_RAW < PER_STAGE ? PB_RAW : PER_STAGE;
+        static_assert(!ILV || STAGES >= 3, "interleaved issue needs the tile after next in flight");
+        auto read_frags = [&](int b, int s_, uint4 (&wf)[CJ], uint4 (&xf)[PI]) {
+            const unsigned char* xs = smem + b * S::STAGE + (wp * (PTL / 2)) * KB + row_off;
+            const unsigned char* ws = smem + b * S::STAGE + S::XB + (wc * (CT / 2)) * KB + row_off;
+            const int slot = ((s_ * 2 + khalf) ^ sw) * 16;
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) wf[j] = *(const uint4*)(ws + j * 32 * KB + slot);
+#pragma unroll
+            for (int i = 0; i < PI; ++i) xf[i] = *(const uint4*)(xs + i * 32 * KB + slot);
+        };
+        uint4 wfa[CJ], xfa[PI], wfb[CJ], xfb[PI];
+        read_frags(0, 0, wfa, xfa);
+        for (int kt = kt0; kt < kt1; ++kt) {
+            issue_tile(kt + STAGES - 1, nbuf);
+            const int cur_nbuf = nbuf;
+#pragma unroll
+            for (int s_ = 0; s_ < NP; ++s_) {
+                uint4 (&wfc)[CJ] = (s_ & 1) ? wfb : wfa;
+                uint4 (&xfc)[PI] = (s_ & 1) ? xfb : xfa;
+                uint4 (&wfn)[CJ] = (s_ & 1) ? wfa : wfb;
+                uint4 (&xfn)[PI] = (s_ & 1) ? xfa : xfb;
+                if (s_ + 1 < NP) {
+                    read_frags(buf, s_ + 1, wfn, xfn);
+                } else {
+                    // tile kt+1 has landed (this wave's share; the barrier extends it to all waves)
+                    wait_vmcnt<(STAGES - 3 >= 0 ? STAGES - 3 : 0) * PER_STAGE + (STAGES >= 3 ? PB : 0)>();
+                    __syncthreads();
+                    buf = buf + 1 == STAGES ? 0 : buf + 1;
+                    nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
+                    if (kt + 1 < kt1) read_frags(buf, 0, wfn, xfn);
+                }
+                mfma_prio<1>();
+#pragma unroll
+                for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < PI; ++i) {
+                        Mma<T>::run(wfc[j], xfc[i], acc[j][i]);
+                        if constexpr (ILV) {
+                            const int m = (s_ * CJ + j) * PI + i;
+                            if (m % EVERY == 0 && m / EVERY < PER_STAGE) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_piece(m / EVERY, cur_nbuf);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                mfma_prio<0>();
+            }
+            if constexpr (ILV) {   // pieces the MFMA count of a tile could not carry
+                constexpr int DONE = (NM + EVERY - 1) / EVERY < PER_STAGE ? (NM + EVERY - 1) / EVERY : PER_STAGE;
+#pragma unroll
+                for (int pc = DONE; pc < PER_STAGE; ++pc) issue_piece(pc, cur_nbuf);
+            }
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (p.ablate & 128) return;
+        conv_epilogue<T, CT, S::CRS, MODE, PTL, (MINW >= 4 ? 2 : 4)>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
+        return;
+    }
     for (int kt = kt0; kt < kt1; ++kt) {
         if (!(p.ablate & 1)) issue_tile(kt + STAGES - 1, nbuf);
         const unsigned char* xs = smem + buf * S::STAGE + (wp * (PTL / 2)) * KB + row_off;
@@ -623,6 +715,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
 #pragma unroll
                 for (int i = 0; i < PI; ++i) asm volatile("" ::"v"(xf[i].x), "v"(xf[i].w));
             } else {
+                mfma_prio<1>();
                 if constexpr (ILV) {
                     constexpr int NM = (KC / 2) * CJ * PI;                   // MFMA groups per K tile
                     constexpr int EVERY = NM / PER_STAGE > 0 ? NM / PER_STAGE : 1;
@@ -644,6 +737,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
 #pragma unroll
                         for (int i = 0; i < PI; ++i) Mma<T>::run(wf[j], xf[i], acc[j][i]);
                 }
+                mfma_prio<0>();
             }
         }
         if constexpr (ILV) {   // pieces the MFMA count of a tile could not carry
@@ -666,6 +760,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     }
     wait_vmcnt<0>();
     __syncthreads();
+    if (p.ablate & 128) {   // measurement aid: no epilogue (one dummy store keeps the accumulators alive)
+        float t = 0.f;
+        for (int j = 0; j < CJ; ++j) for (int i = 0; i < PI; ++i) t += acc[j][i][0];
+        if (t == 1.2345f) ((float*)p.out)[0] = t;
+        return;
+    }
     // rows in flight per thread in the epilogue: the 128-VGPR (4 workgroups/CU) configuration has no room for more than 2
     conv_epilogue<T, CT, S::CRS, MODE, PTL, (MINW >= 4 ? 2 : 4)>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
@@ -687,6 +787,10 @@ int launch(ConvParams& p, hipStream_t stream) {
     static int big_min_k = getenv("VINCE_BIG_MIN_K") ? atoi(getenv("VINCE_BIG_MIN_K")) : 1024;
     static int big_min_tiles = getenv("VINCE_BIG_MIN_TILES") ? atoi(getenv("VINCE_BIG_MIN_TILES")) : 256;
     static long narrow256 = getenv("VINCE_NARROW256_MIN_TILES") ? atol(getenv("VINCE_NARROW256_MIN_TILES")) : 2048;   // 0 = off
+    // rotated main loop (fragment reads one MFMA phase ahead, across the tile barrier): bit 0 the 256x128 tile, 1 the 256x64
+    // tile, 2 the 2-stage 128-pixel tile, 3 the 3-stage 128-pixel tile
+    static int rot = getenv("VINCE_ROT") ? atoi(getenv("VINCE_ROT")) : 9;
+    static int rot_min_k = getenv("VINCE_ROT_MIN_K") ? atoi(getenv("VINCE_ROT_MIN_K")) : 0;
     const bool xf = p.e.in_scale != nullptr;
     if (xf && !(p.in_bytes && p.w_bytes && k_elems >= dlds_min_k && !BWD)) {
         vince_set_error("vince_conv_igemm: the operand transform needs the direct-to-LDS forward kernels (tensors < 2 GiB)");
@@ -696,6 +800,21 @@ int launch(ConvParams& p, hipStream_t stream) {
         const int cpt = p.cpt_mask == 0x7fffffff ? p.total_chunks : p.cpt_mask + 1;
         p.uniform_taps = (cpt % 4 == 0) && (p.total_chunks % 4 == 0);
         p.nkt = (p.total_chunks + 3) / 4;     // 64-byte K rows
+        // 1x1 reductions at least VINCE_KC8_MIN_K long on the 128-pixel tile: 128-byte K rows (KC = 8), i.e. whole cache lines per
+        // DMA'd row -- 64-byte row pieces are request-bound (tools/micro/feed_micro: 14 B/clk/CU against 31 with whole lines);
+        // two stages of 32 KB, two workgroups per CU.  Measured: 2048 -> 512 at 7x7 43.6 -> 37.8 us; shorter reductions and the
+        // 3x3 layers lose more to the halved occupancy than the whole lines give back.
+        static int kc8_min_k = getenv("VINCE_KC8_MIN_K") ? atoi(getenv("VINCE_KC8_MIN_K")) : 2048;   // 0 = off
+        if constexpr (sizeof(T) == 2 && CT == 128) {
+            const bool big = dlds_cfg == 5 && k_elems >= big_min_k && (long)((p.M + 255) / 256) * p.ctiles >= big_min_tiles;
+            if (kc8_min_k > 0 && !xf && !big && p.cpt_mask == 0x7fffffff && p.total_chunks % 8 == 0 && k_elems >= kc8_min_k) {
+                p.uniform_taps = 1;
+                p.nkt = p.total_chunks / 8;
+                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 8, 2, 2, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                VINCE_CHECK_LAUNCH();
+                return VINCE_OK;
+            }
+        }
         if (dlds_cfg == 5 && CT == 128 && k_elems >= big_min_k && (long)((p.M + 255) / 256) * p.ctiles >= big_min_tiles) {
             // 256-pixel tiles, 3 stages (2 workgroups per CU): long reductions with enough tiles to fill the chip --
             // 25 % fewer operand bytes per FLOP through the L2 -> LDS path that bounds the 128-pixel tile
@@ -706,6 +825,9 @@ int launch(ConvParams& p, hipStream_t stream) {
                     if constexpr (!BWD)
                         hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, 0, true>), dim3(p.ptiles * p.ctiles),
                                            dim3(256), 0, stream, p);
+                } else if (rot & 1) {
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE, false, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                                       stream, p);
                 } else {
                     hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
                                        stream, p);
@@ -721,6 +843,9 @@ int launch(ConvParams& p, hipStream_t stream) {
                     if constexpr (!BWD)
                         hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, 0, true>), dim3(p.ptiles * p.ctiles),
                                            dim3(256), 0, stream, p);
+                } else if (rot & 2) {
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, MODE, false, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                                       stream, p);
                 } else {
                     hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
                                        stream, p);
@@ -758,10 +883,16 @@ int launch(ConvParams& p, hipStream_t stream) {
                 // of 2 stages / 4 workgroups
                 // default 2048: layer4's 3x3 (K = 4608) 92.6 -> 85 us, 2048 -> 512 50 -> 44 us; shorter reductions lose
                 static const int s3_min_k = getenv("VINCE_S3_MIN_K") ? atoi(getenv("VINCE_S3_MIN_K")) : 2048;
-                if (s3_min_k > 0 && k_elems >= s3_min_k)
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
-                else
+                if (s3_min_k > 0 && k_elems >= s3_min_k) {
+                    if (rot & 8)
+                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE, false, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                    else
+                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                } else if ((rot & 4) && k_elems >= rot_min_k) {
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE, false, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                } else {
                     hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                }
             }
         }
         VINCE_CHECK_LAUNCH();
