@@ -267,6 +267,23 @@ def test_conv_suite_through_the_256_pixel_tiles():
                       "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem or test_conv_operand_transform")
 
 
+def test_conv_suite_through_the_rotated_main_loop():
+    """The rotated main loop (fragment reads one MFMA phase ahead, across the tile barrier; VINCE_ROT bit per tile shape) is the
+    default only for the 256x128 and the 3-stage tiles, which small test shapes do not reach: the conv parity tests are
+    re-run with every bit set, once on the 128-pixel tiles (K thresholds lowered so the 3-stage ring is taken too) and once
+    with the 256-pixel tiles forced."""
+    _rerun_conv_tests({"VINCE_ROT": "15", "VINCE_S3_MIN_K": "512"},
+                      "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem")
+    _rerun_conv_tests({"VINCE_ROT": "15", "VINCE_BIG_MIN_K": "1", "VINCE_BIG_MIN_TILES": "1", "VINCE_NARROW256_MIN_TILES": "1"},
+                      "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem")
+
+
+def test_conv_suite_through_whole_line_k_rows():
+    """128-byte K rows (KC = 8) are taken by 1x1 reductions of at least VINCE_KC8_MIN_K elements (2048 by default): re-run
+    with the threshold at 64 so that every 1x1 test shape goes through them, forward and input gradient."""
+    _rerun_conv_tests({"VINCE_KC8_MIN_K": "64"}, "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_linear_fwd_bwd")
+
+
 @pytest.mark.parametrize("rows,cin,cout", [(37, 512, 64), (256, 2048, 2048), (256, 2048, 128), (64, 1000, 96)])
 def test_linear_fwd_bwd(rows, cin, cout):
     # (256, 2048, *) are the ResNet-50 projection-MLP shapes: the launcher takes its split-K route for them
