@@ -239,6 +239,53 @@ def test_conv_operand_transform(cfg, dtype):
     assert_close(from_nhwc(got), ref, dtype, bf16=3e-2, what="conv with operand transform")
 
 
+def _random_conv_cases(n=14, seed=20260929):
+    """Seeded shapes off the ResNet grid: odd images, batch tails, channel counts that do not fill a 64- or 128-wide tile,
+    both kernel sizes and strides (multi-tap layers need Ci / 8 to be a power of two: vince_conv_igemm's documented limit)."""
+    rs = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < n:
+        k = int(rs.choice([1, 3]))
+        s_ = int(rs.choice([1, 2]))
+        ci = int(rs.choice([8, 16, 64, 128, 256] if k == 3 else [8, 24, 64, 72, 136, 256, 520]))
+        co = int(rs.choice([8, 16, 64, 128, 256] if k == 3 else [8, 24, 64, 80, 128, 200, 264]))   # (the input gradient of a 3x3 reduces over Co)
+        h, w = int(rs.randint(5, 34)), int(rs.randint(5, 34))
+        cases.append((int(rs.randint(1, 4)), h, w, ci, co, k, s_, k // 2))
+    return cases
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", _random_conv_cases())
+def test_conv_random_shapes_fwd_dgrad_wgrad(cfg, dtype):
+    """Forward (+ statistics), input gradient and weight gradient against torch on the CPU for seeded off-grid shapes."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, p = cfg
+    x = q(rnd(N, Ci, H, W, seed=31), dtype).requires_grad_(True)
+    w = q(rnd(Co, Ci, k, k, seed=32, scale=(2.0 / (Ci * k * k)) ** 0.5), dtype).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = q(rnd(*y.shape, seed=33), dtype)
+    y.backward(dy)
+    wk, wt = weights_krsc(w.detach(), dtype)
+    d = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
+    out = torch.full((N, d.Ho, d.Wo, Co), float("nan"), device=DEV, dtype=dtype)
+    stats = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
+    ops.conv_igemm(d, to_nhwc(x.detach(), dtype), wk, out, stats=stats)
+    assert_close(from_nhwc(out), y.detach(), dtype, what="conv fwd %s" % (cfg,))
+    o = out.float().cpu().reshape(-1, Co).double()
+    np.testing.assert_allclose(stats.sum(0)[:, 0].cpu().numpy(), o.sum(0).numpy(), rtol=1e-5, atol=1e-3)
+    dyg = to_nhwc(dy, dtype)
+    dx = torch.full((N, H, W, Ci), float("nan"), device=DEV, dtype=dtype)
+    descs = ops.dgrad_descs(N, H, W, Ci, Co, k, s, p)
+    if len(descs) < s * s:
+        dx.zero_()
+    for dd in descs:
+        ops.conv_igemm(dd, dyg, wt, dx)
+    assert_close(from_nhwc(dx), x.grad, dtype, what="dgrad %s" % (cfg,))
+    dw = torch.zeros(Co, k * k, Ci, device=DEV)
+    ops.conv_wgrad(d, to_nhwc(x.detach(), dtype), dyg, dw)
+    assert_close(dw, w.grad.permute(0, 2, 3, 1).reshape(Co, k * k, Ci), dtype, f32=1e-4, what="wgrad %s" % (cfg,))
+
+
 def _rerun_conv_tests(extra_env, select="test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem"):
     import os
     import subprocess
