@@ -166,6 +166,15 @@ int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows
 int vince_conv_expand_stats(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co, void* out,
                             double* stats, int32_t replicas, void* stream);
 
+/* Layer1's 3x3 convolution (reference models/building_blocks/resnet.py:119-121 conv2 of the 64-wide bottlenecks: 64 -> 64 channels,
+ * 56 pixels wide, stride 1, pad 1, bf16) as an image-strip kernel: input rows resident in an LDS ring, every input element crosses
+ * the L2 -> LDS path once, the nine taps are shifted fragment reads.  x [N][H][56][64], w [64][9][64] (the prepared [Co][tap][Ci]
+ * copy), out [N][H][56][64]; per-channel (sum, sum of squares) of the STORED output into stats (double[replicas][64][2], zeroed by
+ * the caller; optional) exactly as vince_conv_igemm(stats) computes them.  tap_map: the weight tap read for kernel position
+ * (dh + 1) * 3 + (dw + 1) (null: identity = the forward convolution).  H must be a multiple of 4. */
+int vince_conv3x3_strip(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                        const int32_t* tap_map, void* out, double* stats, int32_t replicas, void* stream);
+
 /* And for the block-input gradient of a bottleneck (the input gradient of its conv1 = an expand-shaped 1x1 again: dx [rows][Co]
  * from dy [rows][K] and W^T [Co][K], bf16, K = 64 / 128, Co multiple of 256) with vince_conv_igemm's gradient epilogues:
  *   out = dgrad + (accumulate ? (acc_mask ? out_old gated by the mask bits : out_old) : 0)        in place, and

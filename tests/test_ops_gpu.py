@@ -758,6 +758,38 @@ def test_similarity_cross_entropy_unequal_positives_use_float():
     loss_util.USE_FLOAT = None
 
 
+@pytest.mark.parametrize("N,H", [(1, 4), (3, 56), (5, 8), (2, 20)])
+def test_conv3x3_image_strip_kernel(N, H):
+    """vince_conv3x3_strip (layer1's 3x3: 64 -> 64 channels, 56 wide): output BIT-identical to vince_conv_igemm's on the same
+    operands, statistics equal to the sums over the stored output, and both against torch on the CPU; also with a permuted tap
+    map (what an input gradient would pass)."""
+    ops = _ops()
+    x = rnd(N, H, 56, 64, seed=41).clamp_(min=0).to(DEV).bfloat16()
+    w = (rnd(64, 9, 64, seed=42) * (2.0 / 576) ** 0.5).to(DEV).bfloat16().contiguous()
+    out = torch.full((N, H, 56, 64), 5.0, device=DEV).bfloat16()
+    stats = torch.zeros(4, 64, 2, device=DEV, dtype=torch.float64)
+    ops.conv3x3_strip(x, w, out, stats=stats, replicas=4)
+    ref = torch.empty_like(out)
+    ops.conv_igemm(ops.conv_desc(N, H, 56, 64, 64, 3, 1, 1), x, w, ref)
+    assert torch.equal(out, ref)
+    o = out.double().reshape(-1, 64)
+    st = stats.sum(0)
+    np.testing.assert_allclose(st[:, 0].cpu().numpy(), o.sum(0).cpu().numpy(), rtol=2e-6, atol=1e-3)
+    np.testing.assert_allclose(st[:, 1].cpu().numpy(), (o * o).sum(0).cpu().numpy(), rtol=2e-6, atol=1e-3)
+    want = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().view(64, 3, 3, 64).permute(0, 3, 1, 2), None, 1, 1)
+    assert_close(out.permute(0, 3, 1, 2), want, torch.bfloat16, bf16=1e-2, what="strip conv vs torch")
+    flip = list(range(8, -1, -1))                            # kernel rotated by 180 degrees
+    ops.conv3x3_strip(x, w, out, tap_map=flip)
+    wantf = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().view(64, 3, 3, 64).flip(1, 2).permute(0, 3, 1, 2), None, 1, 1)
+    assert_close(out.permute(0, 3, 1, 2), wantf, torch.bfloat16, bf16=1e-2, what="strip conv, flipped taps")
+
+
+def test_conv3x3_image_strip_kernel_several_images_per_workgroup():
+    """The ring restarts per image: with fewer workgroups than images (VINCE_STRIP_GRID, read once per process) every workgroup
+    walks several images -- re-run the parity test above in a child process with 2 workgroups."""
+    _rerun_conv_tests({"VINCE_STRIP_GRID": "2"}, "test_conv3x3_image_strip_kernel and not several")
+
+
 @pytest.mark.parametrize("rows,K,Co", [(4 * 14 * 14, 64, 256), (128 * 9 + 77, 64, 512), (3 * 28 * 28, 128, 512), (50, 128, 256)])
 def test_conv_expand_stats_streaming_kernel(rows, K, Co):
     """vince_conv_expand_stats: the expand convolution on its own through the streaming kernel -- output equal to

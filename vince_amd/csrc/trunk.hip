@@ -422,10 +422,17 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
     // kernel's 3.1 (166 us), statistics in registers for the whole launch.  At K = 128 (layer2) it does not win (half-line
     // stores, two channel groups re-reading the input): VINCE_XSTATS_MAX_K=128 to try, 0 = off.
     static const int xstats_max_k = getenv("VINCE_XSTATS_MAX_K") ? atoi(getenv("VINCE_XSTATS_MAX_K")) : 64;
+    static const bool strip3x3 = !(getenv("VINCE_STRIP3X3") && atoi(getenv("VINCE_STRIP3X3")) == 0);
     if (!desc && !xf_bn && train_bn && c.dtype == VINCE_BF16 && cv.k == 1 && cv.stride == 1 && cv.Ci <= xstats_max_k &&
         (cv.Ci == 64 || cv.Ci == 128) && cv.Co % 256 == 0) {
         RC(vince_conv_expand_stats(c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), (int64_t)c.t->cfg.N * cv.Ho * cv.Wo, cv.Ci,
                                    cv.Co, at(c.ws, y_off), e.stats, e.replicas, c.stream));
+    } else if (strip3x3 && !desc && !xf_bn && c.dtype == VINCE_BF16 && cv.k == 3 && cv.stride == 1 && cv.Ci == 64 && cv.Co == 64 &&
+               cv.Wo == 56 && cv.Ho % 4 == 0 && cv.Hi == cv.Ho && cv.Wi == cv.Wo) {
+        // layer1's 3x3 (conv2 of the 64-wide bottlenecks at 56 x 56): the image-strip kernel (csrc/conv3x3_strip.hip) -- input rows
+        // resident in an LDS ring, each element fetched once in whole lines; bit-identical output and statistics
+        RC(vince_conv3x3_strip(c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), c.t->cfg.N, cv.Ho, cv.Wo, cv.Ci, cv.Co, nullptr,
+                               at(c.ws, y_off), e.stats, e.replicas, c.stream));
     } else {
         RC(vince_conv_igemm(&d, c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), &e, c.stream));
     }

@@ -161,6 +161,19 @@ def conv_expand_stats(x, w, out, stats=None, replicas=0):
     return out
 
 
+def conv3x3_strip(x, w, out, stats=None, replicas=0, tap_map=None):
+    """out = conv3x3(x, w) for layer1's shape (x, out [N, H, 56, 64] bf16, w [64, 9, 64]) through the image-strip kernel, BatchNorm
+    statistics of the stored values into stats (double[R][64][2], zeroed by the caller)."""
+    require_gpu(x, w, out, stats)
+    N, H, W, Ci = x.shape
+    tm = None
+    if tap_map is not None:
+        tm = (ctypes.c_int32 * 9)(*[int(v) for v in tap_map])
+    check(lib().vince_conv3x3_strip(dtype_code(x), _ptr(x), _ptr(w), N, H, W, Ci, w.shape[0], tm, _ptr(out), _ptr(stats), replicas,
+                                    stream_ptr()))
+    return out
+
+
 def conv_expand_dgrad(dy, wt, out, accumulate=False, acc_mask=None, bnred=None, replicas=0):
     """out (+)= dy @ wt.T through the streaming kernel with the gradient epilogues (vince_conv_expand_dgrad); dy [rows, K],
     wt [Co, K], out [rows, Co] in place."""
