@@ -87,9 +87,20 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cg = blockIdx.x % p.cgroups;                  // fixed for the lifetime of the workgroup (grid % cgroups == 0)
+    // Workgroup -> (channel group, pixel-tile lane), fixed for its lifetime (grid % cgroups == 0).  The hardware deals consecutive
+    // workgroups to the 8 XCDs round-robin: the channel groups of ONE pixel-tile lane are put on the same XCD, so that the input
+    // tile comes from HBM once and from that XCD's L2 for the other groups (b % cgroups would put them on different XCDs).
+    int cg, first;
+    const int step = gridDim.x / p.cgroups;
+    if (p.cgroups > 1 && gridDim.x % (VINCE_NUM_XCD * p.cgroups) == 0) {
+        const int xcd = blockIdx.x % VINCE_NUM_XCD, i = blockIdx.x / VINCE_NUM_XCD;
+        cg = i % p.cgroups;
+        first = xcd * (step / VINCE_NUM_XCD) + i / p.cgroups;
+    } else {
+        cg = blockIdx.x % p.cgroups;
+        first = blockIdx.x / p.cgroups;
+    }
     const int c0 = cg * XJ_CG;
-    const int first = blockIdx.x / p.cgroups, step = gridDim.x / p.cgroups;
     const int ntiles = first < p.ptiles ? (p.ptiles - first + step - 1) / step : 0;   // pixel tiles first, first + step, ...
 
     const v4i_t rsrc_x = make_rsrc(p.x, p.x_bytes);
