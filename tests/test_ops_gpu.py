@@ -61,6 +61,11 @@ CONVS = [
     (2, 14, 14, 256, 512, 1, 2, 0),
     (2, 7, 7, 512, 512, 3, 1, 1),
     (1, 38, 38, 64, 64, 3, 1, 1),
+    # shapes the 8-wavefront 256 x 256 core takes when forced (Co and the input gradient's Ci multiples of 256, Ci multiple of 64):
+    # several tiles with a ragged last one, a stride-2 3x3 (input gradient = four parity classes with their own tap maps)
+    (3, 14, 14, 256, 256, 3, 1, 1),
+    (5, 9, 9, 512, 256, 1, 1, 0),
+    (3, 13, 15, 256, 512, 3, 2, 1),
 ]
 
 
@@ -323,6 +328,16 @@ def test_conv_suite_through_the_rotated_main_loop():
                       "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem")
     _rerun_conv_tests({"VINCE_ROT": "15", "VINCE_BIG_MIN_K": "1", "VINCE_BIG_MIN_TILES": "1", "VINCE_NARROW256_MIN_TILES": "1"},
                       "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem")
+
+
+def test_conv_suite_through_the_8_wavefront_core():
+    """conv_m8 (256 pixels x 256 channels, 8 wavefronts, csrc/conv_m8.hip) is selected for long bf16 reductions with at least 48
+    tiles -- benchmark sizes only.  Re-run the conv parity tests with both thresholds at 1 so that every shape with Co % 256 == 0
+    and Ci % 64 == 0 (forward) or the transposed condition (input gradient, with the join / BatchNorm-reduction epilogues) goes
+    through it, and once more with it switched off (the default run mixes both)."""
+    sel = "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_random_shapes_fwd_dgrad_wgrad"
+    _rerun_conv_tests({"VINCE_M8_MIN_K": "1", "VINCE_M8_MIN_TILES": "1"}, sel)
+    _rerun_conv_tests({"VINCE_M8": "0"}, "test_conv_fwd_stats or test_conv_dgrad_wgrad")
 
 
 def test_conv_suite_through_whole_line_k_rows():

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libvince_hip.so")
-SOURCES = ["error.cpp", "conv_igemm.hip", "conv_xjoin.hip", "conv3x3_strip.hip", "conv_wgrad.hip", "bn_pool.hip", "misc.hip", "infonce.hip", "trunk.hip", "augment.hip"]
+SOURCES = ["error.cpp", "conv_igemm.hip", "conv_m8.hip", "conv_xjoin.hip", "conv3x3_strip.hip", "conv_wgrad.hip", "bn_pool.hip", "misc.hip", "infonce.hip", "trunk.hip", "augment.hip"]
 # augment.hip restates Pillow's double / float arithmetic: an fma where the C library rounds twice changes results
 EXTRA_FLAGS = {"augment.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
@@ -25,11 +25,22 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, measure=False):
+    """measure=True: the measurement build (-DVINCE_MEASURE: ablation switches inside the conv kernels) as
+    lib/libvince_hip_measure.so, loaded by tools through VINCE_HIP_LIB; the product library never carries them."""
+    global OBJDIR, LIB
+    if measure:
+        OBJDIR = os.path.join(HERE, "build_measure")
+        LIB = os.path.join(LIBDIR, "libvince_hip_measure.so")
+    extra = os.environ.get("VINCE_BUILD_FLAGS", "").split()    # A/B builds of kernel variants: a second library, by name
+    if extra:
+        tag = os.environ.get("VINCE_BUILD_TAG", "ab")
+        OBJDIR = os.path.join(HERE, "build_" + tag)
+        LIB = os.path.join(LIBDIR, "libvince_hip_%s.so" % tag)
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "vince_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_core.h"), os.path.join(os.path.dirname(HERE), "include", "vince_hip.h")]
     jobs = []
     objs = []
     for s in SOURCES:
@@ -37,7 +48,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(h, obj) for h in headers):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + (["-DVINCE_MEASURE"] if measure else []) + extra + EXTRA_FLAGS.get(s, []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):
@@ -57,4 +68,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, measure="--measure" in sys.argv))

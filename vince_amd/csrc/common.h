@@ -178,6 +178,18 @@ static __device__ __forceinline__ void lds_dma16(uint32_t lds_addr_uniform, uint
         : "memory");
 }
 
+// The same without preserving M0: only for kernels whose only M0 users are these instructions (M0 is a reserved register the
+// compiler touches for indirect register indexing, LDS-direct and message sends -- none of which such a kernel may contain).
+static __device__ __forceinline__ void lds_dma16_m0(uint32_t lds_addr_uniform, uint32_t voff, v4i_t rsrc) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, 0 offen lds"
+        :
+        : "s"(lds_addr_uniform), "v"(voff), "s"(rsrc)
+        : "memory");
+}
+
 static __device__ __forceinline__ v4i_t make_rsrc(const void* ptr, uint32_t bytes) {
     const uint64_t a = (uint64_t)ptr;
     v4i_t r;
