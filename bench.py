@@ -38,10 +38,16 @@ STEP_GFLOP_PER_SAMPLE = {"ResNet50": 32.766, "ResNet18": 14.512}     # key fwd +
 FWD_GFLOP_PER_FRAME = {"ResNet50": 8.2000, "ResNet18": 3.6282}
 TRUNK_GFLOP_PER_FRAME = {"ResNet50": 8.1743, "ResNet18": 3.6271}      # conv MACs x 2 per image
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}                          # MI355X_MICROARCH.md dense MFMA peaks
-# one tag per kernel symbol (as rocprofv3 lists them): conv_igemm_dlds_kernel<T, CT, 4, STAGES, MINW, PTL, BWD>
-KERNEL_TAGS = ["conv_igemm<%s,%s,%s>" % (t, shape, e) for t in ("f32", "bf16")
+# One tag per kernel family, in the library's order (csrc/common.h VINCE_TAG_*).  bound "mfma": the profiler's `work` is algorithmic
+# FLOPs and the roof is the dense MFMA peak of the dtype; bound "hbm": `work` is algorithmic BYTES and the roof is 8 TB/s.
+KERNEL_TAGS = [("conv_igemm<%s,%s,%s>" % (t, shape, e), "mfma", t) for t in ("f32", "bf16")
                for shape in ("64ch x 128px", "64ch x 256px", "128ch x 128px", "128ch x 256px") for e in ("fwd", "bwd")] + \
-              ["conv_wgrad<f32>", "conv_wgrad<bf16>"]
+              [("conv_wgrad<f32>", "mfma", "f32"), ("conv_wgrad<bf16>", "mfma", "bf16"),
+               ("conv_m8<bf16,256ch x 256px,fwd>", "mfma", "bf16"), ("conv_m8<bf16,256ch x 256px,bwd>", "mfma", "bf16"),
+               ("conv_xjoin<join>", "hbm", None), ("conv_xjoin<stats>", "hbm", None), ("conv_xjoin<dgrad>", "hbm", None),
+               ("conv3x3_strip", "mfma", "bf16"), ("bn_apply", "hbm", None), ("bn_bwd_apply", "hbm", None),
+               ("bn_bwd_reduce", "hbm", None), ("stem_pool_fwd", "hbm", None), ("stem_bwd", "hbm", None)]
+HBM_PEAK_GBS = 8000.0
 
 
 class PooledFrames:
@@ -76,6 +82,17 @@ def cpu_baseline(arch, embed, K, T, hw, batch, steps):
         tr.step(data, qdata)
     dt = time.time() - t0
     return 2.0 * batch * steps / dt
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or "unknown"
 
 
 def kernel_source_hash():
@@ -151,6 +168,8 @@ def main():
     ap.add_argument("--fp32-steps", type=int, default=5,
                     help="extra leg: the same step with an fp32 trunk (the precision the reference's own config-3 script runs, "
                          "vince/train_moco_v2.sh:40 has --use-apex commented out); 0 = skip")
+    ap.add_argument("--config-steps", type=int, default=5,
+                    help="extra legs c2_step / c5_step (BASELINE configs 2 and 5 on this GPU), steps each; 0 = skip")
     ap.add_argument("--mode", default="moco", choices=["moco", "vince"],
                     help="moco: BASELINE config 3 (the headline); vince: config 5's per-GPU work -- 4 frames per clip, inter-batch + "
                          "self-batch comparison (self T 0.03) and the jigsaw head on one side per step")
@@ -284,7 +303,27 @@ def main():
         tfwd = (time.perf_counter() - tf0) / nf
         fwd_tflops = FWD_GFLOP_PER_FRAME.get(opt.backbone, 0.0) * opt.batch / 1000.0 / tfwd
         out["fwd_infonce"] = {"frames_per_s_per_gpu": round(opt.batch / tfwd, 1), "ms": round(tfwd * 1000, 3),
-                              "tflops": round(fwd_tflops, 1), "mfma_frac": round(fwd_tflops / PEAK_TFLOPS[opt.dtype], 4)}
+                              "tflops": round(fwd_tflops, 1), "mfma_frac": round(fwd_tflops / PEAK_TFLOPS[opt.dtype], 4),
+                              "what": "torch.no_grad() forward (the key encoder's path: nothing saved for backward)"}
+
+        # the same forward with autograd recording: the query encoder's path inside the training step (saves what backward reads)
+        def fwd_grad_once():
+            o = solver.model.get_embeddings(batch_fwd)[0]
+            o.update(dict(queue_embeddings=keys, queue_vectors=kq, data_source="SYN", num_frames=1))
+            o = solver.model(o)
+            return solver.model.loss(o)["nce_loss"][1]
+
+        for _ in range(2):
+            fwd_grad_once()
+        barrier()
+        tg0 = time.perf_counter()
+        for _ in range(nf):
+            fwd_grad_once()
+        barrier()
+        tgrad = (time.perf_counter() - tg0) / nf
+        g_tflops = FWD_GFLOP_PER_FRAME.get(opt.backbone, 0.0) * opt.batch / 1000.0 / tgrad
+        out["fwd_infonce"]["grad_enabled"] = {"ms": round(tgrad * 1000, 3), "tflops": round(g_tflops, 1),
+                                              "mfma_frac": round(g_tflops / PEAK_TFLOPS[opt.dtype], 4)}
 
         # ---- inference: eval-mode extract_features, BatchNorms folded into the convolutions -----------------
         solver.model.eval()
@@ -350,43 +389,61 @@ def main():
         ms, fl, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_int64 * n)()
         L.vince_profile_collect(n, ms, fl, cnt)
         kernels = {}
-        for i, name in enumerate(KERNEL_TAGS):
+        for i, (name, bound, kdt) in enumerate(KERNEL_TAGS):
             if cnt[i]:
-                kernels[name] = {"launches_per_step": cnt[i] // opt.profile_steps, "avg_us": round(1000.0 * ms[i] / cnt[i], 2),
-                                 "ms_per_step": round(ms[i] / opt.profile_steps, 3),
-                                 "tflops": round(fl[i] / (ms[i] * 1e-3) / 1e12, 1)}
+                rate = fl[i] / (ms[i] * 1e-3)
+                k = {"launches_per_step": cnt[i] // opt.profile_steps, "avg_us": round(1000.0 * ms[i] / cnt[i], 2),
+                     "ms_per_step": round(ms[i] / opt.profile_steps, 3), "bound": bound}
+                if bound == "mfma":
+                    k["tflops"] = round(rate / 1e12, 1)
+                    k["frac"] = round(rate / 1e12 / PEAK_TFLOPS["fp32" if kdt == "f32" else "bf16"], 4)
+                else:
+                    k["gbs"] = round(rate / 1e9, 1)
+                    k["frac"] = round(rate / 1e9 / HBM_PEAK_GBS, 4)
+                kernels[name] = k
+        # the dominant kernel = the family with the most time per step, whatever it is, held against the roof that binds it
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
-        convs = [k for k in kernels if k.startswith("conv_igemm")]
-        dom_conv = max(convs, key=lambda k: kernels[k]["ms_per_step"]) if convs else None
-        if dom_conv in kernels:
-            k = kernels[dom_conv]
+        pm = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_conv_igemm.json")) as fh:
+                pm = json.load(fh)
+        except Exception:
+            pass
+        if dom:
+            k = kernels[dom]
             # HBM bytes per launch of that kernel from rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note in
-            # MI355X_MICROARCH.md, + WRITE_SIZE), recorded by tools/rocpd_pmc.py into profiles/ -- bench.py cannot run
+            # MI355X_MICROARCH.md, + WRITE_SIZE), recorded by tools/pmc_summary.py into profiles/ -- bench.py cannot run
             # the counter passes itself
             traffic = traffic_source = traffic_stamp = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_conv_igemm.json")) as fh:
-                    pm = json.load(fh)
-                traffic = pm["kernels"][dom_conv]["bytes_per_launch"]      # HBM bytes per launch of that kernel
-                traffic_source = pm["source"]
+            if pm:
+                traffic = pm.get("kernels", {}).get(dom, {}).get("bytes_per_launch")
+                traffic_source = pm.get("source")
                 # the PMC passes are a separate rocprofv3 run: the file says which kernel sources it was taken from, and a
                 # mismatch with what is built now is reported instead of silently quoting a stale number
                 traffic_stamp = {"kernel_source_hash": pm.get("kernel_source_hash"), "git_head": pm.get("git_head"),
                                  "stale": pm.get("kernel_source_hash") != kernel_source_hash()}
                 if pm.get("step"):
                     # whole-step HBM view: the step as a whole is bandwidth-bound
-                    out["step_hbm"] = {"bytes_per_step": pm["step"]["bytes"], "unit": "GB/s", "peak": 8000.0,
+                    out["step_hbm"] = {"bytes_per_step": pm["step"]["bytes"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                        "achieved": round(pm["step"]["bytes"] / (out["ms_per_step"] * 1e-3) / 1e9, 1),
                                        "frac": round(pm["step"]["bytes"] / (out["ms_per_step"] * 1e-3) / 8e12, 4),
                                        "source": pm["source"]}
-            except Exception:
-                pass
-            out["roofline"] = {"bound": "mfma", "kernel": dom_conv, "achieved": k["tflops"], "peak": PEAK_TFLOPS[opt.dtype],
-                               "unit": "TFLOP/s", "frac": round(k["tflops"] / PEAK_TFLOPS[opt.dtype], 4), "traffic": traffic,
-                               "traffic_unit": "bytes/launch", "traffic_source": traffic_source,
-                               "flops_per_launch": round(k["tflops"] * 1e12 * k["avg_us"] * 1e-6),
-                               "avg_us": k["avg_us"], "launches_per_step": k["launches_per_step"],
-                               "ms_per_step": k["ms_per_step"], "longest_kernel_family": dom}
+            per_launch = fl[[t[0] for t in KERNEL_TAGS].index(dom)] / max(1, cnt[[t[0] for t in KERNEL_TAGS].index(dom)])
+            if k["bound"] == "mfma":
+                out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": k["tflops"], "peak": PEAK_TFLOPS[opt.dtype],
+                                   "unit": "TFLOP/s", "frac": k["frac"], "flops_per_launch": round(per_launch)}
+            else:
+                out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": k["frac"], "algorithmic_bytes_per_launch": round(per_launch)}
+            out["roofline"].update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_source,
+                                    "avg_us": k["avg_us"], "launches_per_step": k["launches_per_step"],
+                                    "ms_per_step": k["ms_per_step"],
+                                    "chosen_by": "largest ms/step over all instrumented kernel families (see `kernels`)"})
+            # the largest matrix-core family beside it, when the dominant family is a streaming one (and vice versa)
+            other = [kk for kk in kernels if kernels[kk]["bound"] != k["bound"]]
+            if other:
+                o = max(other, key=lambda kk: kernels[kk]["ms_per_step"])
+                out["roofline"]["largest_%s_family" % kernels[o]["bound"]] = dict(kernel=o, **kernels[o])
             if traffic_stamp is not None:
                 out["roofline"]["traffic_stale"] = bool(traffic_stamp["stale"])
                 out["roofline"]["traffic_taken_from"] = {k2: traffic_stamp[k2] for k2 in ("git_head", "kernel_source_hash")}
@@ -398,39 +455,74 @@ def main():
             except Exception as e:
                 out["roofline"]["hbm_achievable"] = {"error": repr(e)}
             if traffic:
-                # the same kernel against the HBM roof ("HBM is the secondary bound and must be reported
-                # alongside"): measured bytes per launch / measured duration
+                # the same kernel's MEASURED bytes against the HBM roof ("HBM is the secondary bound and must be
+                # reported alongside"): PMC bytes per launch / measured duration
                 gbs = traffic / (k["avg_us"] * 1e-6) / 1e9
-                out["roofline"]["hbm"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
+                out["roofline"]["hbm"] = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
                 ach = out["roofline"].get("hbm_achievable", {}).get("value")
                 if ach:
                     out["roofline"]["hbm"]["frac_of_achievable"] = round(gbs / ach, 4)
+        out["instrumented_ms_per_step"] = round(sum(kk["ms_per_step"] for kk in kernels.values()), 3)
         out["kernels"] = kernels
-        # ---- fp32 leg: the reference's own config-3 script runs fp32 (train_moco_v2.sh:40); same step, fp32 trunk ------------
+        # ---- extra step legs (a few steps each; every single-GPU BASELINE configuration gets a driver-observed number) --------
+        #   fp32_step: config 3 with an fp32 trunk -- the precision the reference's own config-3 script runs
+        #              (vince/train_moco_v2.sh:40 has --use-apex commented out) and the mode that meets the 1e-3 embedding bar
+        #   c2_step:   BASELINE config 2 (ResNet-18, fp32, B=256, K=4096, D=64, T=0.07)
+        #   c5_step:   BASELINE config 5's per-GPU work (4 frames per clip, inter-batch + self-batch comparison, jigsaw side)
+        def step_leg(steps, frames=1, gflop_backbone=None, **over):
+            nonlocal solver
+            solver = None
+            torch.cuda.empty_cache()
+            base = {k_: getattr(args, k_) for k_ in vars(args)}
+            bsz = over.get("batch_size", base["batch_size"])
+            base["batch_source"] = PooledFrames(bsz, opt.size, opt.size, frames, device, pool=2, rank=rank, world=world)
+            base.update(over)
+            a2 = make_args(**base)
+            with contextlib.redirect_stdout(sys.stderr):
+                s2 = VinceSolver(a2)
+                s2.reset_epoch()
+            for _ in range(2):
+                s2.run_train_iteration()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(steps):
+                s2.run_train_iteration()
+            barrier()
+            t2 = (time.perf_counter() - t2) / steps
+            dt_name = over.get("compute_dtype", base["compute_dtype"])
+            leg = {"frames_per_s_per_gpu": round(2.0 * bsz / t2, 1), "ms_per_step": round(t2 * 1000, 3), "steps": steps,
+                   "dtype": dt_name}
+            gf = STEP_GFLOP_PER_SAMPLE.get(gflop_backbone) if gflop_backbone else None
+            if gf:
+                tfl = gf * bsz / 1000.0 / t2
+                leg.update({"tflops": round(tfl, 1), "mfma_frac": round(tfl / PEAK_TFLOPS[dt_name], 4)})
+            del s2
+            torch.cuda.empty_cache()
+            return leg
+
+        is_c3 = opt.mode == "moco" and opt.input == "float"
         if opt.fp32_steps > 0 and opt.dtype != "fp32":
             try:
-                del solver
-                torch.cuda.empty_cache()
-                args32 = make_args(**{**{k_: getattr(args, k_) for k_ in vars(args)}, "compute_dtype": "fp32"})
-                with contextlib.redirect_stdout(sys.stderr):
-                    s32 = VinceSolver(args32)
-                    s32.reset_epoch()
-                for _ in range(2):
-                    s32.run_train_iteration()
-                barrier()
-                t32 = time.perf_counter()
-                for _ in range(opt.fp32_steps):
-                    s32.run_train_iteration()
-                barrier()
-                t32 = (time.perf_counter() - t32) / opt.fp32_steps
-                tf32 = step_tflop / t32
-                out["fp32_step"] = {"frames_per_s_per_gpu": round(2.0 * opt.batch / t32, 1), "ms_per_step": round(t32 * 1000, 3),
-                                    "steps": opt.fp32_steps, "tflops": round(tf32, 1),
-                                    "mfma_frac": round(tf32 / PEAK_TFLOPS["fp32"], 4), "dtype": "fp32"}
-                del s32
-                torch.cuda.empty_cache()
+                out["fp32_step"] = step_leg(opt.fp32_steps, gflop_backbone=opt.backbone, compute_dtype="fp32")
             except Exception as e:
                 out["fp32_step"] = {"error": repr(e)}
+        if opt.config_steps > 0 and is_c3:
+            try:
+                out["c2_step"] = dict(step_leg(opt.config_steps, gflop_backbone="ResNet18", backbone="ResNet18", compute_dtype="fp32",
+                                               vince_queue_size=4096, vince_embedding_size=64, vince_temperature=0.07),
+                                      workload="BASELINE config 2: ResNet18 %dx%d, B=%d, K=4096, D=64, T=0.07, fp32 trunk"
+                                               % (opt.size, opt.size, opt.batch))
+            except Exception as e:
+                out["c2_step"] = {"error": repr(e)}
+            try:
+                random.seed(1234 + rank)
+                out["c5_step"] = dict(step_leg(opt.config_steps, frames=4, num_frames=4, inter_batch_comparison=True,
+                                               self_batch_comparison=True, jigsaw=True, vince_self_temperature=0.03),
+                                      workload="BASELINE config 5 per-GPU work: %s %dx%d, B=%d clips x 4 frames, K=%d, inter-batch + "
+                                               "self-batch comparison, jigsaw side by a seeded coin, %s trunk"
+                                               % (opt.backbone, opt.size, opt.size, opt.batch, opt.queue, opt.dtype))
+            except Exception as e:
+                out["c5_step"] = {"error": repr(e)}
         # ---- cpu_baseline leg ----------------------------------------------------------------------------------------
         try:
             if opt.cpu_steps <= 0:
@@ -439,6 +531,7 @@ def main():
             cb, csteps = 16, opt.cpu_steps
             v = cpu_baseline(opt.backbone, opt.embed, opt.queue, opt.temperature, opt.size, cb, csteps)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+                                   "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(),
                                    "sample": "CPU oracle (torch-CPU restatement pinned to the reference), %s %dx%d, "
                                              "B=%d, K=%d, %d full training steps after 1 warm-up"
                                              % (opt.backbone, opt.size, opt.size, cb, opt.queue, csteps)}

@@ -386,6 +386,10 @@ int vince_l2norm_bwd(const float* x, const float* norms, const float* dout, floa
                      float eps, void* stream);
 int vince_relu_bwd(const float* dout, const float* act, float* dx, int64_t n, void* stream);
 int vince_colsum(const float* x, float* out, int32_t rows, int32_t cols, void* stream); /* out[c] += sum_r x[r][c] */
+/* The reference asserts torch.isfinite(total_loss) on EVERY iteration (solvers/vince_solver.py:446-452), a host sync per step.
+ * Here the check stays on the device: latch[0] += 1 and latch[1] = step + 1 (first offender only) when *value is NaN or +-inf.
+ * The caller zeroes latch (int64[2]) once, enqueues this every step and reads the latch whenever it synchronises anyway. */
+int vince_nonfinite_latch(const float* value, int64_t step, int64_t* latch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused similarity + InfoNCE + metrics (K10-K14; vince_model.py:198-349, utils/loss_util.py:7-62)

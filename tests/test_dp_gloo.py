@@ -192,6 +192,31 @@ def _save_case(rank, world):
     return calls
 
 
+def _final_save_case(rank, world):
+    """One rank on the exception path of a driver's `finally: solver.save()`, its peer still inside a collective: the final save must
+    not hold a barrier.  Rank 1 'fails' and saves at once; rank 0 first finishes an all-reduce that rank 1 also joins
+    AFTER its save -- with a barrier inside save() the two collectives would be mismatched and this would hang until the timeout."""
+    import torch
+    import torch.distributed as dist
+    from vince_amd.solvers.vince_solver import VinceSolver
+    calls = []
+    model = types.SimpleNamespace(save=lambda it, keep: calls.append((it, keep)))
+    stub = types.SimpleNamespace(model=model, iteration=7)
+    t = torch.ones(4)
+    if rank == 1:
+        VinceSolver.save(stub)          # the failing rank's `finally`
+        dist.all_reduce(t)
+    else:
+        dist.all_reduce(t)              # the healthy rank is in its gradient all-reduce
+        VinceSolver.save(stub)
+    return calls, float(t[0])
+
+
+def test_final_save_holds_no_collective():
+    out = run2(_final_save_case)
+    assert out[0] == ([(7, -1)], 2.0) and out[1] == ([], 2.0)
+
+
 def test_only_rank_zero_writes_checkpoints():
     out = run2(_save_case)
     assert out[0] == [(512, 5)] and out[1] == []

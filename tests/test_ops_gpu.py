@@ -869,3 +869,19 @@ def test_conv_expand_dgrad_streaming_kernel(rows, K, Co, mode):
         xhat = (ylo.double() - mean.double()) * invstd.double()
         np.testing.assert_allclose(a[1][:, 0].cpu().numpy(), gg.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
         np.testing.assert_allclose(a[1][:, 1].cpu().numpy(), (gg * xhat).sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3)
+
+
+def test_nonfinite_loss_latch():
+    """The per-iteration finite-loss assertion of the reference (solvers/vince_solver.py:446-452) as a device-side latch: finite
+    values leave it alone, NaN / +-inf count and keep the FIRST offending step."""
+    ops = _ops()
+    latch = torch.zeros(2, dtype=torch.int64, device=DEV)
+    for step, v in enumerate([1.5, -3.0e38, 0.0, float("inf"), 2.0, float("nan"), float("-inf")]):
+        ops.nonfinite_latch(torch.tensor([v], device=DEV), step, latch)
+    assert latch.tolist() == [3, 3 + 1]
+    from vince_amd.solvers.vince_solver import VinceSolver
+    import types
+    stub = types.SimpleNamespace(_loss_latch=latch)
+    with pytest.raises(AssertionError, match="first at iteration 3"):
+        VinceSolver.check_loss_latch(stub)
+    VinceSolver.check_loss_latch(types.SimpleNamespace(_loss_latch=torch.zeros(2, dtype=torch.int64, device=DEV)))

@@ -8,6 +8,27 @@ import sys
 
 
 def tag_of(name):
+    # families without a tile-shape split: bench.py's KERNEL_TAGS names
+    m8 = re.search(r"conv_m8_kernel(?:ILi|<)([012])", name)
+    if m8:
+        return "conv_m8<bf16,256ch x 256px,%s>" % ("bwd" if m8.group(1) == "1" else "fwd")
+    xj = re.search(r"conv_xjoin_kernel(?:ILi\d+ELi\d+ELb([01])ELb([01])ELb([01])ELb([01])E|<\d+, \d+, (true|false), (true|false), (true|false), (true|false)>)", name)
+    if xj:
+        g = [v for v in xj.groups() if v is not None]
+        plain, dgrad = g[2] in ("1", "true"), g[3] in ("1", "true")
+        return "conv_xjoin<dgrad>" if dgrad else ("conv_xjoin<stats>" if plain else "conv_xjoin<join>")
+    if "conv3x3_strip_kernel" in name:
+        return "conv3x3_strip"
+    if "bn_bwd_apply_kernel" in name:
+        return "bn_bwd_apply"
+    if "bn_bwd_reduce_kernel" in name:
+        return "bn_bwd_reduce"
+    if "bn_apply_kernel" in name:
+        return "bn_apply"
+    if "stem_pool_fwd_kernel" in name:
+        return "stem_pool_fwd"
+    if "stem_bwd_kernel" in name or "stem_pool_bwd_kernel" in name:
+        return "stem_bwd"
     m = re.search(r"conv_igemm_dlds_kernelI([tf])Li(\d+)ELi\d+ELi\d+ELi\d+ELi(\d+)EL[bi]([012])E", name)
     if not m:
         m2 = re.search(r"conv_igemm_dlds_kernel<(unsigned short|float), (\d+), \d+, \d+, \d+, (\d+), (true|false|0|1|2)[,>]", name)

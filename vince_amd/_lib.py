@@ -109,6 +109,7 @@ PROTOTYPES = {
     "vince_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "vince_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vince_colsum": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "vince_nonfinite_latch": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "vince_infonce_workspace_bytes": (c_size_t, [P(InfoNCEDesc)]),
     "vince_infonce_fwd": (c_int, [P(InfoNCEDesc)] + [c_void_p] * 11),
     "vince_infonce_bwd": (c_int, [P(InfoNCEDesc)] + [c_void_p] * 10),

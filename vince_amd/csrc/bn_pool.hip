@@ -834,6 +834,7 @@ inline int grid_for(int64_t total_threads) {
 
 #define DTYPE_OK(fn) VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, fn ": bad dtype %d", dtype)
 #define CH_OF(dtype) ((dtype) == VINCE_F32 ? 4 : 8)
+#define ESZ_OF(dtype) ((dtype) == VINCE_F32 ? 4 : 2)
 
 extern "C" int vince_bn_finalize(const double* stats, int64_t count, int32_t C, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
@@ -857,6 +858,7 @@ extern "C" int vince_bn_apply(int dtype, const void* y, const float* scale, cons
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_target_blocks());
     dim3 grid(w.colgroups, w.rowblocks);
+    VinceProfScope prof(VINCE_TAG_BN_APPLY, (double)rows * C * ESZ_OF(dtype) * (identity ? 3 : 2) + (mask_out ? (double)rows * C / CH_OF(dtype) : 0), stream);
     vince_bn_train fin;
     memset(&fin, 0, sizeof(fin));
     if (dtype == VINCE_F32)
@@ -882,6 +884,7 @@ extern "C" int vince_bn_train_apply(int dtype, const void* y, const vince_bn_tra
     if (fin.replicas <= 0 || fin.replicas > VINCE_STATS_REPLICAS) fin.replicas = VINCE_STATS_REPLICAS;
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_target_blocks());
     dim3 grid(w.colgroups, w.rowblocks);
+    VinceProfScope prof(VINCE_TAG_BN_APPLY, (double)rows * C * ESZ_OF(dtype) * (identity ? 3 : 2) + (mask_out ? (double)rows * C / CH_OF(dtype) : 0), stream);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, nullptr, nullptr,
                            (const float*)identity, id_scale, id_shift, (float*)out, mask_out, rows, C, relu, w, fin);
@@ -926,6 +929,7 @@ extern "C" int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_s
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_bwd_reduce: C=%d not a multiple of %d", C, CH_OF(dtype));
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 2048);
     dim3 grid(w.colgroups, w.rowblocks);
+    VinceProfScope prof(VINCE_TAG_BN_BWD_REDUCE, (double)rows * C * ESZ_OF(dtype) * 2, stream);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
                            msk, (const float*)y, mean, invstd, sums, rows, C, w, replicas);
@@ -957,6 +961,8 @@ extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_sr
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_bwd_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_bwd_target_blocks());
     dim3 grid(w.colgroups, w.rowblocks);
+    VinceProfScope prof(VINCE_TAG_BN_BWD_APPLY, (double)rows * C * ESZ_OF(dtype) * (3 + (g_out ? 1 : 0) + (r2.y ? 1 : 0)) +
+                        (mask_bits ? (double)rows * C / CH_OF(dtype) : 0), stream);
     const double inv_count = 1.0 / (double)count;
 #define VINCE_BWD_APPLY(TT, RR)                                                                                          \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, RR>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)dz, msk,       \
@@ -977,6 +983,7 @@ extern "C" int vince_stem_pool_fwd(int dtype, const void* y, const float* scale,
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_stem_pool_fwd: C=%d not a multiple of %d", C, CH_OF(dtype));
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t total = (int64_t)N * Ho * Wo * (C / CH_OF(dtype));
+    VinceProfScope prof(VINCE_TAG_STEM_POOL, ((double)N * H * W + (double)N * Ho * Wo) * C * ESZ_OF(dtype) + (double)total, stream);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(stem_pool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)y, scale, shift, (float*)out, argmax, N, H, W, C, Ho, Wo);
@@ -994,6 +1001,7 @@ extern "C" int vince_stem_pool_bwd(int dtype, const void* dpool, const uint8_t* 
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_stem_pool_bwd: C=%d not a multiple of %d", C, CH_OF(dtype));
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / CH_OF(dtype));   // one thread per 2x2 pixel block
+    VinceProfScope prof(VINCE_TAG_STEM_BWD, ((double)N * H * W + (double)N * Ho * Wo) * C * ESZ_OF(dtype), stream);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(stem_pool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)dpool, argmax, (float*)g, N, H, W, C, Ho, Wo);
@@ -1014,6 +1022,7 @@ extern "C" int vince_stem_bwd_reduce(int dtype, const void* dpool, const uint8_t
     VINCE_CHECK_ARG(C % CH == 0 && 256 % (C / CH) == 0, VINCE_E_SHAPE, "vince_stem_bwd_reduce: C=%d unsupported", C);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / CH);
+    VinceProfScope prof(VINCE_TAG_STEM_BWD, ((double)N * H * W + 0.25 * N * H * W) * C * ESZ_OF(dtype), stream);   // reads y and the pooled gradient
     const int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL((stem_bwd_kernel<float, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dpool,
@@ -1035,6 +1044,7 @@ extern "C" int vince_stem_bwd_apply(int dtype, const void* dpool, const uint8_t*
     VINCE_CHECK_ARG(C % CH == 0 && 256 % (C / CH) == 0, VINCE_E_SHAPE, "vince_stem_bwd_apply: C=%d unsupported", C);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / CH);
+    VinceProfScope prof(VINCE_TAG_STEM_BWD, (2.0 * N * H * W + 0.25 * N * H * W) * C * ESZ_OF(dtype), stream);   // + writes dy
     const double inv_count = 1.0 / ((double)N * H * W);
     hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, dgamma, dbeta);
     if (dtype == VINCE_F32)

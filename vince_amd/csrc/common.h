@@ -31,6 +31,34 @@ int vince_zero_async(void* ptr, size_t bytes, void* stream);
 int vince_fill_f32_async(float* ptr, int n, float value, void* stream);   // small constant vectors (misc.hip)
 void vince_profile_set_dims(void* token, int a, int b, int c, int d, int e, int f);
 
+// Profile tags (vince_profile_enable: one hipEvent pair per launch, streams serialised by the caller).  `work` is algorithmic FLOPs for
+// the matrix kernels and algorithmic BYTES for the streaming ones; bench.py holds the same table with the roof of each family.
+enum {
+    VINCE_TAG_CONV_IGEMM0 = 0,      // 0..15: conv_igemm [dtype][tile shape][fwd|bwd epilogue]
+    VINCE_TAG_WGRAD_F32 = 16, VINCE_TAG_WGRAD_BF16 = 17,
+    VINCE_TAG_M8_FWD = 18, VINCE_TAG_M8_BWD = 19,
+    VINCE_TAG_XJOIN = 20,           // conv_xjoin: expand + BatchNorm + join (bytes)
+    VINCE_TAG_XSTATS = 21,          // conv_xjoin: expand + statistics (bytes)
+    VINCE_TAG_XDGRAD = 22,          // conv_xjoin: block-input gradient (bytes)
+    VINCE_TAG_STRIP = 23,           // conv3x3_strip (FLOPs)
+    VINCE_TAG_BN_APPLY = 24,        // bn_apply / bn_train_apply (bytes)
+    VINCE_TAG_BN_BWD_APPLY = 25,    // bn_bwd_apply (bytes)
+    VINCE_TAG_BN_BWD_REDUCE = 26,   // bn_bwd_reduce (bytes)
+    VINCE_TAG_STEM_POOL = 27,       // stem_pool_fwd (bytes)
+    VINCE_TAG_STEM_BWD = 28,        // stem_bwd_reduce / stem_bwd_apply / stem_pool_bwd (bytes)
+    VINCE_TAG_COUNT = 29
+};
+struct VinceProfScope {   // brackets the launches an entry point enqueues between construction and return
+    void* tok = nullptr;
+    void* stream;
+    VinceProfScope(int tag, double work, void* s) : stream(s) {
+        if (vince_profile_enabled()) vince_profile_begin_launch(tag, work, s, &tok);
+    }
+    ~VinceProfScope() {
+        if (tok) vince_profile_end_launch(tok, stream);
+    }
+};
+
 #define VINCE_CHECK_ARG(cond, code, ...)   \
     do {                                   \
         if (!(cond)) {                     \

@@ -360,6 +360,7 @@ extern "C" int vince_conv3x3_strip(int dtype, const void* x, const void* w, int3
     static const int grid_env = getenv("VINCE_STRIP_GRID") ? atoi(getenv("VINCE_STRIP_GRID")) : 0;   // (tests: several images per workgroup)
     if (grid_env > 0) grid = grid_env;
     if (grid > N) grid = N;
+    VinceProfScope prof(VINCE_TAG_STRIP, 2.0 * N * H * W * Co * 9.0 * Ci, stream);
     hipLaunchKernelGGL(conv3x3_strip_kernel, dim3((unsigned)grid), dim3(XS_THREADS), 0, (hipStream_t)stream, p);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;

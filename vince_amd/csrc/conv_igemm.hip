@@ -778,7 +778,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
         rc = vince_conv_m8_launch(p, join ? 2 : (bwd ? 1 : 0), s);
     if (rc != -1) {
         if (tok) {
-            vince_profile_set_tag(tok, 18 + (bwd ? 1 : 0));
+            vince_profile_set_tag(tok, VINCE_TAG_M8_FWD + (bwd ? 1 : 0));
             vince_profile_end_launch(tok, stream);
         }
         return rc;

@@ -481,6 +481,7 @@ extern "C" int vince_conv_expand_stats(int dtype, const void* x, const void* w, 
     if (grid > items) grid = items;
     grid = grid / p.cgroups * p.cgroups;
     if (grid < p.cgroups) grid = p.cgroups;
+    VinceProfScope prof(VINCE_TAG_XSTATS, (double)rows * (K + Co) * 2, stream);
     if (K == 64)
         hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
     else
@@ -520,6 +521,8 @@ extern "C" int vince_conv_expand_dgrad(int dtype, const void* dy, const void* wt
     if (grid > items) grid = items;
     grid = grid / p.cgroups * p.cgroups;
     if (grid < p.cgroups) grid = p.cgroups;
+    VinceProfScope prof(VINCE_TAG_XDGRAD, (double)rows * 2 * (K + Co * (1 + (accumulate ? 1 : 0) + (p.br_y ? 1 : 0))) +
+                        (double)rows * Co / 8 * ((acc_mask ? 1 : 0) + (p.br_bits ? 1 : 0)), stream);
     if (K == 64)
         hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, false, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
     else
@@ -545,6 +548,7 @@ extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, i
     const unsigned long long xb = (unsigned long long)rows * K * 2, wb = (unsigned long long)Co * K * 2;
     VINCE_CHECK_ARG(xb < 0x7ff00000ull && rows < (1ll << 31), VINCE_E_UNSUPPORTED, "vince_conv_expand_join: input beyond the 31-bit buffer offsets");
     XjParams p;
+    memset(&p, 0, sizeof(p));
     p.x = x; p.w = w; p.identity = identity; p.out = out; p.y_raw = y_raw; p.mask_out = mask_out;
     p.out_scale = out_scale; p.out_shift = out_shift; p.id_scale = id_scale; p.id_shift = id_shift;
     p.rows = (uint32_t)rows; p.Co = (uint32_t)Co; p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
@@ -565,6 +569,7 @@ extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, i
         if (y_raw) { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, true); else VINCE_XJ_LAUNCH(KK, SS, false, true); }   \
         else { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, false); else VINCE_XJ_LAUNCH(KK, SS, false, false); }       \
     } while (0)
+    VinceProfScope prof(VINCE_TAG_XJOIN, (double)rows * 2 * (K + Co * (2 + (y_raw ? 1 : 0))) + (mask_out ? (double)rows * Co / 8 : 0), stream);
     if (K == 64) VINCE_XJ_PICK(64, 3); else VINCE_XJ_PICK(128, 2);
 #undef VINCE_XJ_PICK
 #undef VINCE_XJ_LAUNCH

@@ -461,6 +461,21 @@ extern "C" int vince_relu_bwd(const float* dout, const float* act, float* dx, in
     return VINCE_OK;
 }
 
+__global__ void nonfinite_latch_kernel(const float* value, long long step, long long* latch) {
+    const float v = *value;
+    if (!(fabsf(v) <= 3.402823466e38f)) {   // NaN compares false, +-inf exceeds FLT_MAX
+        latch[0] += 1;
+        if (latch[1] == 0) latch[1] = step + 1;
+    }
+}
+
+extern "C" int vince_nonfinite_latch(const float* value, int64_t step, int64_t* latch, void* stream) {
+    VINCE_CHECK_ARG(value && latch, VINCE_E_ARG, "vince_nonfinite_latch: null pointer");
+    hipLaunchKernelGGL(nonfinite_latch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, value, (long long)step, (long long*)latch);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
 extern "C" int vince_colsum(const float* x, float* out, int32_t rows, int32_t cols, void* stream) {
     VINCE_CHECK_ARG(x && out && rows > 0 && cols > 0, VINCE_E_ARG, "vince_colsum: bad arguments");
     hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, COLSUM_CHUNKS), dim3(256), 0, (hipStream_t)stream, x, out, rows, cols);

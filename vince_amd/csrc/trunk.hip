@@ -423,12 +423,15 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
     // stores, two channel groups re-reading the input): VINCE_XSTATS_MAX_K=128 to try, 0 = off.
     static const int xstats_max_k = getenv("VINCE_XSTATS_MAX_K") ? atoi(getenv("VINCE_XSTATS_MAX_K")) : 64;
     static const bool strip3x3 = !(getenv("VINCE_STRIP3X3") && atoi(getenv("VINCE_STRIP3X3")) == 0);
+    // (the streaming kernels address their input through one 31-bit buffer descriptor: larger tensors stay on vince_conv_igemm,
+    // whose register-staged kernels have no such limit)
+    const bool small_in = (unsigned long long)c.t->cfg.N * cv.Hi * cv.Wi * cv.Ci * 2 < 0x7ff00000ull;
     if (!desc && !xf_bn && train_bn && c.dtype == VINCE_BF16 && cv.k == 1 && cv.stride == 1 && cv.Ci <= xstats_max_k &&
-        (cv.Ci == 64 || cv.Ci == 128) && cv.Co % 256 == 0) {
+        (cv.Ci == 64 || cv.Ci == 128) && cv.Co % 256 == 0 && small_in) {
         RC(vince_conv_expand_stats(c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), (int64_t)c.t->cfg.N * cv.Ho * cv.Wo, cv.Ci,
                                    cv.Co, at(c.ws, y_off), e.stats, e.replicas, c.stream));
     } else if (strip3x3 && !desc && !xf_bn && c.dtype == VINCE_BF16 && cv.k == 3 && cv.stride == 1 && cv.Ci == 64 && cv.Co == 64 &&
-               cv.Wo == 56 && cv.Ho % 4 == 0 && cv.Hi == cv.Ho && cv.Wi == cv.Wo) {
+               cv.Wo == 56 && cv.Ho % 4 == 0 && cv.Hi == cv.Ho && cv.Wi == cv.Wo && small_in) {
         // layer1's 3x3 (conv2 of the 64-wide bottlenecks at 56 x 56): the image-strip kernel (csrc/conv3x3_strip.hip) -- input rows
         // resident in an LDS ring, each element fetched once in whole lines; bit-identical output and statistics
         RC(vince_conv3x3_strip(c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), c.t->cfg.N, cv.Ho, cv.Wo, cv.Ci, cv.Co, nullptr,
@@ -488,7 +491,8 @@ int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, co
     // again, through the persistent streaming kernel (299 vs 362 us, 306 vs 383 us, 177 vs 192 us).  VINCE_XDGRAD=0: off.
     static const bool xdgrad_env = !(getenv("VINCE_XDGRAD") && atoi(getenv("VINCE_XDGRAD")) == 0);
     if (xdgrad_env && accumulate && c.dtype == VINCE_BF16 && cv.k == 1 && cv.stride == 1 && (cv.Co == 64 || cv.Co == 128) &&
-        cv.Ci % 256 == 0 && !(bnred && bnred->mask_scale))
+        cv.Ci % 256 == 0 && !(bnred && bnred->mask_scale) &&
+        (unsigned long long)c.t->cfg.N * cv.Hi * cv.Wi * cv.Co * 2 < 0x7ff00000ull)
         return vince_conv_expand_dgrad(c.dtype, dy, at((void*)c.wcache, cv.wt), (int64_t)c.t->cfg.N * cv.Hi * cv.Wi, cv.Co, cv.Ci, dx, 1,
                                        acc_mask, bnred, replicas, c.stream);
     vince_conv_desc ds[4];
@@ -747,7 +751,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // (vince_bn_gram_finalize), so they are known BEFORE conv3 runs and its epilogue applies bn3 + identity + ReLU in place on
     // the identity tensor -- y3 is neither written nor re-read and conv3 carries no statistics epilogue (28 -> 21 tensor
     // passes per block).  Backward needs y3, so grad-enabled forwards keep the separate passes.  VINCE_GRAM_JOIN=0: off.
-    const bool gram_env = !(getenv("VINCE_GRAM_JOIN") && atoi(getenv("VINCE_GRAM_JOIN")) == 0);
+    static const bool gram_env = !(getenv("VINCE_GRAM_JOIN") && atoi(getenv("VINCE_GRAM_JOIN")) == 0);
     const bool gram_nograd = gram_env && train_bn && !save && !fuse_xf && !ds_side;
     // Grad-enabled forwards CAN take the same route where the streaming kernel applies (bf16, K = 64 / 128): it writes the block
     // output AND what backward reads -- conv3's raw output and the ReLU mask bytes -- so the join pass, its re-read of y3 and
@@ -766,7 +770,8 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
         const size_t x_in = cur;
         size_t in = x_in;
         const bool xj_ok = xjoin_env && c.dtype == VINCE_BF16 && b.nconv == 3 && (b.c[2].Ci == 64 || b.c[2].Ci == 128) &&
-                           b.c[2].Co % 256 == 0;
+                           b.c[2].Co % 256 == 0 &&
+                           (unsigned long long)t->cfg.N * b.c[2].Hi * b.c[2].Wi * b.c[2].Ci * 2 < 0x7ff00000ull;   // 31-bit descriptor offsets
         const bool gram_blk = b.gram != NONE && ((gram_nograd && bi + 1 < t->blocks.size()) || (gram_train && xj_ok));
         if (b.has_ds && ds_side) {
             Ctx cd = c;

@@ -203,6 +203,14 @@ def linear_fwd(x, weight, bias, relu=False):
     return out
 
 
+def nonfinite_latch(value, step, latch):
+    """Device-side stand-in for the reference's per-iteration `assert torch.isfinite(total_loss)` (solvers/vince_solver.py:446-452):
+    latch (int64[2], zeroed once) counts non-finite values and keeps the first offending step + 1; no host synchronisation."""
+    require_gpu(value, latch)
+    assert value.dtype == torch.float32 and value.numel() == 1 and latch.dtype == torch.int64 and latch.numel() == 2
+    check(lib().vince_nonfinite_latch(_ptr(value), int(step), _ptr(latch), stream_ptr()))
+
+
 def linear_bwd(x, weight_t, dy, dweight, dbias, need_dx=True):
     """dweight += dy.T @ x ; dbias += dy.sum(0) ; returns dx = dy @ weight (weight_t = weight.T contiguous)."""
     rows, cin = x.shape

@@ -86,7 +86,7 @@ def main(argv=None, train_logger=None, val_logger=None):
     finally:
         if args.save:
             print("Saving models")
-            solver.save()
+            solver.save()   # may run on one rank's exception path: the default save holds no collective (VinceSolver.save)
 
 
 if __name__ == "__main__":

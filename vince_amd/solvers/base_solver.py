@@ -118,7 +118,7 @@ class BaseSolver:
         for _ in tqdm.tqdm(range(num_iterations)):
             self.run_train_iteration()
 
-    def save(self, num_to_keep=-1):
+    def save(self, num_to_keep=-1, sync=False):
         self.model.save(self.iteration, num_to_keep)
 
 

@@ -20,7 +20,7 @@ from threading import Thread
 
 import torch
 
-from .. import constants, dp
+from .. import constants, dp, ops
 from ..data_source import SyntheticFrames
 from ..models.vince_model import U8Frames, VinceModel, VinceQueueModel
 from ..optim import FlatSGD
@@ -57,6 +57,7 @@ class VinceSolver(BaseSolver):
         self.drawn_this_epoch = False
         self.reducer = None
         self._dp_step = 0
+        self._loss_latch = None      # int64[2] on the device: (non-finite losses seen, first offending iteration + 1)
         self._key_stream = None
         self._jigsaw_rng = None
         self.overlap_key_encoder = bool(int(os.environ.get("VINCE_OVERLAP_KEY", "1")))
@@ -278,13 +279,17 @@ class VinceSolver(BaseSolver):
         mine = {"queue_embeddings": natural[r * B:(r + 1) * B].contiguous()}
         return [mine], natural
 
-    def save(self, num_to_keep=-1):
+    def save(self, num_to_keep=-1, sync=False):
         """Replicas are bit-identical, so only rank 0 writes (concurrent ranks would race on one file and on the pruning of
-        old checkpoints); the others wait so nobody runs ahead into a collective while rank 0 is still on the disk."""
+        old checkpoints).  sync=True (only the periodic save inside run_train_iteration, which every rank reaches at the same
+        iteration): the others wait so nobody runs ahead into a collective while rank 0 is still on the disk.  The default --
+        what a driver's `finally: solver.save()` gets (solver_runner.py:47-54 of the reference), possibly on an exception path
+        that only SOME ranks took -- is no collective at all: a rank that failed must not enter a barrier its peers answer with a
+        gradient all-reduce."""
         w, r = dp.world()
         if r == 0:
             self.model.save(self.iteration, num_to_keep)
-        if w > 1:
+        if w > 1 and sync:
             torch.distributed.barrier()
 
     def _jigsaw_coin(self):
@@ -300,6 +305,20 @@ class VinceSolver(BaseSolver):
         return self._jigsaw_rng.random()
 
     # ------------------------------------------------------------------------------------------ the hot loop
+    def _watch_loss(self, loss):
+        if self._loss_latch is None:
+            self._loss_latch = torch.zeros(2, dtype=torch.int64, device=loss.device)
+        ops.nonfinite_latch(loss.detach().float().reshape(1), self.iteration, self._loss_latch)
+
+    def check_loss_latch(self, context=None):
+        """Host side of the per-iteration finite-loss check: raises with the FIRST offending iteration (synchronises)."""
+        if self._loss_latch is None:
+            return
+        n, first = (int(v) for v in self._loss_latch.tolist())
+        if n:
+            raise AssertionError("non-finite loss in %d iteration(s), first at iteration %d%s"
+                                 % (n, first - 1, "" if context is None else " (now: %r)" % (context,)))
+
     def run_train_iteration(self):
         total_t_start = time.time()
         t_start = time.time()
@@ -361,12 +380,13 @@ class VinceSolver(BaseSolver):
             loss_dict = {k: v.mean() for k, v in stack_dicts_in_list(loss_list).items()}
             metrics = {k: v.mean() for k, v in stack_dicts_in_list(metrics_list).items()}
 
-        updated_loss_meters = set()
-        total_loss = 0
-        for key, weighted_loss in loss_dict.items():
-            total_loss = total_loss + weighted_loss
-            updated_loss_meters.add(key)
-        loss = total_loss
+        # what is optimised is the plain sum of the weighted terms; the meter names are the dict's keys (logging contract)
+        updated_loss_meters = set(loss_dict)
+        terms = list(loss_dict.values())
+        loss = terms[0] if len(terms) == 1 else torch.stack([t.reshape(()) for t in terms]).sum()
+        # every iteration, without a host sync: a NaN / inf loss latches the step index on the device (ops.nonfinite_latch); the
+        # latch is read wherever the host synchronises anyway (log iterations, save, end of epoch) and raises there
+        self._watch_loss(loss)
 
         t_end = time.time()
         self.time_meters["metrics_time"].update(t_end - t_start)
@@ -387,15 +407,14 @@ class VinceSolver(BaseSolver):
         self.queue_model.vince_update(self.model)
 
         if self.logger_iteration % self.args.save_frequency == 0:
-            self.save(5)
+            self.save(5, sync=True)
 
         if self.logger_iteration % self.args.log_frequency == 0:
             # the only host synchronisation of the step: scalar read-back for the meters (the reference's
             # assert torch.isfinite(loss), vince_solver.py:446, synchronises every step)
             vals = {k: float(v.detach()) for k, v in loss_dict.items()}
             total = sum(vals.values())
-            if not (total == total and abs(total) != float("inf")):
-                raise AssertionError("non-finite loss %r" % vals)
+            self.check_loss_latch(vals)
             for key, v in vals.items():
                 self.loss_meters[key].update(v)
             if "total_loss" in self.loss_meters:
