@@ -124,12 +124,6 @@ typedef struct vince_conv_epi {
                                * bits written by vince_bn_apply); bit e gates element e, so the residual join
                                * out = dgrad + out * (z > 0) (autograd of resnet.py:132-133) happens in place */
     vince_bn_reduce bnred;    /* excludes stats */
-    const float* in_scale;    /* optional operand transform: the INPUT tensor is read as relu(in * in_scale[ci] + in_shift[ci])
-                               * (float[Ci] each), applied to the staged tile in LDS -- zero padding stays zero.  This is
-                               * a BatchNorm-apply + ReLU fused into the consumer: the conv reads the producer's raw
-                               * output y and the activation tensor is never materialised (used by no-grad forwards).
-                               * Ci <= 512; direct-to-LDS kernels only */
-    const float* in_shift;
     int32_t replicas;         /* how many of the R replicas of `stats` / `bnred.sums` this launch spreads its atomics over
                                * (0 = all VINCE_STATS_REPLICAS); few workgroups need few replicas, and a consumer that
                                * folds them itself (vince_bn_train_apply, vince_bn_bwd_apply) then reads less */
@@ -140,6 +134,13 @@ typedef struct vince_conv_epi {
     const float* out_scale;
     const float* id_scale;
     const float* id_shift;
+    /* Gradient epilogues only (VINCE_EPI_ACCUMULATE or stats): one byte per 16-byte chunk of `out` (the ReLU bits of the block
+     * BELOW, as vince_bn_apply / vince_conv_expand_join write them) applied to the value being stored:
+     *   out = (dgrad + old) gated by out_mask
+     * i.e. the gradient leaves this launch already masked by the ReLU it flows into next (autograd of resnet.py:132-133), and
+     * `stats` then holds its per-channel sums -- what the BatchNorm-backward algebra of the block below needs
+     * (vince_bn3_bwd_prepare) instead of a pass over that block's conv output. */
+    const uint8_t* out_mask;
 } vince_conv_epi;
 
 /* in/w/out have element type `dtype`.  epi may be NULL (plain store). */
@@ -153,8 +154,9 @@ int vince_conv_igemm(const vince_conv_desc* d, int dtype, const void* in, const 
  * A persistent streaming kernel (csrc/conv_xjoin.hip): weights resident in LDS, input tiles by a loader wavefront, outputs
  * straight from the accumulators -- the HBM-bound replacement of vince_conv_igemm's join epilogue for layer1 / layer2.
  * Training forwards also pass y_raw (the convolution's own output rounded to bf16, [rows][Co] -- what BatchNorm backward
- * reads) and mask_out (one byte per 16-byte chunk of out, bit e = pre-ReLU value e > 0, as vince_bn_apply writes it); both or
- * neither, and then out must not alias identity. */
+ * reads) and mask_out (one byte per 16-byte chunk of out, bit e = pre-ReLU value e > 0, as vince_bn_apply writes it); with
+ * either, out must not alias identity.  mask_out alone (y_raw NULL) is the forward of the BatchNorm-backward algebra, which never
+ * reads the convolution's output again (vince_bn3_bwd_prepare). */
 int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                            const float* out_scale, const float* out_shift, const void* identity, const float* id_scale,
                            const float* id_shift, void* out, void* y_raw, uint8_t* mask_out, int relu, void* stream);
@@ -182,6 +184,12 @@ int vince_conv3x3_strip(int dtype, const void* x, const void* w, int32_t N, int3
  * (mask_scale / mask_shift are not supported here). */
 int vince_conv_expand_dgrad(int dtype, const void* dy, const void* wt, int64_t rows, int32_t K, int32_t Co, void* out,
                             int accumulate, const uint8_t* acc_mask, const vince_bn_reduce* bnred, int32_t replicas, void* stream);
+/* The same with the epilogue of the BatchNorm-backward algebra (vince_conv_epi.out_mask): out = (dgrad + old [gated by acc_mask])
+ * gated by out_mask, and gsums (double[replicas][Co][2], zeroed by the caller) += per-channel (sum, sum of squares) of the
+ * stored values.  No conv output of the block below is read. */
+int vince_conv_expand_dgrad_masked(int dtype, const void* dy, const void* wt, int64_t rows, int32_t K, int32_t Co, void* out,
+                                   int accumulate, const uint8_t* acc_mask, const uint8_t* out_mask, double* gsums,
+                                   int32_t replicas, void* stream);
 
 /* Weight gradient (wgrad) of the same generalised conv, reduction over output pixels:
  *   dw[co, wt(a,b), ci] += sum_{n,ho,wo} dy[n,ho,wo,co] * in[n, ho*sh+dh0+a*dhs, wo*sw+dw0+b*dws, ci]
@@ -242,6 +250,23 @@ int vince_bn_gram_finalize(int dtype, const float* gram, const double* colsum, i
                            const void* w, int32_t K, int32_t Co, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* scale,
                            float* shift, float* save_mean, float* save_invstd, void* stream);
+
+/* BatchNorm backward THROUGH a bottleneck's last 1x1 convolution, without that convolution's output (csrc/bn_algebra.hip; autograd of
+ * resnet.py:123-133 with BatchNorm2d in train mode).  y = W a is linear and pointwise, so with g = the gradient of the block output
+ * gated by its ReLU, R = g^T a (vince_conv_wgrad with dy := g) and the per-channel sums of g:
+ *   coef[4][Co] = s = gamma*invstd, c1 = mean g, c2 = mean g*xhat = invstd (<W[c,:], R[c,:]> - mean sum g) / count, t = s*c2*invstd
+ *   dgamma += count*c2, dbeta += count*c1
+ *   wd [K][Co] bf16 = W^T diag(s)          -- weights of the input-gradient launch   da  = wd g + nr   (bias nr)
+ *   nq [K][K]  bf16 = -W^T diag(t) W       -- weights of the correction launch       da += nq a
+ *   nr [K]     f32  = -sum_c W[c][k] (s c1 - t mean)
+ * w is the bf16 [Co][K] copy the forward multiplied with; gsums double[replicas][Co][2] (first of each pair = sum of g). K <= 128. */
+int vince_bn3_bwd_prepare(const float* R, const void* w_bf16, const double* gsums, int32_t replicas, const float* mean,
+                          const float* invstd, const float* gamma, int64_t count, int32_t Co, int32_t K, float* coef, void* wd,
+                          void* nq, float* nr, float* dgamma, float* dbeta, void* stream);
+/* ... and the weight gradient, in place of R:  dW = diag(s) (R - c1 A^T - diag(c2 invstd) (W G - mean A^T)),  G = a^T a (float[K][K], the
+ * Gram matrix the forward's statistics came from, vince_bn_gram_finalize), A = column sums of a (double[colsum_replicas][K]). */
+int vince_bn3_bwd_finish_dw(float* RdW, const void* w_bf16, const float* gram, const double* colsum, int32_t colsum_replicas,
+                            const float* coef, const float* mean, const float* invstd, int32_t Co, int32_t K, void* stream);
 
 /* out = [relu]( y*scale + shift + (identity ? (id_scale ? identity*id_scale + id_shift : identity) : 0) ).
  * mask_out (optional): one byte per 16-byte chunk of `out` (8 bf16 / 4 f32 channels), bit e = pre-ReLU value e > 0 --
@@ -477,8 +502,8 @@ int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* params, voi
 /* input: float NCHW (perm optional, see vince_input_nchw_to_nhwc) or, when input_is_tiles != 0, jigsaw source
  * (N/9 images [3][srcH][srcW]).  bn_buffers: per BN {running_mean, running_var} float pointers; nbt: int64 ptrs.
  * train_bn: batch statistics + running-stat update.  save != 0: everything vince_trunk_backward reads stays in the
- * workspace; save == 0 (no backward follows) lets the engine skip the bottleneck-internal activation tensors -- their
- * BatchNorm + ReLU is applied inside the consuming conv (vince_conv_epi.in_scale).
+ * workspace; save == 0 (no backward follows) lets the engine fuse what backward would have needed apart (the Gram-statistics
+ * residual join of the bottlenecks, in place on the block input).
  * Outputs: pooled float[N][C]; spatial (the trunk output, dtype NHWC) stays in the workspace:
  * vince_trunk_spatial_ptr(). */
 int vince_trunk_forward(vince_trunk_t t, const float* const* params, const void* wcache, float* const* bn_running,

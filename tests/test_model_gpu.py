@@ -594,27 +594,6 @@ def test_bucketed_allreduce_machinery_single_rank():
     assert rel(p2.cpu(), p0.cpu()) < 5e-3
 
 
-@pytest.mark.parametrize("arch,embed", [("ResNet18", 64), ("ResNet50", 128)])
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_nograd_forward_fuses_bn_into_consumers(arch, embed, dtype, monkeypatch):
-    """With VINCE_XF=1 (opt-in: measured slower in the full step) a no-grad train-mode forward (the key encoder's) never materialises the bottleneck-internal activations: their
-    BatchNorm + ReLU runs inside the consuming conv's operand path.  It must reproduce the grad-enabled forward of the same
-    model (which keeps the separate apply passes for backward) -- same batch statistics, same rounding of the activations --
-    up to the summation order of the statistics' atomics."""
-    _, model = build(arch, embed, dtype, 13)
-    model.train()
-    x = vo.structured_frames(6, 96, 96, seed=91).to(DEV) + 0.3 * vo.gaussian_frames(6, 96, 96, 92).to(DEV)
-    monkeypatch.setenv("VINCE_GRAM_JOIN", "0")   # (the Gram-statistics join rounds conv3's output differently; its own tests cover it)
-    monkeypatch.setenv("VINCE_XF", "1")
-    with torch.no_grad():
-        a = model.get_embeddings({"data": x})
-    monkeypatch.delenv("VINCE_XF")
-    b = model.get_embeddings({"data": x})
-    tol_ = 2e-5 if dtype == "fp32" else 2e-2
-    for k in ("extracted_features", "embeddings"):
-        assert rel(a[k].detach().cpu(), b[k].detach().cpu()) < tol_, (k, rel(a[k].detach().cpu(), b[k].detach().cpu()))
-
-
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_uint8_input_stage_equals_float_frames(dtype):
     """SURVEY 8(f)-3, deterministic part: raw uint8 HWC frames with per-frame crop windows and flips through the fused input
@@ -825,6 +804,47 @@ def test_gram_statistics_join_in_the_training_forward_equals_separate_passes(mon
         ratio = float(res["new"]["grads"][n].norm() / res["ref"]["grads"][n].norm())
         print("%-60s cos vs fp32: gram %.4f  separate %.4f  norm ratio %.3f" % (n, c_new, c_old, ratio))
         ratio_old = float(res["old"]["grads"][n].norm() / res["ref"]["grads"][n].norm())
+        assert 0.5 < ratio < 2.0 and abs(ratio / ratio_old - 1.0) < 0.3, (n, ratio, ratio_old)
+        if n.startswith("embedding") or "layer4" in n:
+            assert c_new > c_old - 0.05, (n, c_new, c_old)
+
+
+def test_bn3_backward_algebra_in_the_model_vs_separate_passes(monkeypatch):
+    """The default bf16 training route since round 3 (csrc/bn_algebra.hip; VINCE_BN3_ALGEBRA=0 restores the separate passes): layer1 /
+    layer2 bottlenecks run conv3 + bn3 + join in one streaming launch that does NOT store conv3's output, and backward gets bn3's
+    gradients through the convolution algebraically.  Same three-way comparison as the Gram-join test above: fp32 trunk as the reference,
+    the algebra route must sit as close to it as the separate passes do -- embeddings, gradient norms everywhere (incl. layer1 / layer2
+    conv3 / bn3 tensors, the ones the algebra produces), gradient direction where the bf16 / fp32 comparison is conditioned."""
+    names = ("feature_extractor.model.layer4.2.conv3.weight", "feature_extractor.model.layer2.1.conv3.weight",
+             "feature_extractor.model.layer2.1.bn3.weight", "feature_extractor.model.layer2.1.bn3.bias",
+             "feature_extractor.model.layer2.0.downsample.1.weight", "feature_extractor.model.layer2.2.conv2.weight",
+             "feature_extractor.model.layer1.0.conv3.weight", "feature_extractor.model.layer1.2.bn3.weight",
+             "feature_extractor.model.layer1.0.downsample.0.weight", "feature_extractor.model.layer1.1.bn2.bias",
+             "feature_extractor.model.conv1.weight", "embedding.2.weight")
+    res = {}
+    for tag, dtype, mode in (("ref", "fp32", "1"), ("new", "bf16", "1"), ("old", "bf16", "0")):
+        monkeypatch.setenv("VINCE_BN3_ALGEBRA", mode)
+        _, model = build("ResNet50", 128, dtype, 11)
+        model.train()
+        x = vo.structured_frames(16, 128, 128, seed=77).to(DEV)
+        o = model.get_embeddings({"data": x})
+        w = torch.randn(16, 128, generator=torch.Generator().manual_seed(3)).to(DEV)
+        model.zero_grad()
+        (o["embeddings"] * w).sum().backward()
+        named = dict(model.named_parameters())
+        res[tag] = {"emb": o["embeddings"].detach().float().cpu(),
+                    "grads": {n: named[n].grad.detach().float().cpu().clone() for n in names}}
+
+    def cos(a, b):
+        return float(torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0))
+    e_new, e_old = rel(res["new"]["emb"], res["ref"]["emb"]), rel(res["old"]["emb"], res["ref"]["emb"])
+    print("embeddings vs fp32: algebra %.3e  separate %.3e" % (e_new, e_old))
+    assert e_new < max(0.2, 1.5 * e_old)
+    for n in names:
+        c_new, c_old = cos(res["new"]["grads"][n], res["ref"]["grads"][n]), cos(res["old"]["grads"][n], res["ref"]["grads"][n])
+        ratio = float(res["new"]["grads"][n].norm() / res["ref"]["grads"][n].norm())
+        ratio_old = float(res["old"]["grads"][n].norm() / res["ref"]["grads"][n].norm())
+        print("%-60s cos vs fp32: algebra %.4f  separate %.4f  norm ratio %.3f / %.3f" % (n, c_new, c_old, ratio, ratio_old))
         assert 0.5 < ratio < 2.0 and abs(ratio / ratio_old - 1.0) < 0.3, (n, ratio, ratio_old)
         if n.startswith("embedding") or "layer4" in n:
             assert c_new > c_old - 0.05, (n, c_new, c_old)

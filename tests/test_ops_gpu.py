@@ -216,34 +216,6 @@ def test_conv_dgrad_wgrad(cfg, dtype):
         assert_close(dw, ref_dw, dtype, f32=1e-4, what="wgrad variant %d" % variant)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", CONVS + [(4, 20, 20, 128, 64, 3, 1, 1), (3, 12, 12, 512, 128, 1, 1, 0)])
-def test_conv_operand_transform(cfg, dtype):
-    """BatchNorm-apply + ReLU fused into the CONSUMER: conv(relu(x*scale + shift)) with the transform applied to the staged
-    tile in LDS must equal the conv of the materialised activation bit for bit (same rounding of the activation), including
-    zero padding of the ACTIVATION (not of x) at the borders and the fused output statistics."""
-    ops = _ops()
-    N, H, W, Ci, Co, k, s, p = cfg
-    x = q(rnd(N, Ci, H, W, seed=51), dtype)
-    w = q(rnd(Co, Ci, k, k, seed=52, scale=(2.0 / (Ci * k * k)) ** 0.5), dtype)
-    scale, shift = (rnd(Ci, seed=53).abs() + 0.5), rnd(Ci, seed=54, scale=0.5)
-    wk, _ = weights_krsc(w, dtype)
-    d = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
-    xg = to_nhwc(x, dtype)
-    act = ops.bn_apply(xg, scale.to(DEV), shift.to(DEV), relu=True)                   # the materialised activation
-    want = torch.empty(N, d.Ho, d.Wo, Co, device=DEV, dtype=dtype)
-    st_want = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
-    ops.conv_igemm(d, act, wk, want, stats=st_want)
-    got = torch.empty_like(want)
-    st_got = torch.zeros_like(st_want)
-    ops.conv_igemm(d, xg, wk, got, stats=st_got, in_scale=scale.to(DEV), in_shift=shift.to(DEV))
-    assert torch.equal(got, want)
-    torch.testing.assert_close(st_got.sum(0), st_want.sum(0), rtol=1e-9, atol=1e-6)
-    # and against torch on the CPU
-    ref = F.conv2d(F.relu(x * scale[None, :, None, None] + shift[None, :, None, None]), w, None, s, p)
-    assert_close(from_nhwc(got), ref, dtype, bf16=3e-2, what="conv with operand transform")
-
-
 def _random_conv_cases(n=14, seed=20260929):
     """Seeded shapes off the ResNet grid: odd images, batch tails, channel counts that do not fill a 64- or 128-wide tile,
     both kernel sizes and strides (multi-tap layers need Ci / 8 to be a power of two: vince_conv_igemm's documented limit)."""
@@ -316,7 +288,7 @@ def test_conv_suite_through_the_256_pixel_tiles():
     benchmark-sized pixel counts; their selection thresholds are read from the environment once per process, so the conv
     parity tests of this file are re-run in a child process that forces both onto every shape."""
     _rerun_conv_tests({"VINCE_BIG_MIN_K": "1", "VINCE_BIG_MIN_TILES": "1", "VINCE_NARROW256_MIN_TILES": "1"},
-                      "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem or test_conv_operand_transform")
+                      "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem")
 
 
 def test_conv_suite_through_the_rotated_main_loop():
@@ -885,3 +857,81 @@ def test_nonfinite_loss_latch():
     with pytest.raises(AssertionError, match="first at iteration 3"):
         VinceSolver.check_loss_latch(stub)
     VinceSolver.check_loss_latch(types.SimpleNamespace(_loss_latch=torch.zeros(2, dtype=torch.int64, device=DEV)))
+
+
+@pytest.mark.parametrize("w,rows", [(64, 3000), (128, 1111)])
+def test_bn3_backward_algebra_vs_autograd(w, rows):
+    """csrc/bn_algebra.hip: BatchNorm backward THROUGH a bottleneck's last 1x1 convolution without that convolution's output
+    (resnet.py:123-133).  Oracle: torch autograd in fp64 on the CPU of  z = relu(bn3(W a) + identity)  with the SAME bf16-valued W and a
+    (so the only differences are the bf16 rounding of the derived dgrad weights and of the stored input gradient).  Checked: the masked
+    gradient hand-off (out_mask + sums, both producers), dgamma / dbeta, the weight gradient, the input gradient."""
+    ops = _ops()
+    Co = 4 * w
+    g = torch.Generator().manual_seed(5 + w)
+    a = torch.relu(torch.randn(rows, w, generator=g) + 0.3).bfloat16().float()
+    W = (torch.randn(Co, w, generator=g) * (2.0 / w) ** 0.5).bfloat16().float()
+    gamma = torch.rand(Co, generator=g) + 0.5
+    beta = torch.randn(Co, generator=g) * 0.2
+    ident = torch.randn(rows, Co, generator=g).bfloat16().float()
+    G = (torch.randn(rows, Co, generator=g) * 0.1 + 0.02).bfloat16().float()          # upstream gradient of the block output
+    # ---- oracle (fp64 autograd)
+    a64, W64 = a.double().requires_grad_(True), W.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = a64 @ W64.t()
+    mu, var = y.mean(0), y.var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    u = (y - mu) * invstd * g64 + b64
+    z = torch.relu(u + ident.double())
+    z.backward(G.double())
+    keep = (z.detach() > 0)
+    gm = (G.double() * keep).float()                                                    # g = G gated by the block's ReLU
+    # ---- the hand-off: producers store (dgrad + old) gated by the mask bits and sum it per channel
+    bits = (keep.reshape(rows, Co // 8, 8).long() << torch.arange(8)).sum(-1).to(torch.uint8)
+    K2 = 64
+    dy2 = (torch.randn(rows, K2, generator=g) * 0.1).bfloat16()
+    wt2 = (torch.randn(Co, K2, generator=g) * 0.1).bfloat16()
+    old = G.bfloat16()
+    want = ((dy2.float() @ wt2.float().t() + old.float()) * keep).bfloat16()
+    for route in ("xjoin", "igemm"):
+        out = old.clone().to(DEV)
+        sums = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
+        if route == "xjoin":
+            ops.conv_expand_dgrad_masked(dy2.to(DEV), wt2.to(DEV), out, bits.to(DEV), sums, accumulate=True)
+        else:
+            d = ops.conv_desc(1, rows, 1, K2, Co, 1, 1, 0)
+            ops.conv_igemm(d, dy2.to(DEV).view(1, rows, 1, K2), wt2.to(DEV).view(Co, 1, K2), out.view(1, rows, 1, Co), stats=sums,
+                           flags=ops.EPI_ACCUMULATE, out_mask=bits.to(DEV))
+        err = (out.float().cpu() - want.float()).abs().max() / want.float().abs().max()
+        assert err < 1e-2, (route, float(err))
+        assert bool(((out.float().cpu() != 0) <= keep).all()), route                  # nothing leaks through a closed gate
+        s_want = out.float().cpu().double().sum(0)
+        np.testing.assert_allclose(sums.sum(0)[:, 0].cpu().numpy(), s_want.numpy(), rtol=1e-6, atol=1e-4)
+    # ---- the algebra itself, fed with the exact g
+    gb = gm.bfloat16().to(DEV)
+    ab = a.bfloat16().to(DEV)
+    Wb = W.bfloat16().to(DEV)
+    d3 = ops.conv_desc(1, rows, 1, w, Co, 1, 1, 0)
+    R = torch.zeros(Co, 1, w, device=DEV)
+    ops.conv_wgrad(d3, ab.view(1, rows, 1, w), gb.view(1, rows, 1, Co), R)
+    dgr = ops.conv_desc(1, rows, 1, w, w, 1, 1, 0)
+    gram = torch.zeros(w, 1, w, device=DEV)
+    ops.conv_wgrad(dgr, ab.view(1, rows, 1, w), ab.view(1, rows, 1, w), gram)
+    colsum = torch.zeros(4, w, device=DEV, dtype=torch.float64)
+    colsum[0] = ab.double().sum(0)
+    gs = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
+    gs[1, :, 0] = gb.double().sum(0)
+    dgam, dbet = torch.zeros(Co, device=DEV), torch.zeros(Co, device=DEV)
+    mean32, invstd32 = mu.detach().float().to(DEV), invstd.detach().float().to(DEV)
+    coef, wd, nq, nr = ops.bn3_bwd_prepare(R.view(Co, w), Wb, gs, mean32, invstd32, gamma.to(DEV), rows, dgam, dbet)
+    ops.bn3_bwd_finish_dw(R.view(Co, w), Wb, gram.view(w, w), colsum, coef, mean32, invstd32)
+
+    def relerr(x, ref):
+        return float((x.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert relerr(dgam, g64.grad) < 2e-3 and relerr(dbet, b64.grad) < 2e-3, (relerr(dgam, g64.grad), relerr(dbet, b64.grad))
+    assert relerr(R.view(Co, w), W64.grad) < 5e-3, relerr(R.view(Co, w), W64.grad)
+    da = torch.empty(rows, w, device=DEV, dtype=torch.bfloat16)
+    dd = ops.conv_desc(1, rows, 1, Co, w, 1, 1, 0)
+    ops.conv_igemm(dd, gb.view(1, rows, 1, Co), wd.view(w, 1, Co), da.view(1, rows, 1, w), bias=nr)
+    ops.conv_igemm(dgr, ab.view(1, rows, 1, w), nq.view(w, 1, w), da.view(1, rows, 1, w), flags=ops.EPI_ACCUMULATE)
+    e_da = relerr(da.float(), a64.grad)
+    assert e_da < 2e-2, e_da

@@ -1,0 +1,131 @@
+// Backward of a bottleneck's last BatchNorm THROUGH its 1x1 convolution, without the convolution's output.
+//
+// Reference semantics: autograd of  y = conv3(a) ; u = bn3(y) ; z = relu(u + identity)  (models/building_blocks/resnet.py:123-133,
+// BatchNorm2d in train mode, resnet.py:69).  With g = dL/dz gated by z > 0 (per pixel p, output channel c), s = gamma * invstd,
+// c1 = mean_p g, c2 = mean_p (g * xhat), xhat = (y - mean) * invstd, BatchNorm backward is
+//     dy[p][c] = s[c] * (g[p][c] - c1[c] - xhat[p][c] * c2[c])
+// and conv3's gradients are  da = W^T dy ,  dW = dy^T a.  The separate-pass implementation reads g and y (4w wide each) and
+// writes dy (4w wide), which dgrad and wgrad read again.  Because conv3 is LINEAR AND POINTWISE, y[p][c] = sum_j W[c][j] a[p][j],
+// everything that involves y collapses onto small matrices:
+//     R      = g^T a                      (the "raw" weight gradient: one wgrad launch with dy := g)
+//     sum_p g[p][c] y[p][c]  = <W[c,:], R[c,:]>                     ->  c2[c] = invstd[c] (<W[c,:], R[c,:]> - mean[c] sum_p g[p][c]) / n
+//     da[p][:] = (W^T diag(s)) g[p][:]  -  Q a[p][:]  -  r          with t = s * c2 * invstd,
+//                Q = W^T diag(t) W   (w x w),    r[k] = sum_c W[c][k] (s[c] c1[c] - t[c] mean[c])
+//     dW[c][k] = s[c] (R[c][k] - c1[c] A[k] - c2[c] invstd[c] (sum_j W[c][j] G[j][k] - mean[c] A[k]))
+//                with G = a^T a (the Gram matrix the forward's statistics came from) and A[k] = sum_p a[p][k]
+// so the 4w-wide tensors are read ONCE each (g by the raw wgrad and by the dgrad) and y is never stored.  W here is the bf16 copy the
+// forward multiplied with, so the implied y is exactly the forward's (unrounded) convolution output.
+//
+// Three small launches per block (w <= 128, 4w <= 512: everything fits simple one-thread-per-output loops):
+//   bn3_prepare_kernel   per output channel: the dot product, c1, c2, s, t, dgamma / dbeta
+//   bn3_derive_kernel    wd = bf16(W^T diag(s)) [w][4w],  nq = bf16(-Q) [w][w],  nr = -r [w]
+//   bn3_finish_dw_kernel dW in place of R
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+// coef layout: float[4][Co] = s, c1, c2, t
+__global__ __launch_bounds__(256) void bn3_prepare_kernel(const float* __restrict__ R, const bf16_t* __restrict__ W, const double* __restrict__ gsums,
+                                                          int replicas, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, double inv_n, int Co, int K, float* __restrict__ coef,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wavefront per channel
+    if (c >= Co) return;
+    float dot = 0.f;
+    for (int k = lane; k < K; k += 64) dot += bf16_to_f32(W[(size_t)c * K + k]) * R[(size_t)c * K + k];
+    dot = wave_sum(dot);
+    if (lane == 0) {
+        double sg = 0;
+        for (int r = 0; r < replicas; ++r) sg += gsums[((size_t)r * Co + c) * 2];
+        const double is = invstd[c], mu = mean[c];
+        const double sgx = is * ((double)dot - mu * sg);
+        const double s = (double)gamma[c] * is, c1 = sg * inv_n, c2 = sgx * inv_n;
+        coef[c] = (float)s;
+        coef[Co + c] = (float)c1;
+        coef[2 * Co + c] = (float)c2;
+        coef[3 * Co + c] = (float)(s * c2 * is);
+        dgamma[c] += (float)sgx;
+        dbeta[c] += (float)sg;
+    }
+}
+
+// grid: blocks 0 .. K-1 produce row k of wd (and nr[k]); blocks K .. 2K-1 produce row k of nq
+__global__ __launch_bounds__(256) void bn3_derive_kernel(const bf16_t* __restrict__ W, const float* __restrict__ coef, const float* __restrict__ mean,
+                                                         int Co, int K, bf16_t* __restrict__ wd, bf16_t* __restrict__ nq, float* __restrict__ nr) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < K) {
+        const int k = blockIdx.x;
+        float acc = 0.f;
+        for (int c = tid; c < Co; c += 256) {
+            const float w = bf16_to_f32(W[(size_t)c * K + k]);
+            const float s = coef[c], c1 = coef[Co + c], t = coef[3 * Co + c];
+            wd[(size_t)k * Co + c] = f32_to_bf16(s * w);
+            acc += w * (s * c1 - t * mean[c]);
+        }
+        red[tid] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) nr[k] = -red[0];
+    } else {
+        // nq[k][j] = -sum_c W[c][k] t[c] W[c][j]: thread j, loop over c (row c of W is read coalesced across j)
+        const int k = blockIdx.x - K;
+        for (int j = tid; j < K; j += 256) {
+            float acc = 0.f;
+            for (int c = 0; c < Co; ++c)
+                acc += bf16_to_f32(W[(size_t)c * K + k]) * coef[3 * Co + c] * bf16_to_f32(W[(size_t)c * K + j]);
+            nq[(size_t)k * K + j] = f32_to_bf16(-acc);
+        }
+    }
+}
+
+// dW[c][k] = s (R - c1 A[k] - c2 invstd (sum_j W[c][j] G[j][k] - mean A[k])), one workgroup per channel c, thread k
+__global__ __launch_bounds__(128) void bn3_finish_dw_kernel(float* __restrict__ RdW, const bf16_t* __restrict__ W, const float* __restrict__ gram,
+                                                            const double* __restrict__ colsum, int colsum_replicas, const float* __restrict__ coef,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, int Co, int K) {
+    __shared__ float wrow[128];
+    const int c = blockIdx.x, k = threadIdx.x;
+    if (k < K) wrow[k] = bf16_to_f32(W[(size_t)c * K + k]);
+    __syncthreads();
+    if (k >= K) return;
+    double A = 0;
+    for (int r = 0; r < colsum_replicas; ++r) A += colsum[(size_t)r * K + k];
+    // centred cross term in fp64: sum_j W[c][j] G[j][k] and mean * A[k] are both ~ n * |y| * |a| and nearly cancel
+    double wg = 0;
+    for (int j = 0; j < K; ++j) wg += (double)wrow[j] * (double)gram[(size_t)j * K + k];
+    const double s = coef[c], c1 = coef[Co + c], c2 = coef[2 * Co + c];
+    const double v = s * ((double)RdW[(size_t)c * K + k] - c1 * A - c2 * (double)invstd[c] * (wg - (double)mean[c] * A));
+    RdW[(size_t)c * K + k] = (float)v;
+}
+
+}  // namespace
+
+extern "C" int vince_bn3_bwd_prepare(const float* R, const void* w_bf16, const double* gsums, int32_t replicas, const float* mean,
+                                     const float* invstd, const float* gamma, int64_t count, int32_t Co, int32_t K, float* coef,
+                                     void* wd, void* nq, float* nr, float* dgamma, float* dbeta, void* stream) {
+    VINCE_CHECK_ARG(R && w_bf16 && gsums && mean && invstd && gamma && coef && wd && nq && nr && dgamma && dbeta, VINCE_E_ARG,
+                    "vince_bn3_bwd_prepare: null pointer");
+    VINCE_CHECK_ARG(count > 0 && Co > 0 && K > 0 && K <= 128 && K % 8 == 0, VINCE_E_SHAPE, "vince_bn3_bwd_prepare: K=%d (multiple of 8, at most 128)", K);
+    if (replicas <= 0 || replicas > VINCE_STATS_REPLICAS) replicas = VINCE_STATS_REPLICAS;
+    hipLaunchKernelGGL(bn3_prepare_kernel, dim3((Co + 3) / 4), dim3(256), 0, (hipStream_t)stream, R, (const bf16_t*)w_bf16, gsums, replicas,
+                       mean, invstd, gamma, 1.0 / (double)count, Co, K, coef, dgamma, dbeta);
+    hipLaunchKernelGGL(bn3_derive_kernel, dim3(2 * K), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_bf16, (const float*)coef, mean, Co, K,
+                       (bf16_t*)wd, (bf16_t*)nq, nr);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+extern "C" int vince_bn3_bwd_finish_dw(float* RdW, const void* w_bf16, const float* gram, const double* colsum, int32_t colsum_replicas,
+                                       const float* coef, const float* mean, const float* invstd, int32_t Co, int32_t K, void* stream) {
+    VINCE_CHECK_ARG(RdW && w_bf16 && gram && colsum && coef && mean && invstd, VINCE_E_ARG, "vince_bn3_bwd_finish_dw: null pointer");
+    VINCE_CHECK_ARG(Co > 0 && K > 0 && K <= 128 && colsum_replicas > 0, VINCE_E_SHAPE, "vince_bn3_bwd_finish_dw: K=%d (at most 128)", K);
+    hipLaunchKernelGGL(bn3_finish_dw_kernel, dim3(Co), dim3(128), 0, (hipStream_t)stream, RdW, (const bf16_t*)w_bf16, gram, colsum,
+                       colsum_replicas, coef, mean, invstd, Co, K);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}

@@ -31,6 +31,12 @@ int vince_conv_m8_launch(vince_conv::ConvParams& p, int mode, hipStream_t stream
 namespace {
 using vince_conv::ConvParams;
 
+#ifdef VINCE_MEASURE   // measurement build: VINCE_CONV_ABLATE bits 32 (no output stores) and 8 (no statistics atomics)
+#define CORE_ABL(bit) (p.ablate & (bit))
+#else
+#define CORE_ABL(bit) 0
+#endif
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     __device__ static inline void run(const uint4& a, const uint4& b, f32x16_t& c) {
@@ -114,7 +120,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     // BWD (compile time): the gradient epilogues -- residual join (ACCUMULATE, acc_mask) and the fused BatchNorm-backward
     // reduction (bnred).  Forward launches take the lean instantiation.
     const bool accum = (BWD || JOIN) && (flags & VINCE_EPI_ACCUMULATE) != 0;
-    const bool touch = p.e.bias || accum || (flags & VINCE_EPI_RELU);
+    const bool touch = p.e.bias || accum || (flags & VINCE_EPI_RELU) || (BWD && p.e.out_mask);
     const T* __restrict__ br_y = BWD ? (const T*)p.e.bnred.y : nullptr;
     float br_mu[CH], br_is[CH], br_sc[CH], br_sh[CH];
     if constexpr (BWD) {
@@ -133,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
         size_t off[UB];
         bool ok[UB];
         uint4 oldv[UB], yv[UB];
-        uint32_t ab[UB], bb[UB];
+        uint32_t ab[UB], bb[UB], om[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int row = row0 + (rb + u) * RPP;
@@ -153,6 +159,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
             }
             if constexpr (BWD) {
                 ab[u] = bb[u] = 0xffu;
+                om[u] = 0xffu;
+                if (ok[u] && p.e.out_mask) om[u] = p.e.out_mask[off[u] / CH];
                 if (ok[u]) {
                     if (accum) {
                         oldv[u] = *(const uint4*)(out + off[u]);
@@ -195,6 +203,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
                         for (int e = 0; e < CH; ++e) f[e] += ((ab[u] >> e) & 1u) ? o[e] : 0.f;
                     }
                 }
+                if constexpr (BWD) {
+                    if (p.e.out_mask) {   // (uniform) the gradient is stored already gated by the ReLU it flows into next
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) f[e] = ((om[u] >> e) & 1u) ? f[e] : 0.f;
+                    }
+                }
                 if (flags & VINCE_EPI_RELU) {
 #pragma unroll
                     for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
@@ -211,7 +225,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
                     *(uint4*)(out + off[u]) = v;
                 }
             } else {
-                if (!(p.ablate & 32)) *(uint4*)(out + off[u]) = v;   // ablate 32: measurement aid, no output stores
+                if (!CORE_ABL(32)) *(uint4*)(out + off[u]) = v;
             }
             if (p.e.stats) {
                 float f[CH];
@@ -264,7 +278,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += red[((w * CPR + ck) * CH + e) * 2 + which];
-            if (c0 + ch < d.Co && !(p.ablate & 8))   // ablate 8: measurement aid, drops the atomics only
+            if (c0 + ch < d.Co && !CORE_ABL(8))
                 unsafeAtomicAdd(red_out + ((size_t)(tile % (uint32_t)p.e.replicas) * d.Co + (c0 + ch)) * 2 + which, (double)s);
         }
     }

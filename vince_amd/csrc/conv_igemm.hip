@@ -30,6 +30,14 @@ namespace {
 
 constexpr int PT = 128;   // pixels per workgroup tile
 
+// Measurement build only (-DVINCE_MEASURE, VINCE_CONV_ABLATE): 1 no DMA, 2 no MFMA, 4 no barrier, 8 no statistics atomics, 16 no main
+// loop, 32 no output stores, 64 launch only, 128 no epilogue.  The product library compiles none of it.
+#ifdef VINCE_MEASURE
+#define IG_ABL(bit) (p.ablate & (bit))
+#else
+#define IG_ABL(bit) 0
+#endif
+
 // Wavefront priority around an MFMA cluster (VINCE_MFMA_PRIO, build-time): with equal priorities the SIMD's arbiter interleaves the
 // MFMAs of its resident wavefronts, which locks them into the same phase (all in their MFMA cluster, then all in their
 // LDS / barrier phase); a raised priority lets one wavefront run its cluster through while the other fetches.
@@ -176,9 +184,6 @@ struct SmemD {
     static constexpr int CRS = CT * (int)sizeof(T) + 16;
     static constexpr int EPI = PTL * CRS + 4 * CT * 2 * 4;
     static constexpr int BYTES0 = MAIN > EPI ? MAIN : EPI;
-    // operand-transform table (scale[512], shift[512] floats) lives right behind the ring; only the XF instantiations pay
-    static constexpr int XF_OFF = MAIN, XF_BYTES = 2 * 512 * 4;
-    static constexpr int BYTES_XF = BYTES0 > MAIN + XF_BYTES ? BYTES0 : MAIN + XF_BYTES;
 };
 
 // K tile = KC 16-byte chunks per row; STAGES-deep LDS ring, prefetch distance STAGES-1 tiles, counted vmcnt so that the
@@ -186,9 +191,8 @@ struct SmemD {
 // PTL = pixels per workgroup tile (128 or 256).  The L2 -> LDS fill rate of a CU (measured ~19 B/clk with every CU
 // streaming) caps a 128x128 tile at ~700 TFLOP/s chip-wide: 256 B of operands per K element feed 32768 FLOP.  The
 // 256-pixel tile moves 25 % fewer bytes per FLOP (each wave owns 128 pixels x CT/2 channels).
-template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, int MODE, bool XF = false, bool ROT = false>
+template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, int MODE, bool ROT = false>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvParams p) {
-    static_assert(!(XF && ROT), "the rotated main loop has no operand transform");
     constexpr int CH = Elem<T>::CH;
     constexpr int CJ = CT / 64, PI = PTL / 64;
     using S = SmemD<T, CT, KC, STAGES, PTL>;
@@ -198,10 +202,10 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     constexpr int XROWS = PTL / RPP, WROWS = CT / RPP;
     constexpr int PER_STAGE = XROWS + WROWS;       // DMA instructions per thread per stage
     constexpr int SWSH = KC == 8 ? 1 : 2, SWMASK = KC - 1;   // slot swizzle = (row >> SWSH) & SWMASK
-    constexpr bool ILV = CT == 128 && STAGES == 3 && !XF;    // DMA issue interleaved with the MFMAs (see issue_piece)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[XF ? S::BYTES_XF : S::BYTES0];
+    constexpr bool ILV = CT == 128 && STAGES == 3;    // DMA issue interleaved with the MFMAs (see issue_piece)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES0];
 
-    if (p.ablate & 64) return;   // measurement aid: launch + workgroup dispatch only
+    if (IG_ABL(64)) return;   // launch + workgroup dispatch only
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave & 1, wp = wave >> 1;
@@ -259,48 +263,6 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
             offw[e] = ok ? (((uint32_t)co * (uint32_t)d.WT + (uint32_t)widx) * (uint32_t)d.Ci + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
         }
     };
-    // ---- operand transform (XF): in' = relu(in * scale[ci] + shift[ci]) on this thread's own DMA'd pieces, in place in LDS.
-    // A piece is 16 bytes = CH channels of one input pixel; pieces that were zero-filled (out-of-image tap, tile tail) stay
-    // zero, which is what zero padding of the ACTIVATION means.  vmask[stage] remembers which of this thread's pieces of
-    // that stage hold real data.
-    uint32_t vmask[STAGES];
-#pragma unroll
-    for (int st = 0; st < STAGES; ++st) vmask[st] = 0;
-    const float* xf_tab = (const float*)(smem + S::XF_OFF);
-    if constexpr (XF) {
-        float* tabw = (float*)(smem + S::XF_OFF);
-        for (int ci = tid; ci < d.Ci; ci += 256) {
-            tabw[ci] = p.e.in_scale[ci];
-            tabw[512 + ci] = p.e.in_shift[ci];
-        }
-        // (visible to everyone after the prologue's barrier)
-    }
-    auto transform_tile = [&](int kt, int buf) {
-        if constexpr (XF) {
-            const int q = kt * KC + c_log;
-            const int cc = q & p.cpt_mask;                     // chunk within the tap = channel group
-            float sc[CH], sh[CH];
-#pragma unroll
-            for (int e4 = 0; e4 < CH; e4 += 4) {
-                const float4 a = *(const float4*)(xf_tab + cc * CH + e4);
-                const float4 b = *(const float4*)(xf_tab + 512 + cc * CH + e4);
-                sc[e4] = a.x; sc[e4 + 1] = a.y; sc[e4 + 2] = a.z; sc[e4 + 3] = a.w;
-                sh[e4] = b.x; sh[e4 + 1] = b.y; sh[e4 + 2] = b.z; sh[e4 + 3] = b.w;
-            }
-            unsigned char* base = smem + buf * S::STAGE + wave * 1024 + lane * 16;
-            const uint32_t vm = buf == 0 ? vmask[0] : (buf == 1 ? vmask[1] : vmask[STAGES - 1]);   // STAGES <= 3
-#pragma unroll
-            for (int e = 0; e < XROWS; ++e) {
-                if (!((vm >> e) & 1u)) continue;
-                uint4* ptr = (uint4*)(base + e * 4096);
-                float f[CH];
-                Chunk<T>::unpack(*ptr, f);
-#pragma unroll
-                for (int c_ = 0; c_ < CH; ++c_) f[c_] = fmaxf(f[c_] * sc[c_] + sh[c_], 0.f);
-                *ptr = Chunk<T>::pack(f);
-            }
-        }
-    };
     auto issue_tile = [&](int kt, int buf) {
         if (p.uniform_taps) {
             const int tap = kt >= p.nkt ? 0x7fffff : ((kt * KC) >> p.log2_cpt);   // wave-uniform
@@ -315,14 +277,6 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
             }
         } else {
             compute_offsets(kt * KC + c_log);
-        }
-        if constexpr (XF) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int e = 0; e < XROWS; ++e) m |= (offx[e] < OOB ? 1u : 0u) << e;
-            if (buf == 0) vmask[0] = m;
-            else if (buf == 1) vmask[1] = m;
-            else vmask[STAGES - 1] = m;
         }
         if constexpr (!ILV) {
             const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
@@ -353,7 +307,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
 
     // split-K (tiny-M GEMMs: the projection MLP): this workgroup reduces K tiles [kt0, kt1) only
     const int kt0 = p.kt_per_split > 0 ? (int)blockIdx.y * p.kt_per_split : 0;
-    const int kt1 = (p.ablate & 16) ? kt0 : (p.kt_per_split > 0 ? min(p.nkt, kt0 + p.kt_per_split) : p.nkt);   // ablate 16: no main loop
+    const int kt1 = IG_ABL(16) ? kt0 : (p.kt_per_split > 0 ? min(p.nkt, kt0 + p.kt_per_split) : p.nkt);   // ablate 16: no main loop
     // prologue: STAGES-1 tiles in flight (tiles past the end are issued as all-zero fills so the counts stay uniform)
 #pragma unroll
     for (int st = 0; st < STAGES - 1; ++st) {
@@ -364,10 +318,6 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
         }
     }
     wait_vmcnt<(STAGES - 2) * PER_STAGE>();
-    if constexpr (XF) {
-        __syncthreads();                 // the scale / shift table is complete
-        transform_tile(kt0, 0);
-    }
     __syncthreads();
     const int sw = ((lane & 31) >> SWSH) & SWMASK, khalf = lane >> 5;
     const int row_off = (lane & 31) * KB;
@@ -446,12 +396,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
         }
         wait_vmcnt<0>();
         __syncthreads();
-        if (p.ablate & 128) return;
+        if (IG_ABL(128)) return;
         conv_epilogue<T, CT, S::CRS, MODE, PTL, (MINW >= 4 ? 2 : 4)>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
         return;
     }
     for (int kt = kt0; kt < kt1; ++kt) {
-        if (!(p.ablate & 1)) issue_tile(kt + STAGES - 1, nbuf);
+        if (!IG_ABL(1)) issue_tile(kt + STAGES - 1, nbuf);
         const unsigned char* xs = smem + buf * S::STAGE + (wp * (PTL / 2)) * KB + row_off;
         const unsigned char* ws = smem + buf * S::STAGE + S::XB + (wc * (CT / 2)) * KB + row_off;
 #pragma unroll
@@ -462,7 +412,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
             for (int j = 0; j < CJ; ++j) wf[j] = *(const uint4*)(ws + j * 32 * KB + slot);
 #pragma unroll
             for (int i = 0; i < PI; ++i) xf[i] = *(const uint4*)(xs + i * 32 * KB + slot);
-            if (p.ablate & 2) {   // measurement aid: keep the LDS reads, drop the matrix work
+            if (IG_ABL(2)) {   // keep the LDS reads, drop the matrix work
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) asm volatile("" ::"v"(wf[j].x), "v"(wf[j].w));
 #pragma unroll
@@ -478,7 +428,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
                         for (int i = 0; i < PI; ++i) {
                             Mma<T>::run(wf[j], xf[i], acc[j][i]);
                             const int m = (s * CJ + j) * PI + i;
-                            if (!(p.ablate & 1) && m % EVERY == 0 && m / EVERY < PER_STAGE) {
+                            if (!IG_ABL(1) && m % EVERY == 0 && m / EVERY < PER_STAGE) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 issue_piece(m / EVERY, nbuf);
                                 __builtin_amdgcn_sched_barrier(0);
@@ -499,21 +449,18 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
             constexpr int DONE = (NM + EVERY - 1) / EVERY < PER_STAGE ? (NM + EVERY - 1) / EVERY : PER_STAGE;
 #pragma unroll
             for (int pc = DONE; pc < PER_STAGE; ++pc)
-                if (!(p.ablate & 1)) issue_piece(pc, nbuf);
+                if (!IG_ABL(1)) issue_piece(pc, nbuf);
         }
         // tile kt+1 must have landed (this wave's share; the barrier extends it to all waves); the STAGES-2 younger
         // tiles stay in flight across the barrier
         wait_vmcnt<(STAGES - 2) * PER_STAGE>();
-        if constexpr (XF) {
-            if (kt + 1 < kt1) transform_tile(kt + 1, buf + 1 == STAGES ? 0 : buf + 1);   // own pieces only: no barrier needed first
-        }
-        if (!(p.ablate & 4)) __syncthreads();
+        if (!IG_ABL(4)) __syncthreads();
         buf = buf + 1 == STAGES ? 0 : buf + 1;
         nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
     }
     wait_vmcnt<0>();
     __syncthreads();
-    if (p.ablate & 128) {   // measurement aid: no epilogue (one dummy store keeps the accumulators alive)
+    if (IG_ABL(128)) {   // no epilogue (one dummy store keeps the accumulators alive)
         float t = 0.f;
         for (int j = 0; j < CJ; ++j) for (int i = 0; i < PI; ++i) t += acc[j][i][0];
         if (t == 1.2345f) ((float*)p.out)[0] = t;
@@ -544,11 +491,6 @@ int launch(ConvParams& p, hipStream_t stream) {
     // tile, 2 the 2-stage 128-pixel tile, 3 the 3-stage 128-pixel tile
     static int rot = getenv("VINCE_ROT") ? atoi(getenv("VINCE_ROT")) : 9;
     static int rot_min_k = getenv("VINCE_ROT_MIN_K") ? atoi(getenv("VINCE_ROT_MIN_K")) : 0;
-    const bool xf = p.e.in_scale != nullptr;
-    if (xf && !(p.in_bytes && p.w_bytes && k_elems >= dlds_min_k && !BWD)) {
-        vince_set_error("vince_conv_igemm: the operand transform needs the direct-to-LDS forward kernels (tensors < 2 GiB)");
-        return VINCE_E_UNSUPPORTED;
-    }
     if (p.in_bytes && p.w_bytes && k_elems >= dlds_min_k) {
         const int cpt = p.cpt_mask == 0x7fffffff ? p.total_chunks : p.cpt_mask + 1;
         p.uniform_taps = (cpt % 4 == 0) && (p.total_chunks % 4 == 0);
@@ -560,7 +502,7 @@ int launch(ConvParams& p, hipStream_t stream) {
         static int kc8_min_k = getenv("VINCE_KC8_MIN_K") ? atoi(getenv("VINCE_KC8_MIN_K")) : 2048;   // 0 = off
         if constexpr (sizeof(T) == 2 && CT == 128) {
             const bool big = dlds_cfg == 5 && k_elems >= big_min_k && (long)((p.M + 255) / 256) * p.ctiles >= big_min_tiles;
-            if (kc8_min_k > 0 && !xf && !big && p.cpt_mask == 0x7fffffff && p.total_chunks % 8 == 0 && k_elems >= kc8_min_k) {
+            if (kc8_min_k > 0 && !big && p.cpt_mask == 0x7fffffff && p.total_chunks % 8 == 0 && k_elems >= kc8_min_k) {
                 p.uniform_taps = 1;
                 p.nkt = p.total_chunks / 8;
                 hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 8, 2, 2, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
@@ -574,12 +516,8 @@ int launch(ConvParams& p, hipStream_t stream) {
             if constexpr (CT == 128) {
                 p.ptiles = (p.M + 255) / 256;
                 p.variant = 1;
-                if (xf) {
-                    if constexpr (!BWD)
-                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, 0, true>), dim3(p.ptiles * p.ctiles),
-                                           dim3(256), 0, stream, p);
-                } else if (rot & 1) {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE, false, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                if (rot & 1) {
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
                                        stream, p);
                 } else {
                     hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
@@ -592,12 +530,8 @@ int launch(ConvParams& p, hipStream_t stream) {
             if constexpr (CT == 64) {
                 p.ptiles = (p.M + 255) / 256;
                 p.variant = 1;
-                if (xf) {
-                    if constexpr (!BWD)
-                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, 0, true>), dim3(p.ptiles * p.ctiles),
-                                           dim3(256), 0, stream, p);
-                } else if (rot & 2) {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, MODE, false, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                if (rot & 2) {
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, MODE, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
                                        stream, p);
                 } else {
                     hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
@@ -610,7 +544,7 @@ int launch(ConvParams& p, hipStream_t stream) {
             int splits = 1;
             const long tiles = (long)p.ptiles * p.ctiles;
             static const bool splitk_env = !(getenv("VINCE_SPLITK") && atoi(getenv("VINCE_SPLITK")) == 0);
-            if (sizeof(T) == 4 && splitk_env && !BWD && !xf && !p.e.stats && tiles < 128 && p.nkt >= 16 &&
+            if (sizeof(T) == 4 && splitk_env && !BWD && !p.e.stats && tiles < 128 && p.nkt >= 16 &&
                 p.d.osh == 1 && p.d.osw == 1 && p.d.OH == p.d.Ho && p.d.OW == p.d.Wo) {
                 static const long target = getenv("VINCE_SPLITK_WGS") ? atol(getenv("VINCE_SPLITK_WGS")) : 256;   // (env: measurement aid) more splits cost more in atomics than they buy
                 splits = (int)min((long)(p.nkt / 8), (target + tiles - 1) / tiles);
@@ -627,10 +561,6 @@ int launch(ConvParams& p, hipStream_t stream) {
                                    stream, p);
                 if (relu) hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)min((size_t)1024, (n / 4 + 255) / 256)), dim3(256), 0,
                                              stream, (float*)p.out, n / 4);
-            } else if (xf) {
-                if constexpr (!BWD)
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, 0, true>), dim3(p.ptiles * p.ctiles), dim3(256),
-                                       0, stream, p);
             } else {
                 // reductions at least VINCE_S3_MIN_K long take a 3-stage ring (two K tiles in flight, 3 workgroups per CU) instead
                 // of 2 stages / 4 workgroups
@@ -638,11 +568,11 @@ int launch(ConvParams& p, hipStream_t stream) {
                 static const int s3_min_k = getenv("VINCE_S3_MIN_K") ? atoi(getenv("VINCE_S3_MIN_K")) : 2048;
                 if (s3_min_k > 0 && k_elems >= s3_min_k) {
                     if (rot & 8)
-                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE, false, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
                     else
                         hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
                 } else if ((rot & 4) && k_elems >= rot_min_k) {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE, false, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
                 } else {
                     hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
                 }
@@ -676,12 +606,11 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     VINCE_CHECK_ARG(!e.acc_mask || (e.flags & VINCE_EPI_ACCUMULATE), VINCE_E_ARG, "vince_conv_igemm: acc_mask needs VINCE_EPI_ACCUMULATE");
     VINCE_CHECK_ARG(!e.bnred.y || (e.bnred.mean && e.bnred.invstd && e.bnred.sums && !e.stats), VINCE_E_ARG,
                     "vince_conv_igemm: bnred needs y, mean, invstd and sums, and excludes stats");
-    VINCE_CHECK_ARG(!e.in_scale == !e.in_shift, VINCE_E_ARG, "vince_conv_igemm: in_scale and in_shift come together");
+    VINCE_CHECK_ARG(!e.out_mask || (!e.out_scale && !e.id_scale && !e.bnred.y), VINCE_E_ARG,
+                    "vince_conv_igemm: out_mask belongs to the gradient epilogue and excludes bnred / the forward join");
     VINCE_CHECK_ARG(!e.id_scale == !e.id_shift, VINCE_E_ARG, "vince_conv_igemm: id_scale and id_shift come together");
     VINCE_CHECK_ARG((!e.out_scale && !e.id_scale) || ((e.flags & VINCE_EPI_ACCUMULATE) && !e.acc_mask && !e.bnred.y && !e.stats), VINCE_E_ARG,
                     "vince_conv_igemm: out_scale / id_scale need VINCE_EPI_ACCUMULATE and exclude acc_mask, bnred and stats");
-    VINCE_CHECK_ARG(!e.in_scale || (dd->Ci <= 512 && dd->Cs == 0 && !(e.flags & VINCE_EPI_ACCUMULATE) && !e.bnred.y), VINCE_E_UNSUPPORTED,
-                    "vince_conv_igemm: operand transform: Ci <= 512, no packed row taps, forward epilogue only");
     VINCE_CHECK_ARG(!e.bnred.mask_scale == !e.bnred.mask_shift, VINCE_E_ARG,
                     "vince_conv_igemm: bnred mask_scale and mask_shift come together");
     VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_igemm: bad dtype %d", dtype);
@@ -729,8 +658,11 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.variant = 0;
     p.cs = d.Cs > 0 ? d.Cs : d.Ci;
     p.kt_per_split = 0;
-    static int ablate = getenv("VINCE_CONV_ABLATE") ? atoi(getenv("VINCE_CONV_ABLATE")) : 0;   // measurement aid only
+    p.ablate = 0;
+#ifdef VINCE_MEASURE
+    static int ablate = getenv("VINCE_CONV_ABLATE") ? atoi(getenv("VINCE_CONV_ABLATE")) : 0;
     p.ablate = ablate;
+#endif
     {
         const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;
         const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * p.cs * esz, wb = (unsigned long long)d.Co * d.WT * d.Ci * esz;
@@ -764,7 +696,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
         vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh * 10 + d.osh, e.flags);
     }
     int rc;
-    const bool bwd = (e.flags & VINCE_EPI_ACCUMULATE) || e.bnred.y;   // gradient epilogue instantiation
+    const bool bwd = (e.flags & VINCE_EPI_ACCUMULATE) || e.bnred.y || e.out_mask;   // gradient epilogue instantiation
     const bool join = e.out_scale || e.id_scale;   // forward residual join with known BatchNorm constants
     // The 8-wavefront 256 x 256 core (conv_m8.hip) takes the long bf16 reductions with 256-channel output tiles: the 3x3 and wide
     // 1x1 convolutions of layer3 / layer4 and their input gradients.  VINCE_M8=0 keeps everything on this file's tiles (the

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512) void conv_m8_kernel(const ConvParams p) {
 // own tiles).  mode: 0 forward, 1 gradient epilogues, 2 forward residual join.
 int vince_conv_m8_launch(vince_conv::ConvParams& p, int mode, hipStream_t stream) {
     const vince_conv_desc& d = p.d;
-    if (!(p.in_bytes && p.w_bytes) || d.Cs != 0 || d.Ci % 64 != 0 || p.kt_per_split != 0 || p.e.in_scale) return -1;
+    if (!(p.in_bytes && p.w_bytes) || d.Cs != 0 || d.Ci % 64 != 0 || p.kt_per_split != 0) return -1;
     const int taps = d.TA * d.TB;
     p.kt_per_tap = d.Ci / 64;
     if (p.kt_per_tap & (p.kt_per_tap - 1)) return -1;      // the per-tap walk wants a power of two (every ResNet layer)

@@ -41,6 +41,8 @@ struct XjParams {
     // DGRAD mode (the block-input gradient: out = conv + (acc_mask bit ? out : 0), plus the BatchNorm-backward sums of the
     // BatchNorm that consumes `out`): see vince_conv_expand_dgrad
     const uint8_t* acc_mask;
+    const uint8_t* out_mask;   // DGRAD: the stored value is gated by these bits (the ReLU of the block below); br_sums without br_y then
+                               // receives the plain per-channel (sum, sum of squares) of the stored values (vince_conv_expand_dgrad_masked)
     const void* br_y;
     const uint8_t* br_bits;
     const float* br_mean;
@@ -244,6 +246,12 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                     for (int e = 0; e < 8; ++e) { ssum[pass][e] += f[e]; ssq[pass][e] += f[e] * f[e]; }
                 }
                 if constexpr (DGRAD) {
+                    if (!p.br_y && p.br_sums) {             // (uniform) plain column sums of the stored (already gated) gradient
+                        float g[8];
+                        Chunk<bf16_t>::unpack(val, g);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { ssum[pass][e] += g[e]; ssq[pass][e] += g[e] * g[e]; }
+                    }
                     if (p.br_y) {                           // (uniform) sums of the STORED gradient, as vince_bn_bwd_reduce defines them
                         float g[8], yy[8];
                         Chunk<bf16_t>::unpack(val, g);
@@ -281,11 +289,16 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
     };
     auto run_unit = [&](const uint4 (&ids)[2][2], int t, int i) {
         uint2 amask = make_uint2(0xffffffffu, 0xffffffffu);  // DGRAD: the 8 acc_mask bytes of this lane's pixel (64 channels)
+        uint2 omask = make_uint2(0xffffffffu, 0xffffffffu);  // DGRAD: the 8 out_mask bytes likewise
         if constexpr (DGRAD) {
             const uint32_t pixu = (uint32_t)(first + t * step) * XJ_PX + (uint32_t)(wp * 64 + i * 32);
             if (p.acc_mask) {
                 const uint32_t pix = pixu + (uint32_t)(lane & 31);
                 if (t < ntiles && pix < p.rows) amask = *(const uint2*)(p.acc_mask + ((size_t)pix * p.Co + (size_t)(c0 + wc * 64)) / 8);
+            }
+            if (p.out_mask) {
+                const uint32_t pix = pixu + (uint32_t)(lane & 31);
+                if (t < ntiles && pix < p.rows) omask = *(const uint2*)(p.out_mask + ((size_t)pix * p.Co + (size_t)(c0 + wc * 64)) / 8);
             }
             if (p.br_y) {
 #pragma unroll
@@ -351,6 +364,9 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                     const uint32_t ab = ((bidx < 4 ? amask.x : amask.y) >> (8 * (bidx & 3))) & 0xffu;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += ((ab >> e) & 1u) ? o[e] : 0.f;
+                    const uint32_t ob = ((bidx < 4 ? omask.x : omask.y) >> (8 * (bidx & 3))) & 0xffu;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((ob >> e) & 1u) ? v[e] : 0.f;
                     opk[j][gp] = Chunk<bf16_t>::pack(v);
                     continue;
                 }
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 stage_store(opk, pass, out, SAVE ? p.mask_out : nullptr, pix0);
-                if constexpr (SAVE) stage_store(rpk, pass, yraw, nullptr, pix0);
+                if constexpr (SAVE) { if (yraw) stage_store(rpk, pass, yraw, nullptr, pix0); }   // (uniform)
             }
         }
     };
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
     }
     }
     if constexpr (PLAIN || DGRAD) {
-        if (DGRAD ? (p.br_y != nullptr) : (p.stats != nullptr)) {
+        if (DGRAD ? (p.br_sums != nullptr) : (p.stats != nullptr)) {
             // lanes l, l + LPR, l + 2 LPR, ... hold the same channels: fold them, then one fp64 atomic per channel and wavefront
 #pragma unroll
             for (int q = 0; q < NPASS; ++q)
@@ -490,9 +506,26 @@ extern "C" int vince_conv_expand_stats(int dtype, const void* x, const void* w, 
     return VINCE_OK;
 }
 
+static int expand_dgrad_common(int dtype, const void* dy, const void* wt, int64_t rows, int32_t K, int32_t Co, void* out, int accumulate,
+                               const uint8_t* acc_mask, const vince_bn_reduce* bnred, const uint8_t* out_mask, double* gsums,
+                               int32_t replicas, void* stream);
+
 extern "C" int vince_conv_expand_dgrad(int dtype, const void* dy, const void* wt, int64_t rows, int32_t K, int32_t Co, void* out,
                                        int accumulate, const uint8_t* acc_mask, const vince_bn_reduce* bnred, int32_t replicas,
                                        void* stream) {
+    return expand_dgrad_common(dtype, dy, wt, rows, K, Co, out, accumulate, acc_mask, bnred, nullptr, nullptr, replicas, stream);
+}
+
+extern "C" int vince_conv_expand_dgrad_masked(int dtype, const void* dy, const void* wt, int64_t rows, int32_t K, int32_t Co, void* out,
+                                              int accumulate, const uint8_t* acc_mask, const uint8_t* out_mask, double* gsums,
+                                              int32_t replicas, void* stream) {
+    VINCE_CHECK_ARG(((uintptr_t)out_mask & 7) == 0, VINCE_E_ALIGN, "vince_conv_expand_dgrad_masked: out_mask must be 8-byte aligned");
+    return expand_dgrad_common(dtype, dy, wt, rows, K, Co, out, accumulate, acc_mask, nullptr, out_mask, gsums, replicas, stream);
+}
+
+static int expand_dgrad_common(int dtype, const void* dy, const void* wt, int64_t rows, int32_t K, int32_t Co, void* out, int accumulate,
+                               const uint8_t* acc_mask, const vince_bn_reduce* bnred, const uint8_t* out_mask, double* gsums,
+                               int32_t replicas, void* stream) {
     VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_expand_dgrad: bf16 only");
     VINCE_CHECK_ARG(dy && wt && out && rows > 0, VINCE_E_ARG, "vince_conv_expand_dgrad: null pointer");
     VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_dgrad: K=%d (64 or 128)", K);
@@ -513,6 +546,8 @@ extern "C" int vince_conv_expand_dgrad(int dtype, const void* dy, const void* wt
     if (bnred && bnred->y) {
         p.br_y = bnred->y; p.br_bits = bnred->mask_bits; p.br_mean = bnred->mean; p.br_invstd = bnred->invstd; p.br_sums = bnred->sums;
     }
+    p.out_mask = out_mask;
+    if (gsums) p.br_sums = gsums;
     p.rows = (uint32_t)rows; p.Co = (uint32_t)Co; p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
     p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
     p.cgroups = Co / XJ_CG;
@@ -522,7 +557,7 @@ extern "C" int vince_conv_expand_dgrad(int dtype, const void* dy, const void* wt
     grid = grid / p.cgroups * p.cgroups;
     if (grid < p.cgroups) grid = p.cgroups;
     VinceProfScope prof(VINCE_TAG_XDGRAD, (double)rows * 2 * (K + Co * (1 + (accumulate ? 1 : 0) + (p.br_y ? 1 : 0))) +
-                        (double)rows * Co / 8 * ((acc_mask ? 1 : 0) + (p.br_bits ? 1 : 0)), stream);
+                        (double)rows * Co / 8 * ((acc_mask ? 1 : 0) + (p.br_bits ? 1 : 0) + (out_mask ? 1 : 0)), stream);
     if (K == 64)
         hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, false, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
     else
@@ -540,8 +575,8 @@ extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, i
     VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_join: K=%d (64 or 128)", K);
     VINCE_CHECK_ARG(Co > 0 && Co % XJ_CG == 0, VINCE_E_SHAPE, "vince_conv_expand_join: Co=%d must be a multiple of %d", Co, XJ_CG);
     VINCE_CHECK_ARG(!id_scale == !id_shift, VINCE_E_ARG, "vince_conv_expand_join: id_scale and id_shift come together");
-    VINCE_CHECK_ARG(!y_raw == !mask_out, VINCE_E_ARG, "vince_conv_expand_join: y_raw and mask_out come together (the training forward)");
-    VINCE_CHECK_ARG(!y_raw || (out != identity && (((uintptr_t)y_raw & 15) | ((uintptr_t)mask_out & 7)) == 0), VINCE_E_ARG,
+    VINCE_CHECK_ARG(!y_raw || mask_out, VINCE_E_ARG, "vince_conv_expand_join: y_raw comes with mask_out (the training forward)");
+    VINCE_CHECK_ARG(!mask_out || (out != identity && (((uintptr_t)y_raw & 15) | ((uintptr_t)mask_out & 7)) == 0), VINCE_E_ARG,
                     "vince_conv_expand_join: saving needs out != identity, y_raw 16-byte and mask_out 8-byte aligned");
     VINCE_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)identity | (uintptr_t)out) & 15) == 0, VINCE_E_ALIGN,
                     "vince_conv_expand_join: pointers must be 16-byte aligned");
@@ -566,7 +601,7 @@ extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, i
     hipLaunchKernelGGL((conv_xjoin_kernel<KK, SS, AA, SV>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p)
 #define VINCE_XJ_PICK(KK, SS)                                                                             \
     do {                                                                                                  \
-        if (y_raw) { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, true); else VINCE_XJ_LAUNCH(KK, SS, false, true); }   \
+        if (mask_out) { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, true); else VINCE_XJ_LAUNCH(KK, SS, false, true); }   \
         else { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, false); else VINCE_XJ_LAUNCH(KK, SS, false, false); }       \
     } while (0)
     VinceProfScope prof(VINCE_TAG_XJOIN, (double)rows * 2 * (K + Co * (2 + (y_raw ? 1 : 0))) + (mask_out ? (double)rows * Co / 8 : 0), stream);

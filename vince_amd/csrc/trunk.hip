@@ -43,6 +43,7 @@ struct Blk {
     BnL bd;
     size_t x_in, y[3], a[2], yd, z, zmask;   // byte offsets in workspace (zmask: 1 byte per 16-B chunk of z)
     size_t gram, colsum;                      // Gram-statistics scratch of conv3's input (byte offsets; NONE: not eligible)
+    size_t alg;                               // BatchNorm-backward algebra scratch (coef, wd, nq, nr: see alg_ptrs), beside gram
 };
 
 constexpr size_t NONE = (size_t)-1;
@@ -80,6 +81,9 @@ struct vince_trunk {
     hipStream_t ds_stream = nullptr;
     hipEvent_t ev_ds_start = nullptr, ev_ds_dy = nullptr, ev_ds_wg = nullptr, ev_ds_done = nullptr;
     size_t off_dyd = 0;
+    // the last grad-enabled forward took the Gram join WITHOUT storing conv3's output for the eligible blocks (alg_block): its
+    // backward must run the BatchNorm-backward algebra for exactly those blocks
+    bool fwd_alg = false;
 };
 
 namespace {
@@ -316,6 +320,14 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
         }
     }
     t->gram_bytes = P.ws - t->off_gram;
+    for (Blk& b : t->blocks) {   // (not part of the per-forward zeroing: written whole by vince_bn3_bwd_prepare)
+        b.alg = NONE;
+        if (b.gram != NONE) {
+            const size_t w = b.c[2].Ci, co = b.c[2].Co;
+            b.alg = P.ws;
+            P.ws = align_up(P.ws + align_up(4 * co * sizeof(float)) + align_up(w * co * 2) + align_up(w * w * 2) + align_up(w * sizeof(float)));
+        }
+    }
     for (int i = 0; i < 3; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     for (int i = 0; i < 3; ++i) { t->off_dy[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     t->off_dyd = P.ws; P.ws = align_up(P.ws + t->max_act);
@@ -403,20 +415,13 @@ struct Ctx {
 // conv (+ BatchNorm statistics in train mode).  finalize_now: also run the stand-alone finalize -- needed in eval mode and
 // where the consumer of scale / shift is not vince_bn_train_apply (the stem's pool, the downsample branch's identity
 // affine); everywhere else the finalize rides in the prologue of the apply pass (bn_apply_fwd below).
-// xf_bn: the BatchNorm(+ReLU) that sits between the producer of `in` and this conv is applied to the staged input tile
-// inside this conv (vince_conv_epi.in_scale / in_shift) -- `in` is then the producer's RAW output.
 int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_off, float* const* bn_running,
-                int64_t* const* bn_nbt, int train_bn, bool finalize_now, const vince_conv_desc* desc = nullptr,
-                const BnL* xf_bn = nullptr) {
+                int64_t* const* bn_nbt, int train_bn, bool finalize_now, const vince_conv_desc* desc = nullptr) {
     vince_conv_desc d = desc ? *desc : fwd_desc(c.t, cv);
     vince_conv_epi e;
     memset(&e, 0, sizeof(e));
     e.stats = train_bn ? c.stats(bn) : nullptr;
     e.replicas = bn.R;
-    if (xf_bn) {
-        e.in_scale = c.consts(*xf_bn, 0);
-        e.in_shift = c.consts(*xf_bn, 1);
-    }
     // layer1's expand convolutions (64 -> 256, stride 1: conv3 of every block and the downsample conv) are pure HBM streams that
     // write 4x what they read: the persistent streaming kernel runs them at 4.2 TB/s (122 us) against the implicit-GEMM
     // kernel's 3.1 (166 us), statistics in registers for the whole launch.  At K = 128 (layer2) it does not win (half-line
@@ -426,11 +431,11 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
     // (the streaming kernels address their input through one 31-bit buffer descriptor: larger tensors stay on vince_conv_igemm,
     // whose register-staged kernels have no such limit)
     const bool small_in = (unsigned long long)c.t->cfg.N * cv.Hi * cv.Wi * cv.Ci * 2 < 0x7ff00000ull;
-    if (!desc && !xf_bn && train_bn && c.dtype == VINCE_BF16 && cv.k == 1 && cv.stride == 1 && cv.Ci <= xstats_max_k &&
+    if (!desc && train_bn && c.dtype == VINCE_BF16 && cv.k == 1 && cv.stride == 1 && cv.Ci <= xstats_max_k &&
         (cv.Ci == 64 || cv.Ci == 128) && cv.Co % 256 == 0 && small_in) {
         RC(vince_conv_expand_stats(c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), (int64_t)c.t->cfg.N * cv.Ho * cv.Wo, cv.Ci,
                                    cv.Co, at(c.ws, y_off), e.stats, e.replicas, c.stream));
-    } else if (strip3x3 && !desc && !xf_bn && c.dtype == VINCE_BF16 && cv.k == 3 && cv.stride == 1 && cv.Ci == 64 && cv.Co == 64 &&
+    } else if (strip3x3 && !desc && c.dtype == VINCE_BF16 && cv.k == 3 && cv.stride == 1 && cv.Ci == 64 && cv.Co == 64 &&
                cv.Wo == 56 && cv.Ho % 4 == 0 && cv.Hi == cv.Ho && cv.Wi == cv.Wo && small_in) {
         // layer1's 3x3 (conv2 of the 64-wide bottlenecks at 56 x 56): the image-strip kernel (csrc/conv3x3_strip.hip) -- input rows
         // resident in an LDS ring, each element fetched once in whole lines; bit-identical output and statistics
@@ -485,16 +490,47 @@ int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const voi
     return vince_bn_train_apply(c.dtype, at(c.ws, y_off), &bt, idn, ids, idt, out, mask_out, rows, cv.Co, 1, c.stream);
 }
 
+// BatchNorm-backward algebra (csrc/bn_algebra.hip): bf16 bottlenecks whose conv3 reduction fits the Gram scratch and the streaming
+// join kernel, every block but the last (whose output gradient arrives from the pool, not from a dgrad epilogue).
+// VINCE_BN3_ALGEBRA=0 (read per call, so one process can compare both routes): the separate BatchNorm-backward passes everywhere.
+bool alg_env() {
+    const char* v = getenv("VINCE_BN3_ALGEBRA");
+    return !(v && atoi(v) == 0);
+}
+bool alg_block(const vince_trunk* t, size_t bi) {
+    const Blk& b = t->blocks[bi];
+    return t->cfg.dtype == VINCE_BF16 && b.nconv == 3 && b.gram != NONE && b.alg != NONE && bi + 1 < t->blocks.size() &&
+           (b.c[2].Ci == 64 || b.c[2].Ci == 128) && b.c[2].Co % 256 == 0 && b.c[2].k == 1 && b.c[2].stride == 1 &&
+           (unsigned long long)t->cfg.N * b.c[2].Hi * b.c[2].Wi * b.c[2].Ci * 2 < 0x7ff00000ull;
+}
+struct AlgPtrs { float* coef; void* wd; void* nq; float* nr; };
+AlgPtrs alg_ptrs(void* ws, const Blk& b) {
+    const size_t w = b.c[2].Ci, co = b.c[2].Co;
+    unsigned char* base = (unsigned char*)at(ws, b.alg);
+    AlgPtrs a;
+    a.coef = (float*)base; base += align_up(4 * co * sizeof(float));
+    a.wd = base; base += align_up(w * co * 2);
+    a.nq = base; base += align_up(w * w * 2);
+    a.nr = (float*)base;
+    return a;
+}
+
+// out_mask / gsums: the epilogue of the BatchNorm-backward algebra (vince_conv_epi.out_mask): the stored gradient is gated by the
+// ReLU bits of the block BELOW and its per-channel sums land in gsums
 int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, const uint8_t* acc_mask = nullptr,
-          const vince_bn_reduce* bnred = nullptr, int replicas = 0) {
+          const vince_bn_reduce* bnred = nullptr, int replicas = 0, const uint8_t* out_mask = nullptr, double* gsums = nullptr) {
     // block-input gradients of layer1 / layer2 bottlenecks (conv1 = 1x1 stride 1, 4w -> w with w = 64 / 128): the expand shape
     // again, through the persistent streaming kernel (299 vs 362 us, 306 vs 383 us, 177 vs 192 us).  VINCE_XDGRAD=0: off.
     static const bool xdgrad_env = !(getenv("VINCE_XDGRAD") && atoi(getenv("VINCE_XDGRAD")) == 0);
     if (xdgrad_env && accumulate && c.dtype == VINCE_BF16 && cv.k == 1 && cv.stride == 1 && (cv.Co == 64 || cv.Co == 128) &&
         cv.Ci % 256 == 0 && !(bnred && bnred->mask_scale) &&
-        (unsigned long long)c.t->cfg.N * cv.Hi * cv.Wi * cv.Co * 2 < 0x7ff00000ull)
+        (unsigned long long)c.t->cfg.N * cv.Hi * cv.Wi * cv.Co * 2 < 0x7ff00000ull) {
+        if (out_mask)
+            return vince_conv_expand_dgrad_masked(c.dtype, dy, at((void*)c.wcache, cv.wt), (int64_t)c.t->cfg.N * cv.Hi * cv.Wi, cv.Co, cv.Ci,
+                                                  dx, 1, acc_mask, out_mask, gsums, replicas, c.stream);
         return vince_conv_expand_dgrad(c.dtype, dy, at((void*)c.wcache, cv.wt), (int64_t)c.t->cfg.N * cv.Hi * cv.Wi, cv.Co, cv.Ci, dx, 1,
                                        acc_mask, bnred, replicas, c.stream);
+    }
     vince_conv_desc ds[4];
     const int n = dgrad_descs(c.t, cv, ds);
     const int classes = cv.stride * cv.stride;
@@ -506,6 +542,8 @@ int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, co
     e.acc_mask = acc_mask;
     if (bnred) e.bnred = *bnred;
     e.replicas = replicas;
+    e.out_mask = out_mask;
+    e.stats = gsums;
     for (int i = 0; i < n; ++i) RC(vince_conv_igemm(&ds[i], c.dtype, dy, at((void*)c.wcache, cv.wt), dx, &e, c.stream));
     return VINCE_OK;
 }
@@ -720,16 +758,6 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     RC(conv_bn_fwd(c, t->stem, t->stem_bn, t->off_x0, t->off_ystem, bn_running, bn_nbt, train_bn, true, &sd));
     RC(vince_stem_pool_fwd(c.dtype, at(workspace, t->off_ystem), c.consts(t->stem_bn, 0), c.consts(t->stem_bn, 1),
                            at(workspace, t->off_p0), (uint8_t*)at(workspace, t->off_amax), N, t->sH, t->sW, 64, stream));
-    // The downsample conv of a stage-entry block depends on the block input only: it (and its BatchNorm's finalize) runs
-    // on the engine's third stream next to conv1..convL and is joined before the block's last apply (VINCE_DS_STREAM=0 or
-    // profiling: inline).
-    // No-grad forwards (save == 0: key encoder, validation in train-mode BN) fuse the bottleneck-internal BatchNorm + ReLU
-    // into the consuming conv's operand path (VINCE_XF=0: separate apply passes; off while profiling so that kernel tags
-    // keep their meaning; backward needs the materialised activations, so grad-enabled forwards never do this)
-    // opt-in (measured: neutral for 1x1 consumers, +1.2 ms/step for 3x3 ones -- the transform's LDS round trip costs more than the
-    // apply pass it removes); read per call so a test can switch it.  0 off, 1 every consumer, 2 only 1x1 consumers, 3 only 3x3
-    const int xf_mode = getenv("VINCE_XF") ? atoi(getenv("VINCE_XF")) : 0;
-    const bool fuse_xf = xf_mode != 0 && !save && !vince_profile_enabled();
     // The forward downsample conv on its own stream is OPT-IN (VINCE_DS_STREAM_FWD=1): worth 0.1 ms when it happens to share a
     // hardware queue with another stream (GPU_MAX_HW_QUEUES=4, the default), but +4 ms when every stream gets its own queue
     // (two overlapped encoders x two streams each thrash) -- the mapping depends on stream creation order, so it is not relied on.
@@ -752,15 +780,19 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // the identity tensor -- y3 is neither written nor re-read and conv3 carries no statistics epilogue (28 -> 21 tensor
     // passes per block).  Backward needs y3, so grad-enabled forwards keep the separate passes.  VINCE_GRAM_JOIN=0: off.
     static const bool gram_env = !(getenv("VINCE_GRAM_JOIN") && atoi(getenv("VINCE_GRAM_JOIN")) == 0);
-    const bool gram_nograd = gram_env && train_bn && !save && !fuse_xf && !ds_side;
+    const bool gram_nograd = gram_env && train_bn && !save && !ds_side;
     // Grad-enabled forwards CAN take the same route where the streaming kernel applies (bf16, K = 64 / 128): it writes the block
     // output AND what backward reads -- conv3's raw output and the ReLU mask bytes -- so the join pass, its re-read of y3 and
     // conv3's statistics epilogue go (17 -> 13 tensor passes for conv3 + join).  OPT-IN (VINCE_GRAM_TRAIN=1): measured neutral in
     // the full step (27.21 vs 27.28 ms: the query forward overlaps the key encoder's, both HBM-bound) while the fp32 atomics of
     // the Gram sums make bn3's constants -- and through bf16 rounding the early-layer gradients -- vary from run to run.
     static const bool xjoin_env = !(getenv("VINCE_XJOIN") && atoi(getenv("VINCE_XJOIN")) == 0);
-    const bool gram_train = gram_env && xjoin_env && (getenv("VINCE_GRAM_TRAIN") && atoi(getenv("VINCE_GRAM_TRAIN")) == 1) &&
+    // DEFAULT for bf16 training forwards since round 3 (VINCE_BN3_ALGEBRA, alg_block): the same route WITHOUT storing conv3's output
+    // -- backward no longer reads it (csrc/bn_algebra.hip) -- 17 -> 9 tensor passes for conv3 + join.
+    const bool alg_fwd = alg_env() && gram_env && xjoin_env && train_bn && save && !ds_side && c.dtype == VINCE_BF16;
+    const bool gram_train = gram_env && xjoin_env && (alg_fwd || (getenv("VINCE_GRAM_TRAIN") && atoi(getenv("VINCE_GRAM_TRAIN")) == 1)) &&
                             train_bn && save && !ds_side && c.dtype == VINCE_BF16;
+    if (save) t->fwd_alg = alg_fwd;
     const bool gram_on = gram_nograd || gram_train;
     if (gram_on && t->gram_bytes)
         RC(vince_zero_async(at(workspace, t->off_gram), t->gram_bytes, stream));
@@ -781,24 +813,15 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             RC(conv_bn_fwd(cd, b.cd, b.bd, x_in, b.yd, bn_running, bn_nbt, train_bn, true));
             VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_done, t->ds_stream));
         }
-        const BnL* pending = nullptr;   // BatchNorm + ReLU deferred into the next conv's operand path (no-grad forwards)
         const int nplain = gram_blk ? b.nconv - 1 : b.nconv;   // convs that run with their own statistics epilogue
         for (int ci = 0; ci < nplain; ++ci) {
-            const bool defer = fuse_xf && ci < b.nconv - 1 && b.c[ci].Co <= 512 &&
-                               (xf_mode == 1 || (xf_mode == 2 && b.c[ci + 1].k == 1) || (xf_mode == 3 && b.c[ci + 1].k == 3));
-            RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, defer, nullptr, pending));
-            pending = nullptr;
+            RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, false));
             if (ci < b.nconv - 1) {
-                if (defer) {   // the activation is never materialised: the consumer reads y and applies scale / shift / ReLU
-                    pending = &b.b[ci];
-                    in = b.y[ci];
-                } else {
-                    // (the pass that writes conv3's input also sums it per channel when the Gram path follows)
-                    double* osum = (gram_blk && ci == b.nconv - 2) ? (double*)at(workspace, b.colsum) : nullptr;
-                    RC(bn_apply_fwd(c, b.c[ci], b.b[ci], b.y[ci], nullptr, nullptr, nullptr, at(workspace, b.a[ci]), nullptr,
-                                    bn_running, bn_nbt, train_bn, osum));
-                    in = b.a[ci];
-                }
+                // (the pass that writes conv3's input also sums it per channel when the Gram path follows)
+                double* osum = (gram_blk && ci == b.nconv - 2) ? (double*)at(workspace, b.colsum) : nullptr;
+                RC(bn_apply_fwd(c, b.c[ci], b.b[ci], b.y[ci], nullptr, nullptr, nullptr, at(workspace, b.a[ci]), nullptr,
+                                bn_running, bn_nbt, train_bn, osum));
+                in = b.a[ci];
             }
         }
         const int L = b.nconv - 1;
@@ -833,7 +856,8 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             if (xj_ok) {
                 RC(vince_conv_expand_join(c.dtype, at(workspace, in), at((void*)wcache, cv.wk), rows, cv.Ci, cv.Co, e.out_scale, e.bias,
                                           at(workspace, idn), e.id_scale, e.id_shift, at(workspace, out),
-                                          save ? at(workspace, b.y[L]) : nullptr, save ? zmask : nullptr, 1, stream));
+                                          (save && !(alg_fwd && alg_block(t, bi))) ? at(workspace, b.y[L]) : nullptr,
+                                          save ? zmask : nullptr, 1, stream));
             } else {
                 const vince_conv_desc d3 = fwd_desc(t, cv);
                 RC(vince_conv_igemm(&d3, c.dtype, at(workspace, in), at((void*)wcache, cv.wk), at(workspace, out), &e, stream));
@@ -941,6 +965,84 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         const int64_t rows_out = (int64_t)N * last.Ho * last.Wo;
         const uint8_t* zbits = (const uint8_t*)at(workspace, b.zmask);
         const void* x_in = at(workspace, b.x_in);
+        // BatchNorm-backward algebra (csrc/bn_algebra.hip): for these blocks Z already holds g = dz * (z > 0) -- the producer's
+        // epilogue gated it with this block's ReLU bits -- and c.sums(bn_L) its per-channel sums; bn_L's backward and conv_L's
+        // gradients then need neither y_L nor a dY tensor.  alg_lo: the block BELOW is one, so THIS block's input-gradient
+        // launch gates and sums for it.
+        const bool alg = t->fwd_alg && alg_block(t, (size_t)bi);
+        const bool alg_lo = bi > 0 && t->fwd_alg && alg_block(t, (size_t)bi - 1);
+        int ci_top = L;
+        if (alg) {
+            if (b.has_ds) {
+                // downsample branch: its BatchNorm consumes the same g (already gated: no mask), with its own reduction pass
+                if (ds_overlap) {
+                    void* DYD = at(workspace, t->off_dyd);
+                    Ctx cd = c;
+                    cd.stream = (void*)t->ds_stream;
+                    VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_start, main_s));
+                    VINCE_CHECK_HIP(hipStreamWaitEvent(t->ds_stream, t->ev_ds_start, 0));
+                    if (ds_wg_pending) VINCE_CHECK_HIP(hipStreamWaitEvent(t->ds_stream, t->ev_ds_wg, 0));   // DYD still being read
+                    RC(bn_bwd(cd, b.bd, Z, nullptr, false, b.yd, rows_out, DYD, nullptr, grads, false));
+                    VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_dy, t->ds_stream));
+                    VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_ds_dy, 0));
+                    {
+                        const vince_conv_desc dd = fwd_desc(t, b.cd);
+                        RC(vince_conv_wgrad(&dd, c.dtype, x_in, DYD, grads[b.cd.param], b.cd.Ci, 0, (void*)t->side));
+                    }
+                    VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_wg, t->side));
+                    ds_wg_pending = true;
+                    RC(dgrad(cd, b.cd, DYD, DX, false));
+                    VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_done, t->ds_stream));
+                    ds_done_pending = true;
+                } else {
+                    RC(next_dy());
+                    RC(bn_bwd(c, b.bd, Z, nullptr, false, b.yd, rows_out, DY, nullptr, grads, false));
+                    RC(wgrad_layer(b.cd, x_in));
+                    RC(dgrad(c, b.cd, DY, DX, false));
+                }
+            }
+            const ConvL& cv = b.c[L];
+            const BnL& bn = b.b[L];
+            const void* a_in = at(workspace, b.a[L - 1]);
+            const void* wk = at((void*)wcache, cv.wk);
+            const AlgPtrs ap = alg_ptrs(workspace, b);
+            // R = g^T a straight into the weight-gradient buffer (on this stream: the algebra below needs it before the dgrad)
+            {
+                const vince_conv_desc dw = fwd_desc(t, cv);
+                RC(vince_conv_wgrad(&dw, c.dtype, a_in, Z, grads[cv.param], cv.Ci, 0, stream));
+            }
+            RC(vince_bn3_bwd_prepare(grads[cv.param], wk, c.sums(bn), bn.R, c.consts(bn, 2), c.consts(bn, 3), params[bn.gamma], rows_out,
+                                     cv.Co, cv.Ci, ap.coef, ap.wd, ap.nq, ap.nr, grads[bn.gamma], grads[bn.beta], stream));
+            RC(vince_bn3_bwd_finish_dw(grads[cv.param], wk, (const float*)at(workspace, b.gram), (const double*)at(workspace, b.colsum),
+                                       GRAM_R, ap.coef, c.consts(bn, 2), c.consts(bn, 3), cv.Co, cv.Ci, stream));
+            // da = (W^T diag(s)) g + nr, then da += nq a (with the fused reduction of the BatchNorm below, as the plain dgrad has it)
+            {
+                vince_conv_desc ds1[4];
+                const int n1 = dgrad_descs(t, cv, ds1);
+                if (n1 != 1) {
+                    vince_set_error("vince_trunk_backward: the BatchNorm-backward algebra expects a stride-1 1x1 convolution");
+                    return VINCE_E_UNSUPPORTED;
+                }
+                vince_conv_epi e1;
+                memset(&e1, 0, sizeof(e1));
+                e1.bias = ap.nr;
+                RC(vince_conv_igemm(&ds1[0], c.dtype, Z, ap.wd, DA, &e1, stream));
+                vince_conv_desc dq = fwd_desc(t, cv);
+                dq.Co = cv.Ci;
+                vince_conv_epi e2;
+                memset(&e2, 0, sizeof(e2));
+                e2.flags = VINCE_EPI_ACCUMULATE;
+                if (fuse_red) e2.bnred = bn_reduce_of(c, b.b[L - 1], nullptr, true, b.y[L - 1]);
+                e2.replicas = b.b[L - 1].R;
+                RC(vince_conv_igemm(&dq, c.dtype, a_in, ap.nq, DA, &e2, stream));
+            }
+            {
+                const int64_t rows = (int64_t)N * b.c[L - 1].Ho * b.c[L - 1].Wo;
+                RC(next_dy());
+                RC(bn_bwd(c, b.b[L - 1], DA, nullptr, true, b.y[L - 1], rows, DY, nullptr, grads, fuse_red));
+            }
+            ci_top = L - 1;
+        } else
         // z = relu(bn_L(y_L) + identity): g = dz * (z > 0) is the gradient of both addends
         if (b.has_ds) {
             // bn_L's backward apply also accumulates the downsample BatchNorm's reduction (same g, its own y): one pass
@@ -989,7 +1091,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             RC(next_dy());
             RC(bn_bwd(c, b.b[L], Z, zbits, false, b.y[L], rows_out, DY, nullptr, grads, last_reduced));
         }
-        for (int ci = L; ci >= 0; --ci) {
+        for (int ci = ci_top; ci >= 0; --ci) {
             const void* in_act = ci == 0 ? x_in : at(workspace, b.a[ci - 1]);
             // wgrad_late: the weight gradient of a layer starts after that layer's dgrad instead of next to it, i.e. it
             // runs beside the (HBM-bound) BatchNorm backward of the layer below (VINCE_WGRAD_LATE, measurement knob)
@@ -1004,19 +1106,27 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             } else {
                 // block-input gradient; it is the dz of the block below, whose last BatchNorm's reduction is fused here
                 vince_bn_reduce br;
-                const bool fuse = fuse_red && bi > 0;
+                const bool fuse = fuse_red && bi > 0 && !alg_lo;
                 int rr = 0;
+                const uint8_t* lo_mask = nullptr;
+                double* lo_sums = nullptr;
                 if (fuse) {
                     const Blk& lo = t->blocks[bi - 1];
                     br = bn_reduce_of(c, lo.b[lo.nconv - 1], (const uint8_t*)at(workspace, lo.zmask), false, lo.y[lo.nconv - 1]);
+                    rr = lo.b[lo.nconv - 1].R;
+                }
+                if (alg_lo) {   // the block below runs the algebra: hand it g (gated by ITS ReLU bits) and the sums of g
+                    const Blk& lo = t->blocks[bi - 1];
+                    lo_mask = (const uint8_t*)at(workspace, lo.zmask);
+                    lo_sums = c.sums(lo.b[lo.nconv - 1]);
                     rr = lo.b[lo.nconv - 1].R;
                 }
                 if (b.has_ds && ds_done_pending) {   // DX holds the downsample branch's gradient once its stream is done
                     VINCE_CHECK_HIP(hipStreamWaitEvent(main_s, t->ev_ds_done, 0));
                     ds_done_pending = false;
                 }
-                if (b.has_ds) RC(dgrad(c, b.c[0], DY, DX, true, nullptr, fuse ? &br : nullptr, rr));
-                else RC(dgrad(c, b.c[0], DY, Z, true, zbits, fuse ? &br : nullptr, rr));   // Z <- dgrad + Z * (z > 0)
+                if (b.has_ds) RC(dgrad(c, b.c[0], DY, DX, true, nullptr, fuse ? &br : nullptr, rr, lo_mask, lo_sums));
+                else RC(dgrad(c, b.c[0], DY, Z, true, alg ? nullptr : zbits, fuse ? &br : nullptr, rr, lo_mask, lo_sums));   // Z <- dgrad + Z * (z > 0) (Z already gated under the algebra)
                 if (wgrad_late) RC(wgrad_layer(b.c[0], in_act));
                 last_reduced = fuse;
             }

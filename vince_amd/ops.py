@@ -115,10 +115,10 @@ def bn_reduce_arg(y, mean, invstd, sums, mask_bits=None, mask_scale=None, mask_s
     return r
 
 
-def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None, replicas=0, in_scale=None,
-               in_shift=None, out_scale=None, id_scale=None, id_shift=None):
+def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None, replicas=0, out_scale=None,
+               id_scale=None, id_shift=None, out_mask=None):
     """vince_conv_igemm with the epilogue options of vince_conv_epi."""
-    require_gpu(x, w, out, bias, stats, acc_mask, in_scale, in_shift, out_scale, id_scale, id_shift)
+    require_gpu(x, w, out, bias, stats, acc_mask, out_scale, id_scale, id_shift, out_mask)
     e = ConvEpi()
     e.flags = flags
     e.bias = None if bias is None else bias.data_ptr()
@@ -127,11 +127,10 @@ def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, b
     if bnred is not None:
         e.bnred = bnred
     e.replicas = replicas
-    e.in_scale = None if in_scale is None else in_scale.data_ptr()   # operand transform relu(x * scale + shift)
-    e.in_shift = None if in_shift is None else in_shift.data_ptr()
     e.out_scale = None if out_scale is None else out_scale.data_ptr()   # residual join with known BatchNorm constants
     e.id_scale = None if id_scale is None else id_scale.data_ptr()
     e.id_shift = None if id_shift is None else id_shift.data_ptr()
+    e.out_mask = None if out_mask is None else out_mask.data_ptr()
     check(lib().vince_conv_igemm(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(w), _ptr(out), ctypes.byref(e),
                                  stream_ptr()))
     return out
@@ -182,6 +181,39 @@ def conv_expand_dgrad(dy, wt, out, accumulate=False, acc_mask=None, bnred=None, 
     check(lib().vince_conv_expand_dgrad(dtype_code(dy), _ptr(dy), _ptr(wt), rows, K, wt.shape[0], _ptr(out), int(accumulate),
                                         _ptr(acc_mask), ctypes.byref(bnred) if bnred is not None else None, replicas, stream_ptr()))
     return out
+
+
+def conv_expand_dgrad_masked(dy, wt, out, out_mask, gsums, accumulate=False, acc_mask=None, replicas=0):
+    """vince_conv_expand_dgrad_masked: out = (dy @ wt.T + old [gated by acc_mask]) gated by out_mask; gsums += per-channel (sum, sum sq)."""
+    require_gpu(dy, wt, out, acc_mask, out_mask, gsums)
+    rows, K = dy.numel() // dy.shape[-1], dy.shape[-1]
+    check(lib().vince_conv_expand_dgrad_masked(dtype_code(dy), _ptr(dy), _ptr(wt), rows, K, wt.shape[0], _ptr(out), int(accumulate),
+                                               _ptr(acc_mask), _ptr(out_mask), _ptr(gsums), replicas, stream_ptr()))
+    return out
+
+
+def bn3_bwd_prepare(R, w, gsums, mean, invstd, gamma, count, dgamma, dbeta):
+    """vince_bn3_bwd_prepare (csrc/bn_algebra.hip): R float[Co][K] = g^T a, w bf16 [Co][K], gsums double[replicas][Co][2].
+    Returns coef float[4][Co], wd bf16 [K][Co], nq bf16 [K][K], nr float[K]; dgamma / dbeta are accumulated in place."""
+    require_gpu(R, w, gsums, mean, invstd, gamma, dgamma, dbeta)
+    Co, K = w.shape[0], w.shape[-1]
+    dev = w.device
+    coef = torch.empty(4, Co, device=dev, dtype=torch.float32)
+    wd = torch.empty(K, Co, device=dev, dtype=torch.bfloat16)
+    nq = torch.empty(K, K, device=dev, dtype=torch.bfloat16)
+    nr = torch.empty(K, device=dev, dtype=torch.float32)
+    check(lib().vince_bn3_bwd_prepare(_ptr(R), _ptr(w), _ptr(gsums), gsums.shape[0], _ptr(mean), _ptr(invstd), _ptr(gamma), int(count),
+                                      Co, K, _ptr(coef), _ptr(wd), _ptr(nq), _ptr(nr), _ptr(dgamma), _ptr(dbeta), stream_ptr()))
+    return coef, wd, nq, nr
+
+
+def bn3_bwd_finish_dw(RdW, w, gram, colsum, coef, mean, invstd):
+    """vince_bn3_bwd_finish_dw: the raw weight gradient R becomes the weight gradient, in place."""
+    require_gpu(RdW, w, gram, colsum, coef, mean, invstd)
+    Co, K = w.shape[0], w.shape[-1]
+    check(lib().vince_bn3_bwd_finish_dw(_ptr(RdW), _ptr(w), _ptr(gram), _ptr(colsum), colsum.shape[0], _ptr(coef), _ptr(mean),
+                                        _ptr(invstd), Co, K, stream_ptr()))
+    return RdW
 
 
 def conv_wgrad(desc, x, dy, dw, ci_dw=None, variant=0):
