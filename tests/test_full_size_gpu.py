@@ -268,8 +268,24 @@ def test_g9_config3_full_size_bf16_loss_and_reported_embedding_error(tmp_path, g
     north-star 1e-3; the embedding error of the bf16 trunk is REPORTED against the fixture (printed, bounded at twice the
     measured value) -- SURVEY 8d: 'any miss reported as a number, not hidden'."""
     g = np.load(os.path.join(golden_dir, "g9_full.npz"))
-    r = _dump(tmp_path, "bf16", "bf16", {})
+    r = _dump(tmp_path, "bf16", "bf16", {}, [n for n, _, _ in G9_SAMPLED])
     np.testing.assert_allclose(float(r["loss"]), float(g["loss"]), rtol=1e-3)
+    # the bf16 trunk's GRADIENTS against the reference (VERDICT r2 weak #7): sum |g| of every tensor, direction of the sampled rows
+    gn = list(g["grad_names"])
+    ratios = {n: abs(r["grad_checksums"][i][2] / g["grad_checksums"][gn.index(n)][2] - 1) for i, n in enumerate(r["grad_names"])}
+    late = {n: v for n, v in ratios.items() if "layer4" in n or n.startswith("embedding")}
+    coss = {}
+    for n, rows, _ in G9_SAMPLED:
+        got = r["grad_" + n]
+        got = (got if rows is None else got[:rows]).astype(np.float64).ravel()
+        want = g["grad_" + n].astype(np.float64).ravel()
+        coss[n] = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-300))
+    print("G9 bf16 gradients vs reference: sum|g| rel err median %.3e, worst %.3e (%s); layer4 + head worst %.3e; sampled-row cosines: %s"
+          % (float(np.median(list(ratios.values()))), max(ratios.values()), max(ratios, key=ratios.get), max(late.values()),
+             ", ".join("%s %.4f" % (n.replace("feature_extractor.model.", ""), c) for n, c in coss.items())))
+    assert max(late.values()) < BF16_GRAD_LATE_BOUND and max(ratios.values()) < BF16_GRAD_BOUND
+    assert min(c for n, c in coss.items() if n.startswith("embedding")) > BF16_GRAD_COS_HEAD
+    assert min(c for n, c in coss.items() if "layer4" in n) > BF16_GRAD_COS_LAYER4
     err = _rel(r["embeddings"], g["embeddings"])
     kerr = _rel(r["queue_embeddings"], g["queue_embeddings"])
     e, ge = r["embeddings"].astype(np.float64), g["embeddings"].astype(np.float64)
@@ -280,7 +296,11 @@ def test_g9_config3_full_size_bf16_loss_and_reported_embedding_error(tmp_path, g
     np.testing.assert_allclose(float(r["m_nce_accuracy_mean"]), float(g["m_nce_accuracy_mean"]), atol=2e-2)
 
 
-BF16_EMB_BOUND = 0.22   # twice the measured value (0.102 queries / 0.108 keys of max|e|, min cosine 0.9954)
+BF16_EMB_BOUND = 0.16   # 1.5 x the measured value (0.102 queries / 0.108 keys of max|e|, min cosine 0.9954)
+# bf16 trunk gradients against the reference at the full size, each bound 1.5 x the measured miss: sum|g| per tensor 7.7e-2 (layer4 + head)
+# / 3.9e-1 (worst of all 161: layer2.1.bn1.bias; median 1.7e-2); direction of the sampled rows: head 0.946-0.982, layer4 0.51-0.96
+# (early layers 0.23-0.43: a freshly initialised, nearly collapsed encoder -- DESIGN section 3 "Conditioning")
+BF16_GRAD_LATE_BOUND, BF16_GRAD_BOUND, BF16_GRAD_COS_HEAD, BF16_GRAD_COS_LAYER4 = 0.12, 0.6, 0.915, 0.25
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
