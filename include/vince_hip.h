@@ -526,6 +526,10 @@ int vince_trunk_prepare_weights_folded(vince_trunk_t t, const float* const* para
                                        void* stream);
 int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, const float* input, const int64_t* perm,
                                int32_t jigsaw_src_h, int32_t jigsaw_src_w, void* workspace, float* pooled, void* stream);
+/* Host callback of vince_trunk_backward: cb(e, user) is called on the calling thread right after bucket event e (see below) has been
+ * recorded -- the data-parallel layer enqueues that bucket's gradient all-reduce behind the event at that moment, while the host is
+ * still enqueueing the rest of backward (vince_amd/dp.py).  NULL clears it. */
+int vince_trunk_set_bucket_callback(vince_trunk_t t, void (*cb)(int32_t, void*), void* user);
 /* grads: float pointers parallel to params (accumulated into; zero them first).  dpooled: float[N][C].
  * Gradient buckets for data parallelism: after the backward of residual block event_blocks[e] (blocks are numbered in
  * forward order; backward visits them last to first) has been enqueued, hipEvent_t events[e] is recorded on `stream`;

@@ -144,6 +144,7 @@ PROTOTYPES = {
     "vince_trunk_prepare_weights_folded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vince_trunk_forward_folded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                            c_void_p]),
+    "vince_trunk_set_bucket_callback": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vince_trunk_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                      c_void_p]),
     "vince_trunk_num_blocks": (c_int32, [c_void_p]),

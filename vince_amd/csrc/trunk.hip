@@ -84,6 +84,9 @@ struct vince_trunk {
     // the last grad-enabled forward took the Gram join WITHOUT storing conv3's output for the eligible blocks (alg_block): its
     // backward must run the BatchNorm-backward algebra for exactly those blocks
     bool fwd_alg = false;
+    // host callback of vince_trunk_backward: invoked right after bucket event e has been recorded (vince_trunk_set_bucket_callback)
+    void (*bucket_cb)(int32_t, void*) = nullptr;
+    void* bucket_cb_user = nullptr;
 };
 
 namespace {
@@ -353,6 +356,12 @@ extern "C" void vince_trunk_destroy(vince_trunk_t t) {
         hipStreamDestroy(t->ds_stream);
     }
     delete t;
+}
+extern "C" int vince_trunk_set_bucket_callback(vince_trunk_t t, void (*cb)(int32_t, void*), void* user) {
+    VINCE_CHECK_ARG(t, VINCE_E_ARG, "vince_trunk_set_bucket_callback: null handle");
+    t->bucket_cb = cb;
+    t->bucket_cb_user = user;
+    return VINCE_OK;
 }
 extern "C" int32_t vince_trunk_num_params(vince_trunk_t t) { return t ? t->nparams : 0; }
 extern "C" int32_t vince_trunk_num_bn(vince_trunk_t t) { return t ? t->nbn : 0; }
@@ -1143,6 +1152,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                 } else {
                     VINCE_CHECK_HIP(hipEventRecord((hipEvent_t)events[e], main_s));
                 }
+                if (t->bucket_cb) t->bucket_cb(e, t->bucket_cb_user);   // e.g. enqueue this bucket's all-reduce behind the event NOW
             }
     }
     // stem: Z = gradient wrt the pooled stem output

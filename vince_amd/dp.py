@@ -12,6 +12,8 @@ statistics, gradients reduced to device 0, heads / loss / queue on one GPU.  The
     permutation of the gathered keys;
   * BN statistics stay per rank (the reference's per-chunk statistics); EMA and SGD are replicated.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -57,7 +59,6 @@ class GradientReducer:
         51 instead of 112 MB per step at ResNet-50 -- and are summed back into the fp32 gradient buffer; an opt-in for links
         where the all-reduce does not hide under backward (the sum of `world` bf16-rounded gradients, so not the reference's
         arithmetic: off by default)."""
-        import os
         self.payload = payload or ("bf16" if os.environ.get("VINCE_DP_GRAD_BF16") == "1" else "fp32")
         self.model = model
         self.plan = bucket_plan(model, arch_layers)
@@ -69,32 +70,60 @@ class GradientReducer:
                 ev.record()          # torch creates the underlying hipEvent lazily; the engine needs a live handle
             self.done = torch.cuda.Event()
             model._bucket_events = [(blk, ev) for (blk, _, _), ev in zip(self.plan, self.events) if blk is not None]
+            # every bucket but the last is launched from INSIDE the engine's backward call, the moment its event has been recorded
+            # (engine.Trunk.set_bucket_callback): the all-reduce of layer4 + heads is queued behind its event while the host is
+            # still enqueueing layer3's backward, not after backward() has returned
+            model._bucket_hook = self._launch_bucket
+            self._launched = set()
+            self._hook_error = None
+            # VINCE_DP_TRACE_PROXY=1 (single-rank traces): a device copy of each bucket stands in for the collective, which RCCL
+            # elides at world size 1 -- so a kernel trace shows WHEN each bucket's communication slot runs relative to backward
+            self._proxy = (torch.empty_like(model._flat_grad) if os.environ.get("VINCE_DP_TRACE_PROXY") == "1" and world()[0] == 1
+                           else None)
+
+    def _reduce_bucket(self, a, b):
+        grad = self.model._flat_grad
+        if self.payload == "bf16":
+            buf = grad[a:b].to(torch.bfloat16)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            grad[a:b].copy_(buf)
+        else:
+            dist.all_reduce(grad[a:b], op=dist.ReduceOp.SUM)
+        if self.on_gpu and self._proxy is not None:
+            self._proxy[a:b].copy_(grad[a:b])
+
+    def _launch_bucket(self, e):
+        """Engine callback (bucket index e in plan order): wait for the bucket's event on the communication stream, then reduce."""
+        try:
+            blk, a, b = self.plan[e]
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(self.events[e])
+                self._reduce_bucket(a, b)
+            self._launched.add(e)
+        except BaseException as exc:        # a ctypes callback cannot propagate: reduce_after_backward re-raises
+            self._hook_error = exc
 
     def reduce_after_backward(self):
-        """Call right after loss.backward(): enqueues the bucket all-reduces (each waits for its own event) and makes
-        the compute stream wait for all of them."""
-        grad = self.model._flat_grad
-
-        def reduce_bucket(a, b):
-            if self.payload == "bf16":
-                buf = grad[a:b].to(torch.bfloat16)
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-                grad[a:b].copy_(buf)
-            else:
-                dist.all_reduce(grad[a:b], op=dist.ReduceOp.SUM)
-
+        """Call right after loss.backward(): launches whatever the engine hook has not (the stem + layer1 bucket, final only when
+        backward ends; every bucket on CPU / when the trunk was not part of this backward) and makes the compute stream wait."""
         if not self.on_gpu:
             for _, a, b in self.plan:
-                reduce_bucket(a, b)
+                self._reduce_bucket(a, b)
             return
+        if self._hook_error is not None:
+            err, self._hook_error = self._hook_error, None
+            raise err
         cur = torch.cuda.current_stream()
         tail_event = torch.cuda.Event()
         tail_event.record(cur)
         with torch.cuda.stream(self.comm_stream):
-            for (blk, a, b), ev in zip(self.plan, self.events):
-                self.comm_stream.wait_event(ev if blk is not None else tail_event)
-                reduce_bucket(a, b)
+            for e, (blk, a, b) in enumerate(self.plan):
+                if e in self._launched:
+                    continue
+                self.comm_stream.wait_event(tail_event)
+                self._reduce_bucket(a, b)
             self.done.record(self.comm_stream)
+        self._launched.clear()
         cur.wait_event(self.done)
 
 

@@ -143,6 +143,15 @@ class Trunk:
                                          ctypes.c_void_p(workspace.data_ptr()), ctypes.c_void_p(dpooled.data_ptr()),
                                          grad_ptrs, blocks, events, n, ops.stream_ptr()))
 
+    def set_bucket_callback(self, fn):
+        """fn(e) is called from inside backward() right after bucket event e has been recorded (None clears it)."""
+        if fn is None:
+            self._bucket_cb = None
+            check(lib().vince_trunk_set_bucket_callback(self._h, None, None))
+            return
+        self._bucket_cb = ctypes.CFUNCTYPE(None, ctypes.c_int32, ctypes.c_void_p)(lambda e, _user: fn(int(e)))   # kept alive here
+        check(lib().vince_trunk_set_bucket_callback(self._h, ctypes.cast(self._bucket_cb, ctypes.c_void_p), None))
+
     def spatial_view(self, workspace):
         """The trunk output inside `workspace` as an [N, C, h, w] tensor with channels_last strides (zero copy)."""
         ptr = lib().vince_trunk_spatial_ptr(self._h, ctypes.c_void_p(workspace.data_ptr()))

@@ -307,6 +307,7 @@ class VinceModel(BaseModel):
         self._segments = {"trunk": (0, offs[ntrunk]), "embedding": (offs[ntrunk], emb_end), "jigsaw": (emb_end, n_train)}
         self._touched = {"trunk": False, "embedding": False, "jigsaw": False}
         self._bucket_events = None
+        self._bucket_hook = None     # callable(e): data-parallel reducer's per-bucket launch (vince_amd/dp.py)
         # first trunk-parameter offset of every ResNet stage (gradient buckets for data parallelism)
         self._stage_offsets = {}
         for i, (name, _, _, _) in enumerate(res.plan.params):
@@ -503,6 +504,8 @@ class VinceModel(BaseModel):
         if dpool_total is None:
             return
         self._touched["trunk"] = True
+        # data parallel: the reducer's hook runs inside the engine call, right after each bucket's event is recorded
+        s["trunk"].set_bucket_callback(self._bucket_hook if self._bucket_events else None)
         s["trunk"].backward(self._param_ptrs, self._wcache, self._saved_ws, dpool_total.contiguous(), self._grad_ptrs,
                             bucket_events=self._bucket_events)
 

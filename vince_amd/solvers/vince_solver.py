@@ -96,7 +96,7 @@ class VinceSolver(BaseSolver):
                 # stream budget (include/vince_hip.h vince_set_side_streams): main, key encoder (= gradient all-reduce during
                 # backward), weight gradients, RCCL's own -- the downsample-branch stream gives its hardware queue away
                 from .._lib import lib
-                lib().vince_set_side_streams(1)
+                lib().vince_set_side_streams(int(os.environ.get("VINCE_DP_SIDE_STREAMS", "1")))   # (2: measurement, keeps the downsample stream)
                 if self.overlap_key_encoder:
                     with torch.cuda.device(self.model.device):
                         self._key_stream = torch.cuda.Stream()
