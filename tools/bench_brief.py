@@ -9,4 +9,4 @@ d = json.loads(line)
 k = d.get("kernels", {})
 r = d.get("roofline") or {}
 print(sys.argv[2] if len(sys.argv) > 2 else src, d["value"], d["ms_per_step"], r.get("achieved"), r.get("frac"),
-      d.get("fwd_infonce"), d.get("inference_extract_features"), {n: (v["ms_per_step"], v["tflops"]) for n, v in k.items()})
+      d.get("fwd_infonce"), d.get("inference_extract_features"), {n: (v["ms_per_step"], v.get("tflops", v.get("gbs"))) for n, v in k.items()})

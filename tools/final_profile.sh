@@ -29,6 +29,7 @@ cat $O/pmc_summary.txt | head -12
 bash tools/aug_profile.sh > /dev/null 2>&1; cp gpurun_out/aug_kstats.txt $O/input_stage_kernel_stats.txt
 timeout 300 python bench.py --no-extras --input u8aug > $O/bench_u8aug.json 2>/dev/null
 timeout 20 python tools/bench_brief.py $O/bench_u8aug.json u8aug
+export VINCE_GIT_HEAD=${VINCE_GIT_HEAD:-unknown}
 # the bench line once more, now that profiles/pmc_conv_igemm.json of THIS build exists (traffic_stale false)
 cp $O/pmc_conv_igemm.json profiles/pmc_conv_igemm.json
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err

@@ -103,9 +103,28 @@ class GradientReducer:
         except BaseException as exc:        # a ctypes callback cannot propagate: reduce_after_backward re-raises
             self._hook_error = exc
 
+    def sync_extra_parameters(self, params):
+        """Parameters outside the flat buffer (the optional ImageNet side decoders, vince_model.py:79-90 of the reference): their
+        per-rank nn.Linear initialisation is replaced by rank 0's, and reduce_after_backward averages their gradients -- otherwise
+        the replicas drift apart and rank 0's checkpoint is not the model the other ranks trained."""
+        self.extra = [p for p in params]
+        if world()[0] > 1:
+            for p in self.extra:
+                dist.broadcast(p.data, src=0)
+
+    def _reduce_extra(self):
+        w = world()[0]
+        if w == 1:
+            return
+        for p in getattr(self, "extra", ()):
+            if p.grad is not None:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                p.grad.div_(w)
+
     def reduce_after_backward(self):
         """Call right after loss.backward(): launches whatever the engine hook has not (the stem + layer1 bucket, final only when
         backward ends; every bucket on CPU / when the trunk was not part of this backward) and makes the compute stream wait."""
+        self._reduce_extra()
         if not self.on_gpu:
             for _, a, b in self.plan:
                 self._reduce_bucket(a, b)

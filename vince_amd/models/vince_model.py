@@ -351,8 +351,13 @@ class VinceModel(BaseModel):
         self._grad_zero_pending = True
         self._touched = {"trunk": False, "embedding": False, "jigsaw": False}
         if hasattr(self, "imagenet_decoders"):
+            # torch 1.4 (the reference's pin) zeroes in place: a decoder that has received a gradient once keeps a zero .grad and is
+            # stepped (weight decay + momentum) on every later iteration, also on batches without labelled data -- the same rule
+            # FlatSGD applies to the heads inside the flat buffer (optim.py `_ever_touched`)
             for p in self.imagenet_decoders.parameters():
-                p.grad = None
+                if p.grad is not None:
+                    p.grad.detach_()
+                    p.grad.zero_()
 
     def flat_parameters(self):
         """(flat params, flat grads, trainable length, ema length) for the fused optimiser / EMA / all-reduce."""

@@ -104,6 +104,8 @@ class VinceSolver(BaseSolver):
             self.reducer = dp.GradientReducer(self.model, ARCH_LAYERS[self.model.feature_extractor.arch], comm_stream=comm,
                                               payload=getattr(self.args, "dp_grad_payload", None))
             self.optimizer.grad_scale = 1.0 / w
+            if hasattr(self.model, "imagenet_decoders"):
+                self.reducer.sync_extra_parameters(self.model.imagenet_decoders.parameters())
         self.print_optimizer()
 
     def setup_model(self):

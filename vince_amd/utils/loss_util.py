@@ -29,7 +29,8 @@ def _mask_from_spec(spec, device):
 
 
 class _SceRowsFn(torch.autograd.Function):
-    last_neg_sum = None   # the row kernel's exp-sum over non-mask columns of the latest forward (USE_FLOAT fill values)
+    """Returns (dists, softmax weights, neg_sum); neg_sum -- the row kernel's exp-sum over the non-mask columns, relative to the
+    row maximum -- is an extra non-differentiable output (the USE_FLOAT fill values), so every call owns its own."""
 
     @staticmethod
     def forward(ctx, sims, mask_u8, p, inv_t):
@@ -42,12 +43,12 @@ class _SceRowsFn(torch.autograd.Function):
         check(lib().vince_sce_rows_fwd(ops._ptr(sc), ops._ptr(mask_u8), b, cols, p, inv_t, ops._ptr(dists), ops._ptr(sw),
                                        ops._ptr(rmax), ops._ptr(nsum), ops.stream_ptr()))
         ctx.saved = (sc, mask_u8, p, inv_t, rmax, nsum)
-        _SceRowsFn.last_neg_sum = nsum
-        ctx.mark_non_differentiable(sw)
-        return dists, sw
+        ns_out = nsum.clone()
+        ctx.mark_non_differentiable(sw, ns_out)
+        return dists, sw, ns_out
 
     @staticmethod
-    def backward(ctx, g_dists, _g_sw):
+    def backward(ctx, g_dists, _g_sw, _g_ns):
         sc, mask_u8, p, inv_t, rmax, nsum = ctx.saved
         b, cols = sc.shape
         dsims = torch.empty_like(sc)
@@ -82,7 +83,7 @@ def similarity_cross_entropy(similarities, temperature, n_feat, n_rows1, mask=No
                            "USE_FLOAT = False for this process (reference loss_util.py:28-29,38-39); set loss_util.USE_FLOAT = None")
     b, cols = similarities.shape
     # one row kernel for both paths: positives compacted per row to [b, p] (rows with fewer positives leave zeros at the end)
-    dists_c, sw_c = _SceRowsFn.apply(similarities.float(), mask.to(torch.uint8).contiguous(), p, 1.0 / temperature)
+    dists_c, sw_c, neg_sum = _SceRowsFn.apply(similarities.float(), mask.to(torch.uint8).contiguous(), p, 1.0 / temperature)
     if not USE_FLOAT:
         dists = dists_c.view(n_feat, n_rows1, p)
         sw = sw_c.view(n_feat, n_rows1, p)
@@ -91,7 +92,6 @@ def similarity_cross_entropy(similarities, temperature, n_feat, n_rows1, mask=No
     # dists = -(-2**20 - log(neg_sum)) in fp32 and weights = exp(-2**20 - ...) = 0
     rank = torch.cumsum(mask.to(torch.int64), dim=1) - 1                       # position of each positive inside its row
     rows = torch.arange(b, device=mask.device).unsqueeze(1).expand_as(mask)
-    neg_sum = _SceRowsFn.last_neg_sum                                             # [b], exp-sum over the non-mask columns
     fill = -(torch.full((b, 1), -2.0 ** 20, device=mask.device) - torch.log(neg_sum.view(b, 1)))
     dists = fill.expand(b, cols).clone()
     sw = torch.zeros(b, cols, device=mask.device)
