@@ -141,6 +141,12 @@ typedef struct vince_conv_epi {
      * `stats` then holds its per-channel sums -- what the BatchNorm-backward algebra of the block below needs
      * (vince_bn3_bwd_prepare) instead of a pass over that block's conv output. */
     const uint8_t* out_mask;
+    /* A reduction split over TWO input tensors: the LAST tap (index TA*TB - 1; needs TA*TB >= 2) reads in2 -- same N x Hi x Wi, with
+     * in2_channels <= Ci channels per pixel (its own row stride) -- instead of `in`; the weights stay [Co][WT][Ci] with only the
+     * first in2_channels entries of that tap's block used.  With all tap displacements zero this is  out = W1 in + W2 in2  in one
+     * launch (the input gradient of the BatchNorm-backward algebra: da = wd g + nq a, csrc/bn_algebra.hip).  Direct-to-LDS kernels only. */
+    const void* in2;
+    int32_t in2_channels;
 } vince_conv_epi;
 
 /* in/w/out have element type `dtype`.  epi may be NULL (plain store). */
@@ -256,13 +262,13 @@ int vince_bn_gram_finalize(int dtype, const float* gram, const double* colsum, i
  * gated by its ReLU, R = g^T a (vince_conv_wgrad with dy := g) and the per-channel sums of g:
  *   coef[4][Co] = s = gamma*invstd, c1 = mean g, c2 = mean g*xhat = invstd (<W[c,:], R[c,:]> - mean sum g) / count, t = s*c2*invstd
  *   dgamma += count*c2, dbeta += count*c1
- *   wd [K][Co] bf16 = W^T diag(s)          -- weights of the input-gradient launch   da  = wd g + nr   (bias nr)
- *   nq [K][K]  bf16 = -W^T diag(t) W       -- weights of the correction launch       da += nq a
+ *   wd [K][Co] bf16 = W^T diag(s)  and  nq [K][K] bf16 = -W^T diag(t) W  (row strides wd_ld / nq_ld in elements): the weights of
+ *                     da = wd g + nq a + nr -- ONE launch when interleaved as the two taps [K][2][Co] of vince_conv_epi.in2
  *   nr [K]     f32  = -sum_c W[c][k] (s c1 - t mean)
  * w is the bf16 [Co][K] copy the forward multiplied with; gsums double[replicas][Co][2] (first of each pair = sum of g). K <= 128. */
 int vince_bn3_bwd_prepare(const float* R, const void* w_bf16, const double* gsums, int32_t replicas, const float* mean,
                           const float* invstd, const float* gamma, int64_t count, int32_t Co, int32_t K, float* coef, void* wd,
-                          void* nq, float* nr, float* dgamma, float* dbeta, void* stream);
+                          int32_t wd_ld, void* nq, int32_t nq_ld, float* nr, float* dgamma, float* dbeta, void* stream);
 /* ... and the weight gradient, in place of R:  dW = diag(s) (R - c1 A^T - diag(c2 invstd) (W G - mean A^T)),  G = a^T a (float[K][K], the
  * Gram matrix the forward's statistics came from, vince_bn_gram_finalize), A = column sums of a (double[colsum_replicas][K]). */
 int vince_bn3_bwd_finish_dw(float* RdW, const void* w_bf16, const float* gram, const double* colsum, int32_t colsum_replicas,

@@ -1,6 +1,6 @@
 """Helper of tests/test_full_size_gpu.py: ONE grad-enabled forward + InfoNCE + backward of BASELINE config 3 (ResNet-50,
 B=256, 224x224, K=65536, D=128, T=0.2) on the G9 inputs, dumped as an .npz.  Run as a child process so that the engine's
-environment switches (VINCE_WGRAD_STREAM, VINCE_DS_STREAM, ... -- read once per process) can differ between two runs.
+environment switches (VINCE_KNOBS="wgrad_stream=0,ds_stream=0,...", VINCE_OVERLAP_KEY -- read once per process) can differ between two runs.
 usage: full_size_grad_dump.py <out.npz> <bf16|fp32>"""
 import os
 import sys

@@ -305,7 +305,7 @@ BF16_GRAD_LATE_BOUND, BF16_GRAD_BOUND, BF16_GRAD_COS_HEAD, BF16_GRAD_COS_LAYER4 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_full_size_backward_serialised_vs_overlapped_streams(tmp_path, dtype):
-    """N=256 backward with every engine stream serialised (VINCE_WGRAD_STREAM=0, VINCE_DS_STREAM=0, key encoder inline)
+    """N=256 backward with every engine stream serialised (VINCE_KNOBS="wgrad_stream=0,ds_stream=0", key encoder inline)
     against the shipped arrangement (weight gradients, downsample branch and key encoder on their own streams, 3-slot dY
     ring).  A stream race is size-dependent and moves gradients by O(1); what legitimately differs is summation order --
     fp32 atomics (1e-6) and, at the four stage-entry blocks, which of the two branch gradients is stored first and which is
@@ -316,9 +316,9 @@ def test_full_size_backward_serialised_vs_overlapped_streams(tmp_path, dtype):
     # bf16: the key encoder's Gram-statistics join sums with fp32 atomics -- 1e-7 on bn3's constants from run to run, which bf16
     # rounding and this ill-conditioned start amplify to percents in early-layer gradients; off here so that what is left is
     # the stream arrangement alone (the fp32 run keeps it on)
-    common = {"VINCE_GRAM_JOIN": "0"} if dtype == "bf16" else {}
-    a = _dump(tmp_path, "ser", dtype, dict(common, VINCE_WGRAD_STREAM="0", VINCE_DS_STREAM="0", VINCE_OVERLAP_KEY="0"), sampled)
-    b = _dump(tmp_path, "ovl", dtype, common, sampled)
+    common = "gram_join=0," if dtype == "bf16" else ""
+    a = _dump(tmp_path, "ser", dtype, dict(VINCE_KNOBS=common + "wgrad_stream=0,ds_stream=0", VINCE_OVERLAP_KEY="0"), sampled)
+    b = _dump(tmp_path, "ovl", dtype, {"VINCE_KNOBS": common} if common else {}, sampled)
     # (fp32 atomics of the weight-gradient kernel also feed the Gram statistics: run-to-run 1e-7 on bn3's constants, which a
     # bf16 trunk turns into rounding flips)
     assert float(a["loss"]) == pytest.approx(float(b["loss"]), rel=1e-6)

@@ -242,7 +242,7 @@ def test_g5_first_step_vs_reference_golden(mode):
     pcs = np.array([vo.tensor_checksum(p.detach().cpu().contiguous())[2] for _, p in model.named_parameters()])
     # Stem-adjacent gradients of a freshly initialised (nearly collapsed) encoder are ill-conditioned: two fp32 summation
     # orders of the SAME stem convolution (outputs equal to 3e-6) move conv1 / bn1 / layer1.0 gradients by ~5e-3
-    # element-wise while layer4 and head gradients stay within 1e-5 (tools/debug_stem.py, VINCE_STEM_PACKED=0 vs 1).  The
+    # element-wise while layer4 and head gradients stay within 1e-5 (tools/debug_stem.py, VINCE_KNOBS=stem_packed=0 vs 1).  The
     # updated conv1 / bn1 parameters are therefore held to 2e-3, everything else to 1e-4.
     names = [n for n, _ in model.named_parameters()]
     stem = np.array([n.startswith("feature_extractor.model.conv1") or n.startswith("feature_extractor.model.bn1") for n in names])
@@ -843,12 +843,12 @@ def test_g7_per_rank_computation_vs_reference_chunkwise_emulation(world):
 @pytest.mark.parametrize("dtype,arch", [("fp32", "ResNet50"), ("bf16", "ResNet50")])
 def test_gram_statistics_join_equals_separate_passes_in_the_model(monkeypatch, dtype, arch):
     """No-grad train-mode forwards (the key encoder, forward + InfoNCE) take the Gram-statistics residual join in layer1 /
-    layer2 (csrc/trunk.hip gram_on); VINCE_GRAM_JOIN=0 runs the separate passes.  Same embeddings, same running statistics;
+    layer2 (csrc/trunk.hip gram_on); VINCE_KNOBS=gram_join=0 runs the separate passes.  Same embeddings, same running statistics;
     and the fp32 run still reproduces the reference's G3 goldens."""
     g = load("g3_trunk.npz")
     outs, stats = {}, {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("VINCE_GRAM_JOIN", mode)
+        monkeypatch.setenv("VINCE_KNOBS", "gram_join=%s" % mode)
         _, model = build(arch, 128, dtype, 11)
         model.train()
         x = vo.structured_frames(2, 224, 224, seed=500 + 224).to(DEV)
@@ -871,7 +871,7 @@ def test_gram_statistics_join_equals_separate_passes_in_the_model(monkeypatch, d
 
 def test_gram_statistics_join_in_the_training_forward_equals_separate_passes(monkeypatch):
     """Grad-enabled bf16 forwards run layer1 / layer2's conv3 + bn3 + join through the streaming kernel with the Gram
-    statistics (VINCE_GRAM_TRAIN=1, opt-in); backward then reads the y3 / mask / mean / invstd that kernel and the Gram
+    statistics (VINCE_KNOBS=gram_train=1 with bn3_algebra=0; the algebra route of the next test is the default); backward then reads the y3 / mask / mean / invstd that kernel and the Gram
     finalize left.  Two bf16 arrangements differ from each other by bf16 noise, which a freshly initialised 16-block
     BatchNorm chain amplifies, so both are held against the fp32 trunk: the new arrangement must be as
     close to it as the separate passes are -- embeddings, gradient norms everywhere, gradient direction where the fp32 / bf16
@@ -883,7 +883,7 @@ def test_gram_statistics_join_in_the_training_forward_equals_separate_passes(mon
              "feature_extractor.model.conv1.weight", "embedding.2.weight")
     res = {}
     for tag, dtype, mode in (("ref", "fp32", "1"), ("new", "bf16", "1"), ("old", "bf16", "0")):
-        monkeypatch.setenv("VINCE_GRAM_TRAIN", mode)
+        monkeypatch.setenv("VINCE_KNOBS", "bn3_algebra=0,gram_train=%s" % mode)
         _, model = build("ResNet50", 128, dtype, 11)
         model.train()
         x = vo.structured_frames(16, 128, 128, seed=77).to(DEV)
@@ -911,7 +911,7 @@ def test_gram_statistics_join_in_the_training_forward_equals_separate_passes(mon
 
 
 def test_bn3_backward_algebra_in_the_model_vs_separate_passes(monkeypatch):
-    """The default bf16 training route since round 3 (csrc/bn_algebra.hip; VINCE_BN3_ALGEBRA=0 restores the separate passes): layer1 /
+    """The default bf16 training route since round 3 (csrc/bn_algebra.hip; VINCE_KNOBS=bn3_algebra=0 restores the separate passes): layer1 /
     layer2 bottlenecks run conv3 + bn3 + join in one streaming launch that does NOT store conv3's output, and backward gets bn3's
     gradients through the convolution algebraically.  Same three-way comparison as the Gram-join test above: fp32 trunk as the reference,
     the algebra route must sit as close to it as the separate passes do -- embeddings, gradient norms everywhere (incl. layer1 / layer2
@@ -924,7 +924,7 @@ def test_bn3_backward_algebra_in_the_model_vs_separate_passes(monkeypatch):
              "feature_extractor.model.conv1.weight", "embedding.2.weight")
     res = {}
     for tag, dtype, mode in (("ref", "fp32", "1"), ("new", "bf16", "1"), ("old", "bf16", "0")):
-        monkeypatch.setenv("VINCE_BN3_ALGEBRA", mode)
+        monkeypatch.setenv("VINCE_KNOBS", "bn3_algebra=%s" % mode)
         _, model = build("ResNet50", 128, dtype, 11)
         model.train()
         x = vo.structured_frames(16, 128, 128, seed=77).to(DEV)

@@ -280,25 +280,25 @@ def _rerun_conv_tests(extra_env, select="test_conv_fwd_stats or test_conv_dgrad_
 def test_conv_suite_through_the_register_staged_fallback():
     """Tensors beyond the 31-bit buffer offsets of the direct-to-LDS kernels (> 2 GiB) take the register-staged conv and
     wgrad kernels; no test tensor is that large, so the same parity tests are re-run with those kernels forced."""
-    _rerun_conv_tests({"VINCE_DLDS_MIN_K": "1000000000", "VINCE_WGRAD_DLDS": "0"})
+    _rerun_conv_tests({"VINCE_KNOBS": "dlds_min_k=1000000000,wgrad_dlds=0"})
 
 
 def test_conv_suite_through_the_256_pixel_tiles():
     """The 256-pixel tile kernels (128ch x 256px for K >= 1024, 64ch x 256px for the stem / layer1) are only selected at
     benchmark-sized pixel counts; their selection thresholds are read from the environment once per process, so the conv
     parity tests of this file are re-run in a child process that forces both onto every shape."""
-    _rerun_conv_tests({"VINCE_BIG_MIN_K": "1", "VINCE_BIG_MIN_TILES": "1", "VINCE_NARROW256_MIN_TILES": "1"},
+    _rerun_conv_tests({"VINCE_KNOBS": "big_min_k=1,big_min_tiles=1,narrow256_min_tiles=1"},
                       "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem")
 
 
 def test_conv_suite_through_the_rotated_main_loop():
-    """The rotated main loop (fragment reads one MFMA phase ahead, across the tile barrier; VINCE_ROT bit per tile shape) is the
+    """The rotated main loop (fragment reads one MFMA phase ahead, across the tile barrier; VINCE_KNOBS rot = bit per tile shape) is the
     default only for the 256x128 and the 3-stage tiles, which small test shapes do not reach: the conv parity tests are
     re-run with every bit set, once on the 128-pixel tiles (K thresholds lowered so the 3-stage ring is taken too) and once
     with the 256-pixel tiles forced."""
-    _rerun_conv_tests({"VINCE_ROT": "15", "VINCE_S3_MIN_K": "512"},
+    _rerun_conv_tests({"VINCE_KNOBS": "rot=15,s3_min_k=512"},
                       "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem")
-    _rerun_conv_tests({"VINCE_ROT": "15", "VINCE_BIG_MIN_K": "1", "VINCE_BIG_MIN_TILES": "1", "VINCE_NARROW256_MIN_TILES": "1"},
+    _rerun_conv_tests({"VINCE_KNOBS": "rot=15,big_min_k=1,big_min_tiles=1,narrow256_min_tiles=1"},
                       "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_stem")
 
 
@@ -308,14 +308,14 @@ def test_conv_suite_through_the_8_wavefront_core():
     and Ci % 64 == 0 (forward) or the transposed condition (input gradient, with the join / BatchNorm-reduction epilogues) goes
     through it, and once more with it switched off (the default run mixes both)."""
     sel = "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_conv_random_shapes_fwd_dgrad_wgrad"
-    _rerun_conv_tests({"VINCE_M8_MIN_K": "1", "VINCE_M8_MIN_TILES": "1"}, sel)
-    _rerun_conv_tests({"VINCE_M8": "0"}, "test_conv_fwd_stats or test_conv_dgrad_wgrad")
+    _rerun_conv_tests({"VINCE_KNOBS": "m8_min_k=1,m8_min_tiles=1"}, sel)
+    _rerun_conv_tests({"VINCE_KNOBS": "m8=0"}, "test_conv_fwd_stats or test_conv_dgrad_wgrad")
 
 
 def test_conv_suite_through_whole_line_k_rows():
-    """128-byte K rows (KC = 8) are taken by 1x1 reductions of at least VINCE_KC8_MIN_K elements (2048 by default): re-run
+    """128-byte K rows (KC = 8) are taken by 1x1 reductions of at least kc8_min_k (VINCE_KNOBS) elements (2048 by default): re-run
     with the threshold at 64 so that every 1x1 test shape goes through them, forward and input gradient."""
-    _rerun_conv_tests({"VINCE_KC8_MIN_K": "64"}, "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_linear_fwd_bwd")
+    _rerun_conv_tests({"VINCE_KNOBS": "kc8_min_k=64"}, "test_conv_fwd_stats or test_conv_dgrad_wgrad or test_linear_fwd_bwd")
 
 
 @pytest.mark.parametrize("rows,cin,cout", [(37, 512, 64), (256, 2048, 2048), (256, 2048, 128), (64, 1000, 96)])
@@ -772,9 +772,9 @@ def test_conv3x3_image_strip_kernel(N, H):
 
 
 def test_conv3x3_image_strip_kernel_several_images_per_workgroup():
-    """The ring restarts per image: with fewer workgroups than images (VINCE_STRIP_GRID, read once per process) every workgroup
+    """The ring restarts per image: with fewer workgroups than images (VINCE_KNOBS strip_grid, read once per process) every workgroup
     walks several images -- re-run the parity test above in a child process with 2 workgroups."""
-    _rerun_conv_tests({"VINCE_STRIP_GRID": "2"}, "test_conv3x3_image_strip_kernel and not several")
+    _rerun_conv_tests({"VINCE_KNOBS": "strip_grid=2"}, "test_conv3x3_image_strip_kernel and not several")
 
 
 @pytest.mark.parametrize("rows,K,Co", [(4 * 14 * 14, 64, 256), (128 * 9 + 77, 64, 512), (3 * 28 * 28, 128, 512), (50, 128, 256)])
@@ -922,16 +922,24 @@ def test_bn3_backward_algebra_vs_autograd(w, rows):
     gs[1, :, 0] = gb.double().sum(0)
     dgam, dbet = torch.zeros(Co, device=DEV), torch.zeros(Co, device=DEV)
     mean32, invstd32 = mu.detach().float().to(DEV), invstd.detach().float().to(DEV)
-    coef, wd, nq, nr = ops.bn3_bwd_prepare(R.view(Co, w), Wb, gs, mean32, invstd32, gamma.to(DEV), rows, dgam, dbet)
+    coef, w2, nr = ops.bn3_bwd_prepare(R.view(Co, w), Wb, gs, mean32, invstd32, gamma.to(DEV), rows, dgam, dbet)
     ops.bn3_bwd_finish_dw(R.view(Co, w), Wb, gram.view(w, w), colsum, coef, mean32, invstd32)
 
     def relerr(x, ref):
         return float((x.double().cpu() - ref).abs().max() / ref.abs().max())
     assert relerr(dgam, g64.grad) < 2e-3 and relerr(dbet, b64.grad) < 2e-3, (relerr(dgam, g64.grad), relerr(dbet, b64.grad))
     assert relerr(R.view(Co, w), W64.grad) < 5e-3, relerr(R.view(Co, w), W64.grad)
+    # the input gradient in ONE launch: the reduction runs over g's Co channels (tap 0) and then over a's w channels (tap 1 = in2)
     da = torch.empty(rows, w, device=DEV, dtype=torch.bfloat16)
-    dd = ops.conv_desc(1, rows, 1, Co, w, 1, 1, 0)
-    ops.conv_igemm(dd, gb.view(1, rows, 1, Co), wd.view(w, 1, Co), da.view(1, rows, 1, w), bias=nr)
-    ops.conv_igemm(dgr, ab.view(1, rows, 1, w), nq.view(w, 1, w), da.view(1, rows, 1, w), flags=ops.EPI_ACCUMULATE)
+    from vince_amd._lib import ConvDesc
+    dd = ConvDesc(N=1, Hi=rows, Wi=1, Ci=Co, Ho=rows, Wo=1, Co=w, sh=1, sw=1, TA=1, TB=2, dh0=0, dhs=1, dw0=0, dws=0, wt0=0, wta=0,
+                  wtb=1, WT=2, OH=rows, OW=1, osh=1, osw=1, oh0=0, ow0=0)
+    ops.conv_igemm(dd, gb.view(1, rows, 1, Co), w2, da.view(1, rows, 1, w), bias=nr, in2=ab.view(1, rows, 1, w))
+    # ... equals the two launches it replaces (wd g + nr, then += nq a) up to one bf16 rounding of the intermediate
+    da2 = torch.empty_like(da)
+    ops.conv_igemm(ops.conv_desc(1, rows, 1, Co, w, 1, 1, 0), gb.view(1, rows, 1, Co), w2[:, 0].contiguous().view(w, 1, Co),
+                   da2.view(1, rows, 1, w), bias=nr)
+    ops.conv_igemm(dgr, ab.view(1, rows, 1, w), w2[:, 1, :w].contiguous().view(w, 1, w), da2.view(1, rows, 1, w), flags=ops.EPI_ACCUMULATE)
+    assert relerr(da.float(), da2.float().double().cpu()) < 1.2e-2
     e_da = relerr(da.float(), a64.grad)
     assert e_da < 2e-2, e_da

@@ -7,12 +7,12 @@ timeout 20 python tools/bench_brief.py $O/bench.json bench
 # per-layer roofline table of every conv launch of the instrumented steps (bench.py --profile-steps, default 3)
 timeout 60 python tools/layer_roofline.py $O/layers.csv 3 > $O/layer_roofline.txt 2>&1
 # the no-grad forward alone (the forward + InfoNCE leg's trunk)
-bash tools/fwd_kstats.sh VINCE_GRAM_JOIN=1 VINCE_GRAM_JOIN=0 > $O/fwd_ms.txt 2>&1; cp gpurun_out/r2/fwd_kstats_1.txt $O/fwd_kernel_stats.txt; cp gpurun_out/r2/fwd_kstats_2.txt $O/fwd_kernel_stats_separate_passes.txt
+bash tools/fwd_kstats.sh VINCE_KNOBS=gram_join=1 VINCE_KNOBS=gram_join=0 > $O/fwd_ms.txt 2>&1; cp gpurun_out/r2/fwd_kstats_1.txt $O/fwd_kernel_stats.txt; cp gpurun_out/r2/fwd_kstats_2.txt $O/fwd_kernel_stats_separate_passes.txt
 timeout 600 rocprofv3 --kernel-trace -d $O/kt -o kt -- python bench.py --no-extras > $O/kt.log 2>&1
 DB=$(find $O/kt -name '*.db' | head -1); timeout 60 python tools/rocpd_stats.py $DB 45 > $O/kernel_stats.txt 2>&1; rm -rf $O/kt
 # the same with every stream serialised (one kernel at a time, like the instrumented steps behind bench.py's `roofline`): the
 # per-kernel average durations of THIS file are the ones that agree with roofline.avg_us
-VINCE_OVERLAP_KEY=0 VINCE_WGRAD_STREAM=0 VINCE_DS_STREAM=0 timeout 600 rocprofv3 --kernel-trace -d $O/kts -o kt -- python bench.py --no-extras > $O/kts.log 2>&1
+VINCE_OVERLAP_KEY=0 VINCE_KNOBS=wgrad_stream=0,ds_stream=0 timeout 600 rocprofv3 --kernel-trace -d $O/kts -o kt -- python bench.py --no-extras > $O/kts.log 2>&1
 DB=$(find $O/kts -name '*.db' | head -1); timeout 60 python tools/rocpd_stats.py $DB 45 > $O/kernel_stats_serialised.txt 2>&1; rm -rf $O/kts
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --steps 2 --warmup 1 --no-extras > $O/pmc_$C.log 2>&1

@@ -10,9 +10,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 HBM = float(sys.argv[3]) if len(sys.argv) > 3 else 5.28
 PEAK = 2500.0
-names = ["ig %s/%s%s" % (t, sh, e) for t in ("f32", "bf16") for sh in ("64", "64x256", "128", "128x256") for e in ("", " bwd")] + ["wg f32", "wg bf16"]
+names = ["ig %s/%s%s" % (t, sh, e) for t in ("f32", "bf16") for sh in ("64", "64x256", "128", "128x256") for e in ("", " bwd")] + ["wg f32", "wg bf16", "m8 bf16/256x256", "m8 bf16/256x256 bwd"]
 agg = collections.OrderedDict()
 for r in rows:
+    if int(r["tag"]) >= len(names) or int(r["taps"]) == 0:     # streaming families (bytes, not conv shapes): bench.py's `kernels` has them
+        continue
     key = (int(r["tag"]), int(r["M"]), int(r["Co"]), int(r["K"]), int(r["taps"]), int(r["stride"]), int(r["flags"]))
     a = agg.setdefault(key, [0, 0.0, 0.0])
     a[0] += 1
@@ -22,7 +24,7 @@ print("%-18s %8s %5s %5s %4s %4s %6s %8s %8s %8s %7s %7s %7s %6s %s" % (
     "kernel", "M", "Co", "K", "taps", "s/os", "n/step", "GFLOP", "MB", "us", "TF/s", "TB/s", "%MFMA", "%HBM", "bound (roof time us)"))
 tot = tot_roof = 0.0
 for (tag, M, Co, K, taps, so, fl), (n, us, w) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    esz = 4 if tag < 8 else 2
+    esz = 4 if (tag < 8 or tag == 16) else 2
     t_us = us / n
     tf = w / us
     gflop = tf * t_us * 1e-3        # TFLOP/s * us = MFLOP -> GFLOP

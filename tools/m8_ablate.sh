@@ -3,7 +3,7 @@
 # then SQ counters of the full kernel.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-export VINCE_HIP_LIB=$R/vince_amd/lib/libvince_hip_measure.so VINCE_M8_MIN_K=1 VINCE_M8_MIN_TILES=1
+export VINCE_HIP_LIB=$R/vince_amd/lib/libvince_hip_measure.so VINCE_KNOBS=m8_min_k=1,m8_min_tiles=1
 OUT=$R/gpurun_out/m8_ablate.txt
 : > $OUT
 FIRST="$1"

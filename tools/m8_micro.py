@@ -1,7 +1,7 @@
 """conv_m8 (8-wavefront 256 x 256 core) against conv_igemm's own tiles, layer by layer at the benchmark batch.
 
-    VINCE_M8=0 python tools/m8_micro.py save /tmp/m8ref     # reference outputs + timings of the 4-wavefront tiles
-    VINCE_M8=1 python tools/m8_micro.py check /tmp/m8ref    # the same launches through conv_m8: bitwise comparison + timings
+    VINCE_KNOBS=m8=0 python tools/m8_micro.py save /tmp/m8ref     # reference outputs + timings of the 4-wavefront tiles
+    VINCE_KNOBS=m8_min_k=1,m8_min_tiles=1 python tools/m8_micro.py check /tmp/m8ref    # the same launches through conv_m8: bitwise comparison + timings
 
 Each shape runs `reps` times and every repetition is compared (a race in the LDS-DMA pipeline shows up as a rare mismatch)."""
 import os

@@ -25,7 +25,7 @@ class BnReduce(ctypes.Structure):
 class ConvEpi(ctypes.Structure):
     _fields_ = [("flags", c_int32), ("bias", c_void_p), ("stats", c_void_p), ("acc_mask", c_void_p),
                 ("bnred", BnReduce), ("replicas", c_int32),
-                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p), ("out_mask", c_void_p)]
+                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p), ("out_mask", c_void_p), ("in2", c_void_p), ("in2_channels", c_int32)]
 
 
 class BnTrain(ctypes.Structure):
@@ -61,7 +61,7 @@ PROTOTYPES = {
     "vince_conv_expand_dgrad_masked": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_void_p, c_void_p,
                                                c_void_p, c_int32, c_void_p]),
     "vince_bn3_bwd_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
-                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vince_bn3_bwd_finish_dw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                         c_void_p]),
     "vince_conv_expand_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_void_p, P(BnReduce),

@@ -510,7 +510,7 @@ extern "C" int vince_aug_blur_to_rows(int dtype, const uint8_t* img, const uint8
                     "aug_blur_to_rows: bad shape N=%d %dx%d Wp=%d left=%d", N, H, W, Wp, left);
     VINCE_CHECK_ARG((((uintptr_t)out | (uintptr_t)tmp) & 15) == 0, VINCE_E_ALIGN, "aug_blur_to_rows: tmp / out must be 16-byte aligned");
     const Norm nm{mean255[0], mean255[1], mean255[2], std255[0], std255[1], std255[2]};
-    static const bool fused_env = !(getenv("VINCE_BLUR_FUSED") && atoi(getenv("VINCE_BLUR_FUSED")) == 0);
+    static const bool fused_env = (VINCE_MEASURE_KNOB("blur_fused", 1) != 0);
     const size_t lds = blur_fused_lds(do_blur ? ks : 1);
     if (fused_env && lds <= 160 * 1024) {
         const dim3 grid((Wp + BLUR_TW - 1) / BLUR_TW, (H + BLUR_TH - 1) / BLUR_TH, N);

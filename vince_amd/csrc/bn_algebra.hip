@@ -18,7 +18,8 @@
 //
 // Three small launches per block (w <= 128, 4w <= 512: everything fits simple one-thread-per-output loops):
 //   bn3_prepare_kernel   per output channel: the dot product, c1, c2, s, t, dgamma / dbeta
-//   bn3_derive_kernel    wd = bf16(W^T diag(s)) [w][4w],  nq = bf16(-Q) [w][w],  nr = -r [w]
+//   bn3_derive_kernel    wd = bf16(W^T diag(s)) [w][4w],  nq = bf16(-Q) [w][w] (row strides given: the engine interleaves them as the
+//                        two taps of ONE input-gradient launch, vince_conv_epi.in2),  nr = -r [w]
 //   bn3_finish_dw_kernel dW in place of R
 #include <string.h>
 
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void bn3_prepare_kernel(const float* __restric
 
 // grid: blocks 0 .. K-1 produce row k of wd (and nr[k]); blocks K .. 2K-1 produce row k of nq
 __global__ __launch_bounds__(256) void bn3_derive_kernel(const bf16_t* __restrict__ W, const float* __restrict__ coef, const float* __restrict__ mean,
-                                                         int Co, int K, bf16_t* __restrict__ wd, bf16_t* __restrict__ nq, float* __restrict__ nr) {
+                                                         int Co, int K, bf16_t* __restrict__ wd, int wd_ld, bf16_t* __restrict__ nq, int nq_ld, float* __restrict__ nr) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < K) {
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void bn3_derive_kernel(const bf16_t* __restric
         for (int c = tid; c < Co; c += 256) {
             const float w = bf16_to_f32(W[(size_t)c * K + k]);
             const float s = coef[c], c1 = coef[Co + c], t = coef[3 * Co + c];
-            wd[(size_t)k * Co + c] = f32_to_bf16(s * w);
+            wd[(size_t)k * wd_ld + c] = f32_to_bf16(s * w);
             acc += w * (s * c1 - t * mean[c]);
         }
         red[tid] = acc;
@@ -73,13 +74,25 @@ __global__ __launch_bounds__(256) void bn3_derive_kernel(const bf16_t* __restric
         }
         if (tid == 0) nr[k] = -red[0];
     } else {
-        // nq[k][j] = -sum_c W[c][k] t[c] W[c][j]: thread j, loop over c (row c of W is read coalesced across j)
+        // nq[k][j] = -sum_c W[c][k] t[c] W[c][j].  Column k of W scaled by t is staged in LDS once; thread = (j, part): the Co
+        // reduction is split over the 256 / K parts of a column (row c of W is read coalesced across j), folded through LDS.
+        __shared__ float tk[512];
         const int k = blockIdx.x - K;
-        for (int j = tid; j < K; j += 256) {
-            float acc = 0.f;
-            for (int c = 0; c < Co; ++c)
-                acc += bf16_to_f32(W[(size_t)c * K + k]) * coef[3 * Co + c] * bf16_to_f32(W[(size_t)c * K + j]);
-            nq[(size_t)k * K + j] = f32_to_bf16(-acc);
+        for (int c = tid; c < Co; c += 256) tk[c] = coef[3 * Co + c] * bf16_to_f32(W[(size_t)c * K + k]);
+        __syncthreads();
+        const int parts = 256 / K, j = tid % K, part = tid / K;
+        float acc = 0.f;
+        if (part < parts) {
+            const int c0 = part * (Co / parts), c1 = part + 1 == parts ? Co : c0 + Co / parts;
+#pragma unroll 8
+            for (int c = c0; c < c1; ++c) acc += tk[c] * bf16_to_f32(W[(size_t)c * K + j]);
+        }
+        red[tid] = acc;
+        __syncthreads();
+        if (tid < K) {
+            float sum = 0.f;
+            for (int q = 0; q < parts; ++q) sum += red[q * K + tid];
+            nq[(size_t)k * nq_ld + tid] = f32_to_bf16(-sum);
         }
     }
 }
@@ -107,15 +120,15 @@ __global__ __launch_bounds__(128) void bn3_finish_dw_kernel(float* __restrict__ 
 
 extern "C" int vince_bn3_bwd_prepare(const float* R, const void* w_bf16, const double* gsums, int32_t replicas, const float* mean,
                                      const float* invstd, const float* gamma, int64_t count, int32_t Co, int32_t K, float* coef,
-                                     void* wd, void* nq, float* nr, float* dgamma, float* dbeta, void* stream) {
+                                     void* wd, int32_t wd_ld, void* nq, int32_t nq_ld, float* nr, float* dgamma, float* dbeta, void* stream) {
     VINCE_CHECK_ARG(R && w_bf16 && gsums && mean && invstd && gamma && coef && wd && nq && nr && dgamma && dbeta, VINCE_E_ARG,
                     "vince_bn3_bwd_prepare: null pointer");
-    VINCE_CHECK_ARG(count > 0 && Co > 0 && K > 0 && K <= 128 && K % 8 == 0, VINCE_E_SHAPE, "vince_bn3_bwd_prepare: K=%d (multiple of 8, at most 128)", K);
+    VINCE_CHECK_ARG(count > 0 && Co > 0 && Co <= 512 && (K == 64 || K == 128), VINCE_E_SHAPE, "vince_bn3_bwd_prepare: K=%d (64 or 128), Co=%d (at most 512)", K, Co);
     if (replicas <= 0 || replicas > VINCE_STATS_REPLICAS) replicas = VINCE_STATS_REPLICAS;
     hipLaunchKernelGGL(bn3_prepare_kernel, dim3((Co + 3) / 4), dim3(256), 0, (hipStream_t)stream, R, (const bf16_t*)w_bf16, gsums, replicas,
                        mean, invstd, gamma, 1.0 / (double)count, Co, K, coef, dgamma, dbeta);
     hipLaunchKernelGGL(bn3_derive_kernel, dim3(2 * K), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_bf16, (const float*)coef, mean, Co, K,
-                       (bf16_t*)wd, (bf16_t*)nq, nr);
+                       (bf16_t*)wd, wd_ld, (bf16_t*)nq, nq_ld, nr);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

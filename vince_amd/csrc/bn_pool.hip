@@ -50,8 +50,8 @@ __device__ __forceinline__ void st16(void* ptr, const uint4& v, int nt) {
     }
 }
 inline int bn_nt_policy(int64_t rows, int C, int esize) {
-    static const int mask = getenv("VINCE_BN_NT") ? atoi(getenv("VINCE_BN_NT")) : 0;
-    static const long long min_bytes = getenv("VINCE_BN_NT_MIN") ? atoll(getenv("VINCE_BN_NT_MIN")) : (64ll << 20);
+    static const int mask = VINCE_MEASURE_KNOB("bn_nt", 0);
+    static const long long min_bytes = VINCE_MEASURE_KNOB("bn_nt_min", (64ll << 20));
     return (long long)rows * C * esize >= min_bytes ? mask : 0;
 }
 
@@ -814,12 +814,12 @@ inline int bn_bwd_target_blocks() {
     // bn_bwd_apply opens with the replica fold + seven per-channel constant vectors: ~3 us of dependent L2 latency per
     // workgroup before the first row moves.  Half as many, twice as long workgroups than the forward apply: -0.4 ms/step
     // (swept 512..3072; the forward apply stays best at 2048).
-    static const int n = getenv("VINCE_BN_BWD_BLOCKS") ? atoi(getenv("VINCE_BN_BWD_BLOCKS")) : 1024;
+    static const int n = VINCE_MEASURE_KNOB("bn_bwd_blocks", 1024);
     return n;
 }
 
 inline int bn_target_blocks() {
-    static const int n = getenv("VINCE_BN_BLOCKS") ? atoi(getenv("VINCE_BN_BLOCKS")) : 2048;   // swept 1024..16384: 1536-2048 best
+    static const int n = VINCE_MEASURE_KNOB("bn_blocks", 2048);   // swept 1024..16384: 1536-2048 best
     return n;
 }
 

@@ -20,6 +20,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // error plumbing: every export returns int, never throws; message kept thread-local
 // ---------------------------------------------------------------------------------------------
 void vince_set_error(const char* fmt, ...);
+// Cross-check switches of the product library, all inside ONE environment variable:  VINCE_KNOBS="name=value,name=value".
+// vince_knob: parsed at the call (callers cache it in a static); vince_knob_live: for switches a test flips inside one process.
+// Documented names: DESIGN.md section 9.  Everything else that used to be an environment knob is a constant of the product build
+// and an environment variable VINCE_<NAME> only in the measurement build (python -m vince_amd.build --measure).
+long vince_knob(const char* name, long dflt);
+inline long vince_knob_live(const char* name, long dflt) { return vince_knob(name, dflt); }
+#ifdef VINCE_MEASURE
+long vince_measure_knob(const char* name, long dflt);
+#define VINCE_MEASURE_KNOB(name, dflt) vince_measure_knob(name, dflt)
+#else
+#define VINCE_MEASURE_KNOB(name, dflt) (dflt)
+#endif
 bool vince_profile_enabled();
 int vince_side_stream_budget();   // vince_set_side_streams(): 2 = wgrad + downsample streams, 1 = wgrad only, 0 = none
 void vince_profile_begin_launch(int tag, double work, void* stream, void** token);

@@ -357,7 +357,7 @@ extern "C" int vince_conv3x3_strip(int dtype, const void* x, const void* w, int3
         VINCE_CHECK_ARG(p.tap_w[t] >= 0 && p.tap_w[t] < 9, VINCE_E_ARG, "vince_conv3x3_strip: tap_map[%d] out of range", t);
     }
     int grid = xs_num_cu();
-    static const int grid_env = getenv("VINCE_STRIP_GRID") ? atoi(getenv("VINCE_STRIP_GRID")) : 0;   // (tests: several images per workgroup)
+    static const int grid_env = vince_knob("strip_grid", 0);   // (tests: several images per workgroup)
     if (grid_env > 0) grid = grid_env;
     if (grid > N) grid = N;
     VinceProfScope prof(VINCE_TAG_STRIP, 2.0 * N * H * W * Co * 9.0 * Ci, stream);

@@ -20,6 +20,9 @@ struct ConvParams {
     const void* w;
     void* out;
     uint32_t in_bytes, w_bytes;   // buffer-descriptor ranges for the direct-to-LDS variant (0 = tensor too large)
+    const void* in2;    // second input tensor of the last tap (vince_conv_epi.in2), its byte range and channel stride
+    uint32_t in2_bytes;
+    int cs2;
     vince_conv_epi e;   // epilogue options (bias, statistics, residual join, fused BatchNorm forward / backward-reduce)
 };
 

@@ -216,6 +216,10 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     constexpr uint32_t OOB = 0x80000000u;   // descriptors cover < 2 GiB, so this (and small increments of it) reads as zero
 
     const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
+    // second input tensor of the LAST tap (vince_conv_epi.in2: a reduction split over two tensors); same descriptor otherwise
+    const v4i_t rsrc_x2 = make_rsrc(p.in2 ? p.in2 : p.in, p.in2 ? p.in2_bytes : p.in_bytes);
+    const int tap2 = p.in2 ? d.TA * d.TB - 1 : 0x7ffffff;
+    bool src2 = false;   // (wave-uniform) the offsets in offx belong to the second tensor
     const v4i_t rsrc_w = make_rsrc(p.w, p.w_bytes);
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
 
@@ -250,11 +254,13 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
         const int dh = d.dh0 + a * d.dhs, dw = d.dw0 + b * d.dws;
         const int widx = d.wt0 + a * d.wta + b * d.wtb;
         const bool qv = q < p.total_chunks;       // also false for kt >= nkt: the whole tile is zero filled
+        src2 = __builtin_amdgcn_readfirstlane(tap) == tap2;    // (every lane of a tile is in the same tap here: uniform_taps)
+        const uint32_t cs = src2 ? (uint32_t)p.cs2 : (uint32_t)p.cs;
 #pragma unroll
         for (int e = 0; e < XROWS; ++e) {
             const int hi = hb[e] + dh, wi = wb[e] + dw;
             const bool ok = rv[e] && qv && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
-            offx[e] = ok ? ((nb[e] + (uint32_t)(hi * d.Wi + wi)) * (uint32_t)p.cs + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
+            offx[e] = ok ? ((nb[e] + (uint32_t)(hi * d.Wi + wi)) * cs + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
         }
 #pragma unroll
         for (int e = 0; e < WROWS; ++e) {
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
             const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
             const uint32_t ws = xs + S::XB;
 #pragma unroll
-            for (int e = 0; e < XROWS; ++e) lds_dma16(xs + e * 4096, offx[e], rsrc_x);
+            for (int e = 0; e < XROWS; ++e) lds_dma16(xs + e * 4096, offx[e], src2 ? rsrc_x2 : rsrc_x);
 #pragma unroll
             for (int e = 0; e < WROWS; ++e) lds_dma16(ws + e * 4096, offw[e], rsrc_w);
         }
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     // short-reduction configurations lose 2-5 % and keep the up-front issue.
     auto issue_piece = [&](int piece, int buf) {
         const uint32_t xs = __builtin_amdgcn_readfirstlane(smem_base + buf * S::STAGE + wave * 1024);
-        if (piece < XROWS) lds_dma16(xs + piece * 4096, offx[piece < XROWS ? piece : 0], rsrc_x);
+        if (piece < XROWS) lds_dma16(xs + piece * 4096, offx[piece < XROWS ? piece : 0], src2 ? rsrc_x2 : rsrc_x);
         else lds_dma16(xs + S::XB + (piece - XROWS) * 4096, offw[piece >= XROWS ? piece - XROWS : 0], rsrc_w);
     };
 
@@ -480,26 +486,30 @@ __global__ void relu_inplace_kernel(float* x, size_t n4) {
 template <typename T, int CT, int MODE>
 int launch(ConvParams& p, hipStream_t stream) {
     constexpr bool BWD = MODE != 0;   // (anything but the lean forward epilogue)
-    static int dlds_min_k = getenv("VINCE_DLDS_MIN_K") ? atoi(getenv("VINCE_DLDS_MIN_K")) : 0;
+    static int dlds_min_k = vince_knob("dlds_min_k", 0);
     const int k_elems = p.total_chunks * (16 / (int)sizeof(T));
     // VINCE_DLDS_CFG=4 forces the 128-pixel tile everywhere (measurement aid); the default (5) adds the 256-pixel tile
-    static int dlds_cfg = getenv("VINCE_DLDS_CFG") ? atoi(getenv("VINCE_DLDS_CFG")) : 5;
-    static int big_min_k = getenv("VINCE_BIG_MIN_K") ? atoi(getenv("VINCE_BIG_MIN_K")) : 1024;
-    static int big_min_tiles = getenv("VINCE_BIG_MIN_TILES") ? atoi(getenv("VINCE_BIG_MIN_TILES")) : 256;
-    static long narrow256 = getenv("VINCE_NARROW256_MIN_TILES") ? atol(getenv("VINCE_NARROW256_MIN_TILES")) : 2048;   // 0 = off
+    static int dlds_cfg = VINCE_MEASURE_KNOB("dlds_cfg", 5);
+    static int big_min_k = vince_knob("big_min_k", 1024);
+    static int big_min_tiles = vince_knob("big_min_tiles", 256);
+    static long narrow256 = vince_knob("narrow256_min_tiles", 2048);   // 0 = off
     // rotated main loop (fragment reads one MFMA phase ahead, across the tile barrier): bit 0 the 256x128 tile, 1 the 256x64
     // tile, 2 the 2-stage 128-pixel tile, 3 the 3-stage 128-pixel tile
-    static int rot = getenv("VINCE_ROT") ? atoi(getenv("VINCE_ROT")) : 9;
-    static int rot_min_k = getenv("VINCE_ROT_MIN_K") ? atoi(getenv("VINCE_ROT_MIN_K")) : 0;
+    static int rot = vince_knob("rot", 9);
+    static int rot_min_k = VINCE_MEASURE_KNOB("rot_min_k", 0);
     if (p.in_bytes && p.w_bytes && k_elems >= dlds_min_k) {
         const int cpt = p.cpt_mask == 0x7fffffff ? p.total_chunks : p.cpt_mask + 1;
         p.uniform_taps = (cpt % 4 == 0) && (p.total_chunks % 4 == 0);
         p.nkt = (p.total_chunks + 3) / 4;     // 64-byte K rows
+        if (p.in2 && !p.uniform_taps) {
+            vince_set_error("vince_conv_igemm: in2 needs Ci and in2_channels to be multiples of a 64-byte K row");
+            return VINCE_E_UNSUPPORTED;
+        }
         // 1x1 reductions at least VINCE_KC8_MIN_K long on the 128-pixel tile: 128-byte K rows (KC = 8), i.e. whole cache lines per
         // DMA'd row -- 64-byte row pieces are request-bound (tools/micro/feed_micro: 14 B/clk/CU against 31 with whole lines);
         // two stages of 32 KB, two workgroups per CU.  Measured: 2048 -> 512 at 7x7 43.6 -> 37.8 us; shorter reductions and the
         // 3x3 layers lose more to the halved occupancy than the whole lines give back.
-        static int kc8_min_k = getenv("VINCE_KC8_MIN_K") ? atoi(getenv("VINCE_KC8_MIN_K")) : 2048;   // 0 = off
+        static int kc8_min_k = vince_knob("kc8_min_k", 2048);   // 0 = off
         if constexpr (sizeof(T) == 2 && CT == 128) {
             const bool big = dlds_cfg == 5 && k_elems >= big_min_k && (long)((p.M + 255) / 256) * p.ctiles >= big_min_tiles;
             if (kc8_min_k > 0 && !big && p.cpt_mask == 0x7fffffff && p.total_chunks % 8 == 0 && k_elems >= kc8_min_k) {
@@ -543,10 +553,10 @@ int launch(ConvParams& p, hipStream_t stream) {
             // reduction over grid.y, partial sums meet in a zeroed output through fp32 atomics, ReLU runs afterwards.
             int splits = 1;
             const long tiles = (long)p.ptiles * p.ctiles;
-            static const bool splitk_env = !(getenv("VINCE_SPLITK") && atoi(getenv("VINCE_SPLITK")) == 0);
+            static const bool splitk_env = (VINCE_MEASURE_KNOB("splitk", 1) != 0);
             if (sizeof(T) == 4 && splitk_env && !BWD && !p.e.stats && tiles < 128 && p.nkt >= 16 &&
                 p.d.osh == 1 && p.d.osw == 1 && p.d.OH == p.d.Ho && p.d.OW == p.d.Wo) {
-                static const long target = getenv("VINCE_SPLITK_WGS") ? atol(getenv("VINCE_SPLITK_WGS")) : 256;   // (env: measurement aid) more splits cost more in atomics than they buy
+                static const long target = VINCE_MEASURE_KNOB("splitk_wgs", 256);   // (env: measurement aid) more splits cost more in atomics than they buy
                 splits = (int)min((long)(p.nkt / 8), (target + tiles - 1) / tiles);
                 if (splits < 2) splits = 1;
             }
@@ -565,7 +575,7 @@ int launch(ConvParams& p, hipStream_t stream) {
                 // reductions at least VINCE_S3_MIN_K long take a 3-stage ring (two K tiles in flight, 3 workgroups per CU) instead
                 // of 2 stages / 4 workgroups
                 // default 2048: layer4's 3x3 (K = 4608) 92.6 -> 85 us, 2048 -> 512 50 -> 44 us; shorter reductions lose
-                static const int s3_min_k = getenv("VINCE_S3_MIN_K") ? atoi(getenv("VINCE_S3_MIN_K")) : 2048;
+                static const int s3_min_k = vince_knob("s3_min_k", 2048);
                 if (s3_min_k > 0 && k_elems >= s3_min_k) {
                     if (rot & 8)
                         hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
@@ -580,6 +590,10 @@ int launch(ConvParams& p, hipStream_t stream) {
         }
         VINCE_CHECK_LAUNCH();
         return VINCE_OK;
+    }
+    if (p.in2) {
+        vince_set_error("vince_conv_igemm: in2 needs the direct-to-LDS kernels (tensors < 2 GiB, taps a whole number of K tiles)");
+        return VINCE_E_UNSUPPORTED;
     }
     // register-staged fallback (tensors beyond the 31-bit buffer offsets of the direct-to-LDS path): K tile = 128 bytes
     // per row (8 chunks) when the reduction is long enough to pipeline, else 64 bytes.  Generic epilogue.
@@ -614,6 +628,9 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     VINCE_CHECK_ARG(!e.bnred.mask_scale == !e.bnred.mask_shift, VINCE_E_ARG,
                     "vince_conv_igemm: bnred mask_scale and mask_shift come together");
     VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_igemm: bad dtype %d", dtype);
+    VINCE_CHECK_ARG(!e.in2 || (dd->TA * dd->TB >= 2 && dd->Cs == 0 && e.in2_channels > 0 && e.in2_channels <= dd->Ci &&
+                               e.in2_channels % (dtype == VINCE_F32 ? 4 : 8) == 0 && ((uintptr_t)e.in2 & 15) == 0), VINCE_E_ARG,
+                    "vince_conv_igemm: in2 is the input of the last of at least two taps, in2_channels <= Ci, 16-byte aligned");
     const vince_conv_desc& d = *dd;
     const int CH = dtype == VINCE_F32 ? 4 : 8;
     VINCE_CHECK_ARG(d.N > 0 && d.Hi > 0 && d.Wi > 0 && d.Ho > 0 && d.Wo > 0 && d.Co > 0 && d.Ci > 0, VINCE_E_SHAPE,
@@ -649,6 +666,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
         p.cpt_mask = cpt - 1;
     }
     p.total_chunks = T * cpt;
+    if (e.in2) p.total_chunks = (T - 1) * cpt + e.in2_channels / CH;   // the last tap reads the (narrower) second tensor
     p.nkt = (p.total_chunks + 3) / 4;
     p.M = d.N * d.Ho * d.Wo;
     p.tb_mul = (65536 + d.TB - 1) / d.TB;
@@ -657,33 +675,33 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.in = in; p.w = w; p.out = out; p.e = e;
     p.variant = 0;
     p.cs = d.Cs > 0 ? d.Cs : d.Ci;
+    p.in2 = e.in2;
+    p.cs2 = e.in2_channels;
+    p.in2_bytes = 0;
     p.kt_per_split = 0;
     p.ablate = 0;
 #ifdef VINCE_MEASURE
-    static int ablate = getenv("VINCE_CONV_ABLATE") ? atoi(getenv("VINCE_CONV_ABLATE")) : 0;
+    static int ablate = VINCE_MEASURE_KNOB("conv_ablate", 0);
     p.ablate = ablate;
 #endif
     {
         const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;
         const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * p.cs * esz, wb = (unsigned long long)d.Co * d.WT * d.Ci * esz;
         p.in_bytes = ib < 0x7ff00000ull ? (uint32_t)ib : 0;   // the direct-to-LDS path addresses with 31-bit offsets
+        if (e.in2) {
+            const unsigned long long ib2 = (unsigned long long)d.N * d.Hi * d.Wi * e.in2_channels * esz;
+            p.in2_bytes = ib2 < 0x7ff00000ull ? (uint32_t)ib2 : 0;
+            if (!p.in2_bytes) p.in_bytes = 0;
+        }
         p.w_bytes = wb < 0x7ff00000ull ? (uint32_t)wb : 0;
     }
     p.ptiles = (p.M + PT - 1) / PT;
     // 64-channel tiles for short reductions: such layers are HBM-bound and the smaller accumulator footprint buys
     // occupancy (5 waves/SIMD vs 3), which is what a streaming kernel needs
-    static int ct64_max_k = getenv("VINCE_CT64_MAX_K") ? atoi(getenv("VINCE_CT64_MAX_K")) : 0;
-    static double ct64_cost = getenv("VINCE_CT64_COST") ? atof(getenv("VINCE_CT64_COST")) : 0.0;
+    static int ct64_max_k = VINCE_MEASURE_KNOB("ct64_max_k", 0);
     bool narrow = d.Co <= 64 || (d.TA * d.TB * d.Ci <= ct64_max_k);
     // tiny-M GEMMs (the projection MLP: 256 rows -> 2 pixel tiles): 64-channel tiles double the workgroup count
     if (!narrow && (long)p.ptiles * ((d.Co + 127) / 128) < 128) narrow = true;
-    if (!narrow && ct64_cost > 0 && d.TA * d.TB * d.Ci >= 512) {
-        // wave quantisation: 128-channel tiles hold 3 workgroups per CU, 64-channel tiles 4; pick the one whose number of
-        // full-chip rounds times relative tile cost is smaller (784 tiles on 768 slots is two rounds)
-        const long t128 = (long)p.ptiles * ((d.Co + 127) / 128), t64 = (long)p.ptiles * ((d.Co + 63) / 64);
-        const double c128 = (double)((t128 + 767) / 768), c64 = (double)((t64 + 1023) / 1024) * ct64_cost;
-        narrow = c64 < c128;
-    }
     const int CT = narrow ? 64 : 128;
     p.ctiles = (d.Co + CT - 1) / CT;
     hipStream_t s = (hipStream_t)stream;
@@ -701,11 +719,11 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     // The 8-wavefront 256 x 256 core (conv_m8.hip) takes the long bf16 reductions with 256-channel output tiles: the 3x3 and wide
     // 1x1 convolutions of layer3 / layer4 and their input gradients.  VINCE_M8=0 keeps everything on this file's tiles (the
     // cross-check of the parity tests), VINCE_M8_MIN_K moves the threshold.
-    static const int m8_on = getenv("VINCE_M8") ? atoi(getenv("VINCE_M8")) : 1;
-    static const int m8_min_k = getenv("VINCE_M8_MIN_K") ? atoi(getenv("VINCE_M8_MIN_K")) : 1024;
-    static const int m8_min_tiles = getenv("VINCE_M8_MIN_TILES") ? atoi(getenv("VINCE_M8_MIN_TILES")) : 128;
+    static const int m8_on = vince_knob("m8", 1);
+    static const int m8_min_k = vince_knob("m8_min_k", 1024);
+    static const int m8_min_tiles = vince_knob("m8_min_tiles", 128);
     rc = -1;
-    if (m8_on && dtype == VINCE_BF16 && d.Co % 256 == 0 && T * d.Ci >= m8_min_k &&
+    if (m8_on && !e.in2 && dtype == VINCE_BF16 && d.Co % 256 == 0 && T * d.Ci >= m8_min_k &&
         (long)((p.M + 255) / 256) * (d.Co / 256) >= m8_min_tiles)
         rc = vince_conv_m8_launch(p, join ? 2 : (bwd ? 1 : 0), s);
     if (rc != -1) {

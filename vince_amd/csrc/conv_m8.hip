@@ -298,7 +298,7 @@ int vince_conv_m8_launch(vince_conv::ConvParams& p, int mode, hipStream_t stream
     p.ctiles = (d.Co + M8_CT - 1) / M8_CT;
     p.variant = 3;
 #ifdef VINCE_MEASURE
-    p.ablate = getenv("VINCE_M8_ABLATE") ? atoi(getenv("VINCE_M8_ABLATE")) : 0;
+    p.ablate = VINCE_MEASURE_KNOB("m8_ablate", 0);
 #endif
     const dim3 grid(p.ptiles * p.ctiles), block(512);
     if (mode == 0) hipLaunchKernelGGL(conv_m8_kernel<0>, grid, block, 0, stream, p);

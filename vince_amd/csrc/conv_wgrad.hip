@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
 
 template <typename T, int CT, int NT>
 int launch(const WgradParams& p, int splits, hipStream_t stream) {
-    static int use_dlds = getenv("VINCE_WGRAD_DLDS") ? atoi(getenv("VINCE_WGRAD_DLDS")) : 1;
+    static int use_dlds = vince_knob("wgrad_dlds", 1);
     if (use_dlds && p.in_bytes && p.dy_bytes && p.variant == 0) {
         if (use_dlds == 2)
             hipLaunchKernelGGL((conv_wgrad_dlds_kernel<T, CT, NT, 4>), dim3(p.ctiles * p.ntiles, splits), dim3(256), 0, stream, p);
@@ -451,14 +451,14 @@ int dispatch(WgradParams& p, hipStream_t stream) {
     const int CT = d.Co <= 64 ? 64 : 128, NT = ntot <= 64 ? 64 : 128;
     p.ctiles = (d.Co + CT - 1) / CT;
     p.ntiles = (ntot + NT - 1) / NT;
-    static int use_dlds_d = getenv("VINCE_WGRAD_DLDS") ? atoi(getenv("VINCE_WGRAD_DLDS")) : 1;
+    static int use_dlds_d = vince_knob("wgrad_dlds", 1);
     const bool dlds = use_dlds_d && p.in_bytes && p.dy_bytes && p.variant == 0;
     const int kp = dlds ? KPD : KP;                 // pixels per K slice of the kernel that will run
     p.nkt_total = (p.M + kp - 1) / kp;
     // Split the pixel range so that the grid is about one resident wave of workgroups (256 CUs x 2): every extra split
     // costs Co*T*Ci fp32 atomics in the epilogue, and the L2 atomic rate -- not MFMA -- bounds this kernel when the grid
     // is cut 3x finer.  At least 8 K-tiles per split.
-    static int target_blocks = getenv("VINCE_WGRAD_BLOCKS") ? atoi(getenv("VINCE_WGRAD_BLOCKS")) : 512;
+    static int target_blocks = VINCE_MEASURE_KNOB("wgrad_blocks", 512);
     const int tiles = p.ctiles * p.ntiles;
     int splits = (target_blocks + tiles - 1) / tiles;
     const int max_splits = (p.nkt_total * kp / 64 + 7) / 8;   // at least 512 pixels per split
@@ -468,7 +468,7 @@ int dispatch(WgradParams& p, hipStream_t stream) {
     splits = (p.nkt_total + p.kt_per_split - 1) / p.kt_per_split;
     // XCD grouping pays most when many tiles share a pixel range (kernels timed alone: -15 % at 16-36 tiles, +12 % at 5
     // tiles; in the overlapped step always-on measured best, so the threshold stays a measurement knob)
-    static const int xcd_min_tiles = getenv("VINCE_WGRAD_XCD_MIN_TILES") ? atoi(getenv("VINCE_WGRAD_XCD_MIN_TILES")) : 1;
+    static const int xcd_min_tiles = VINCE_MEASURE_KNOB("wgrad_xcd_min_tiles", 1);
     p.xcd_group = p.xcd_group && tiles >= xcd_min_tiles;
     if (CT == 64 && NT == 64) return launch<T, 64, 64>(p, splits, stream);
     if (CT == 64) return launch<T, 64, 128>(p, splits, stream);
@@ -524,7 +524,7 @@ extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.dy = dy; p.dw = dw; p.Ci_dw = Ci_dw; p.variant = variant;
     p.cs = d.Cs > 0 ? d.Cs : d.Ci;
-    static const int xcd_group = !(getenv("VINCE_WGRAD_XCD") && atoi(getenv("VINCE_WGRAD_XCD")) == 0);
+    static const int xcd_group = (VINCE_MEASURE_KNOB("wgrad_xcd", 1) != 0);
     p.xcd_group = xcd_group;
     {
         const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;

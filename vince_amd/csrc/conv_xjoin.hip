@@ -78,7 +78,8 @@ struct XjSmem {
 // and the (sum g', sum g' xhat) reduction of the BatchNorm below that consumes `out` (g' = out gated by ITS ReLU bits, xhat from
 // its saved conv output) -- the join in the MFMA layout with out_old requested a unit ahead, the reduction after the
 // transposition where a lane owns the same 8 channels for the whole launch.
-template <int K, int STAGES, bool ID_AFFINE, bool SAVE, bool PLAIN = false, bool DGRAD = false>
+// SAVE: 0 nothing beside `out`; 1 the ReLU mask bytes (the forward of the BatchNorm-backward algebra); 2 mask bytes + the raw conv output
+template <int K, int STAGES, bool ID_AFFINE, int SAVE, bool PLAIN = false, bool DGRAD = false>
 __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p) {
     using S = XjSmem<K, STAGES>;
     constexpr int NKT = S::NKT;
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                     v[e] = __uint_as_float(r[0]);
                     v[4 + e] = __uint_as_float(r[1]);
                 }
-                if constexpr (SAVE) rpk[j][gp] = Chunk<bf16_t>::pack(v);
+                if constexpr (SAVE == 2) rpk[j][gp] = Chunk<bf16_t>::pack(v);
                 if constexpr (PLAIN) {
                     opk[j][gp] = Chunk<bf16_t>::pack(v);
                     continue;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 stage_store(opk, pass, out, SAVE ? p.mask_out : nullptr, pix0);
-                if constexpr (SAVE) { if (yraw) stage_store(rpk, pass, yraw, nullptr, pix0); }   // (uniform)
+                if constexpr (SAVE == 2) stage_store(rpk, pass, yraw, nullptr, pix0);
             }
         }
     };
@@ -499,9 +500,9 @@ extern "C" int vince_conv_expand_stats(int dtype, const void* x, const void* w, 
     if (grid < p.cgroups) grid = p.cgroups;
     VinceProfScope prof(VINCE_TAG_XSTATS, (double)rows * (K + Co) * 2, stream);
     if (K == 64)
-        hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, false, 0, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((conv_xjoin_kernel<128, 2, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((conv_xjoin_kernel<128, 2, false, 0, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
@@ -559,9 +560,9 @@ static int expand_dgrad_common(int dtype, const void* dy, const void* wt, int64_
     VinceProfScope prof(VINCE_TAG_XDGRAD, (double)rows * 2 * (K + Co * (1 + (accumulate ? 1 : 0) + (p.br_y ? 1 : 0))) +
                         (double)rows * Co / 8 * ((acc_mask ? 1 : 0) + (p.br_bits ? 1 : 0) + (out_mask ? 1 : 0)), stream);
     if (K == 64)
-        hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, false, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, false, 0, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((conv_xjoin_kernel<128, 2, false, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((conv_xjoin_kernel<128, 2, false, 0, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
@@ -591,7 +592,7 @@ extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, i
     p.cgroups = Co / XJ_CG;
     p.relu = relu;
     const int n_cu = xj_num_cu();
-    static const int wg_per_cu = getenv("VINCE_XJ_WGS") ? atoi(getenv("VINCE_XJ_WGS")) : 1;   // (measurement aid)
+    static const int wg_per_cu = VINCE_MEASURE_KNOB("xj_wgs", 1);   // (measurement aid)
     long grid = (long)n_cu * wg_per_cu;
     const long items = (long)p.ptiles * p.cgroups;
     if (grid > items) grid = items;
@@ -601,8 +602,9 @@ extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, i
     hipLaunchKernelGGL((conv_xjoin_kernel<KK, SS, AA, SV>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p)
 #define VINCE_XJ_PICK(KK, SS)                                                                             \
     do {                                                                                                  \
-        if (mask_out) { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, true); else VINCE_XJ_LAUNCH(KK, SS, false, true); }   \
-        else { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, false); else VINCE_XJ_LAUNCH(KK, SS, false, false); }       \
+        if (y_raw) { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, 2); else VINCE_XJ_LAUNCH(KK, SS, false, 2); }            \
+        else if (mask_out) { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, 1); else VINCE_XJ_LAUNCH(KK, SS, false, 1); }    \
+        else { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, 0); else VINCE_XJ_LAUNCH(KK, SS, false, 0); }                  \
     } while (0)
     VinceProfScope prof(VINCE_TAG_XJOIN, (double)rows * 2 * (K + Co * (2 + (y_raw ? 1 : 0))) + (mask_out ? (double)rows * Co / 8 : 0), stream);
     if (K == 64) VINCE_XJ_PICK(64, 3); else VINCE_XJ_PICK(128, 2);

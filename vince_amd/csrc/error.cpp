@@ -14,6 +14,31 @@ void vince_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// VINCE_KNOBS="name=value,name=value" (common.h): the product library's cross-check switches
+#include <string.h>
+long vince_knob(const char* name, long dflt) {
+    const char* s = getenv("VINCE_KNOBS");
+    if (!s) return dflt;
+    const size_t n = strlen(name);
+    while (*s) {
+        while (*s == ',' || *s == ' ') ++s;
+        if (strncmp(s, name, n) == 0 && s[n] == '=') return strtol(s + n + 1, nullptr, 10);
+        while (*s && *s != ',') ++s;
+    }
+    return dflt;
+}
+#ifdef VINCE_MEASURE
+#include <ctype.h>
+long vince_measure_knob(const char* name, long dflt) {   // measurement build: VINCE_<NAME> in the environment
+    char env[96] = "VINCE_";
+    size_t i = 6;
+    for (const char* c = name; *c && i + 1 < sizeof(env); ++c) env[i++] = (char)toupper((unsigned char)*c);
+    env[i] = 0;
+    const char* v = getenv(env);
+    return v ? strtol(v, nullptr, 10) : dflt;
+}
+#endif
+
 extern "C" const char* vince_last_error(void) { return g_err; }
 extern "C" int vince_abi_version(void) { return 1; }
 

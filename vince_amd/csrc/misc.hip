@@ -414,7 +414,7 @@ extern "C" int vince_transpose_f32(const float* in, float* out, int32_t rows, in
 extern "C" int vince_prepare_weights_batched(int dtype, const vince_prep_entry* table_dev, int32_t n, void* stream) {
     DTYPE_OK("vince_prepare_weights_batched");
     VINCE_CHECK_ARG(table_dev && n > 0, VINCE_E_ARG, "vince_prepare_weights_batched: bad arguments");
-    static const int tiled = !(getenv("VINCE_PREP_TILED") && atoi(getenv("VINCE_PREP_TILED")) == 0);   // measurement aid
+    static const int tiled = (VINCE_MEASURE_KNOB("prep_tiled", 1) != 0);   // measurement aid
     const dim3 grid(512, n);   // blocks beyond a small layer's element count fall through the grid-stride loop at once
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(prepare_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, table_dev, tiled);

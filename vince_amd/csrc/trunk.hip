@@ -179,7 +179,7 @@ int replicas_for(int64_t rows) {
 // column 2*wo -- K = 7 x 32 instead of 49 taps x 8 padded channels, one 64-byte (bf16) LDS-DMA row per tap.
 constexpr int STEM_CS = 4, STEM_K = 32, STEM_LEFT = 3;
 bool stem_packed() {
-    static const bool on = !(getenv("VINCE_STEM_PACKED") && atoi(getenv("VINCE_STEM_PACKED")) == 0);
+    static const bool on = (vince_knob("stem_packed", 1) != 0);
     return on;
 }
 vince_conv_desc fwd_desc(const vince_trunk* t, const ConvL& c);
@@ -328,7 +328,7 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
         if (b.gram != NONE) {
             const size_t w = b.c[2].Ci, co = b.c[2].Co;
             b.alg = P.ws;
-            P.ws = align_up(P.ws + align_up(4 * co * sizeof(float)) + align_up(w * co * 2) + align_up(w * w * 2) + align_up(w * sizeof(float)));
+            P.ws = align_up(P.ws + align_up(4 * co * sizeof(float)) + align_up(w * 2 * co * 2) + align_up(w * sizeof(float)));
         }
     }
     for (int i = 0; i < 3; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
@@ -435,8 +435,8 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
     // write 4x what they read: the persistent streaming kernel runs them at 4.2 TB/s (122 us) against the implicit-GEMM
     // kernel's 3.1 (166 us), statistics in registers for the whole launch.  At K = 128 (layer2) it does not win (half-line
     // stores, two channel groups re-reading the input): VINCE_XSTATS_MAX_K=128 to try, 0 = off.
-    static const int xstats_max_k = getenv("VINCE_XSTATS_MAX_K") ? atoi(getenv("VINCE_XSTATS_MAX_K")) : 64;
-    static const bool strip3x3 = !(getenv("VINCE_STRIP3X3") && atoi(getenv("VINCE_STRIP3X3")) == 0);
+    static const int xstats_max_k = VINCE_MEASURE_KNOB("xstats_max_k", 64);
+    static const bool strip3x3 = (vince_knob("strip3x3", 1) != 0);
     // (the streaming kernels address their input through one 31-bit buffer descriptor: larger tensors stay on vince_conv_igemm,
     // whose register-staged kernels have no such limit)
     const bool small_in = (unsigned long long)c.t->cfg.N * cv.Hi * cv.Wi * cv.Ci * 2 < 0x7ff00000ull;
@@ -467,7 +467,7 @@ int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const voi
                  void* out, uint8_t* mask_out, float* const* bn_running, int64_t* const* bn_nbt, int train_bn,
                  double* out_sum = nullptr) {
     const int64_t rows = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
-    static const bool fuse_fin = !(getenv("VINCE_FUSE_FINALIZE") && atoi(getenv("VINCE_FUSE_FINALIZE")) == 0);
+    static const bool fuse_fin = (VINCE_MEASURE_KNOB("fuse_finalize", 1) != 0);
     if (!train_bn)
         return vince_bn_apply(c.dtype, at(c.ws, y_off), c.consts(bn, 0), c.consts(bn, 1), idn, ids, idt, out, mask_out, rows,
                               cv.Co, 1, c.stream);
@@ -503,8 +503,7 @@ int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const voi
 // join kernel, every block but the last (whose output gradient arrives from the pool, not from a dgrad epilogue).
 // VINCE_BN3_ALGEBRA=0 (read per call, so one process can compare both routes): the separate BatchNorm-backward passes everywhere.
 bool alg_env() {
-    const char* v = getenv("VINCE_BN3_ALGEBRA");
-    return !(v && atoi(v) == 0);
+    return vince_knob_live("bn3_algebra", 1) != 0;
 }
 bool alg_block(const vince_trunk* t, size_t bi) {
     const Blk& b = t->blocks[bi];
@@ -512,14 +511,13 @@ bool alg_block(const vince_trunk* t, size_t bi) {
            (b.c[2].Ci == 64 || b.c[2].Ci == 128) && b.c[2].Co % 256 == 0 && b.c[2].k == 1 && b.c[2].stride == 1 &&
            (unsigned long long)t->cfg.N * b.c[2].Hi * b.c[2].Wi * b.c[2].Ci * 2 < 0x7ff00000ull;
 }
-struct AlgPtrs { float* coef; void* wd; void* nq; float* nr; };
+struct AlgPtrs { float* coef; void* w2; float* nr; };   // w2: bf16 [w][2][4w] -- tap 0 = wd, tap 1 = nq in its first w entries
 AlgPtrs alg_ptrs(void* ws, const Blk& b) {
     const size_t w = b.c[2].Ci, co = b.c[2].Co;
     unsigned char* base = (unsigned char*)at(ws, b.alg);
     AlgPtrs a;
     a.coef = (float*)base; base += align_up(4 * co * sizeof(float));
-    a.wd = base; base += align_up(w * co * 2);
-    a.nq = base; base += align_up(w * w * 2);
+    a.w2 = base; base += align_up(w * 2 * co * 2);
     a.nr = (float*)base;
     return a;
 }
@@ -530,7 +528,7 @@ int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, co
           const vince_bn_reduce* bnred = nullptr, int replicas = 0, const uint8_t* out_mask = nullptr, double* gsums = nullptr) {
     // block-input gradients of layer1 / layer2 bottlenecks (conv1 = 1x1 stride 1, 4w -> w with w = 64 / 128): the expand shape
     // again, through the persistent streaming kernel (299 vs 362 us, 306 vs 383 us, 177 vs 192 us).  VINCE_XDGRAD=0: off.
-    static const bool xdgrad_env = !(getenv("VINCE_XDGRAD") && atoi(getenv("VINCE_XDGRAD")) == 0);
+    static const bool xdgrad_env = (vince_knob("xdgrad", 1) != 0);
     if (xdgrad_env && accumulate && c.dtype == VINCE_BF16 && cv.k == 1 && cv.stride == 1 && (cv.Co == 64 || cv.Co == 128) &&
         cv.Ci % 256 == 0 && !(bnred && bnred->mask_scale) &&
         (unsigned long long)c.t->cfg.N * cv.Hi * cv.Wi * cv.Co * 2 < 0x7ff00000ull) {
@@ -770,8 +768,8 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // The forward downsample conv on its own stream is OPT-IN (VINCE_DS_STREAM_FWD=1): worth 0.1 ms when it happens to share a
     // hardware queue with another stream (GPU_MAX_HW_QUEUES=4, the default), but +4 ms when every stream gets its own queue
     // (two overlapped encoders x two streams each thrash) -- the mapping depends on stream creation order, so it is not relied on.
-    static const int ds_fwd_mode = (getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0) ? 0
-                                   : (getenv("VINCE_DS_STREAM_FWD") ? atoi(getenv("VINCE_DS_STREAM_FWD")) : 0);
+    static const int ds_fwd_mode = (vince_knob("ds_stream", 1) == 0) ? 0
+                                   : (vince_knob("ds_stream_fwd", 0));
     // mode 2: only a handle that already owns a downsample stream from an earlier backward (the query encoder's) uses it in
     // forward too -- no stream is created for it, the key encoder stays inline
     const bool ds_side = (ds_fwd_mode == 1 || (ds_fwd_mode == 2 && save && t->ds_stream)) && !vince_profile_enabled() &&
@@ -788,18 +786,18 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // (vince_bn_gram_finalize), so they are known BEFORE conv3 runs and its epilogue applies bn3 + identity + ReLU in place on
     // the identity tensor -- y3 is neither written nor re-read and conv3 carries no statistics epilogue (28 -> 21 tensor
     // passes per block).  Backward needs y3, so grad-enabled forwards keep the separate passes.  VINCE_GRAM_JOIN=0: off.
-    static const bool gram_env = !(getenv("VINCE_GRAM_JOIN") && atoi(getenv("VINCE_GRAM_JOIN")) == 0);
+    static const bool gram_env = (vince_knob("gram_join", 1) != 0);
     const bool gram_nograd = gram_env && train_bn && !save && !ds_side;
     // Grad-enabled forwards CAN take the same route where the streaming kernel applies (bf16, K = 64 / 128): it writes the block
     // output AND what backward reads -- conv3's raw output and the ReLU mask bytes -- so the join pass, its re-read of y3 and
     // conv3's statistics epilogue go (17 -> 13 tensor passes for conv3 + join).  OPT-IN (VINCE_GRAM_TRAIN=1): measured neutral in
     // the full step (27.21 vs 27.28 ms: the query forward overlaps the key encoder's, both HBM-bound) while the fp32 atomics of
     // the Gram sums make bn3's constants -- and through bf16 rounding the early-layer gradients -- vary from run to run.
-    static const bool xjoin_env = !(getenv("VINCE_XJOIN") && atoi(getenv("VINCE_XJOIN")) == 0);
+    static const bool xjoin_env = (vince_knob("xjoin", 1) != 0);
     // DEFAULT for bf16 training forwards since round 3 (VINCE_BN3_ALGEBRA, alg_block): the same route WITHOUT storing conv3's output
     // -- backward no longer reads it (csrc/bn_algebra.hip) -- 17 -> 9 tensor passes for conv3 + join.
     const bool alg_fwd = alg_env() && gram_env && xjoin_env && train_bn && save && !ds_side && c.dtype == VINCE_BF16;
-    const bool gram_train = gram_env && xjoin_env && (alg_fwd || (getenv("VINCE_GRAM_TRAIN") && atoi(getenv("VINCE_GRAM_TRAIN")) == 1)) &&
+    const bool gram_train = gram_env && xjoin_env && (alg_fwd || (vince_knob_live("gram_train", 0) == 1)) &&
                             train_bn && save && !ds_side && c.dtype == VINCE_BF16;
     if (save) t->fwd_alg = alg_fwd;
     const bool gram_on = gram_nograd || gram_train;
@@ -901,14 +899,14 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     // bound MFMA work next to HBM-bound streams).  dY lives in a 3-slot ring; a slot is rewritten only after the wgrad
     // that read it has finished (ev_wg), and a wgrad starts when its dY is complete (ev_dy).
     // (per-kernel event timing wants kernels to run alone: overlap is off while vince_profile_enable(1) is in effect)
-    static const bool overlap_env = !(getenv("VINCE_WGRAD_STREAM") && atoi(getenv("VINCE_WGRAD_STREAM")) == 0);
+    static const bool overlap_env = (vince_knob("wgrad_stream", 1) != 0);
     const bool overlap = overlap_env && !vince_profile_enabled() && vince_side_stream_budget() >= 1;
     hipStream_t main_s = (hipStream_t)stream;
     if (overlap && !t->side) {
         // The weight gradients are off the critical path (the chain of dgrad / BatchNorm launches on the caller's stream):
         // their stream gets the LOWEST priority so that a 1000-workgroup wgrad never delays the next dgrad's start
         // (-0.1 ms/step, 4 of 4 paired runs).  VINCE_SIDE_PRIO: 1 lowest (default), 0 same as the caller's, -1 highest.
-        static const int side_prio = getenv("VINCE_SIDE_PRIO") ? atoi(getenv("VINCE_SIDE_PRIO")) : 1;
+        static const int side_prio = VINCE_MEASURE_KNOB("side_prio", 1);
         if (side_prio != 0) {
             int least = 0, greatest = 0;
             VINCE_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -923,8 +921,8 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     }
     // the downsample branch of a stage-entry block only meets the main chain again at the block-input gradient: it runs on a
     // third stream (VINCE_DS_STREAM=0: inline on the main stream)
-    static const bool ds_env = !(getenv("VINCE_DS_STREAM") && atoi(getenv("VINCE_DS_STREAM")) == 0) &&
-                               !(getenv("VINCE_DS_STREAM_BWD") && atoi(getenv("VINCE_DS_STREAM_BWD")) == 0);
+    static const bool ds_env = (vince_knob("ds_stream", 1) != 0) &&
+                               (vince_knob("ds_stream_bwd", 1) != 0);
     const bool ds_overlap = overlap && ds_env && vince_side_stream_budget() >= 2;
     if (ds_overlap && !t->ds_stream) {
         VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->ds_stream, hipStreamNonBlocking));
@@ -964,8 +962,8 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     RC(vince_avgpool_bwd(c.dtype, dpooled, Z, N, t->outH * t->outW, t->outC, stream));
     // BatchNorm-backward reductions ride in the epilogue of the dgrad that produces their input gradient
     // (VINCE_FUSE_BNRED=0 runs them as separate passes: measurement aid)
-    static const bool fuse_red = !(getenv("VINCE_FUSE_BNRED") && atoi(getenv("VINCE_FUSE_BNRED")) == 0);
-    static const bool wgrad_late = getenv("VINCE_WGRAD_LATE") && atoi(getenv("VINCE_WGRAD_LATE")) != 0;
+    static const bool fuse_red = (VINCE_MEASURE_KNOB("fuse_bnred", 1) != 0);
+    static const bool wgrad_late = VINCE_MEASURE_KNOB("wgrad_late", 0) != 0;
     bool last_reduced = false;   // was the last-BN reduction of the current block done by the block above it?
     for (int bi = (int)t->blocks.size() - 1; bi >= 0; --bi) {
         const Blk& b = t->blocks[bi];
@@ -1021,10 +1019,12 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                 RC(vince_conv_wgrad(&dw, c.dtype, a_in, Z, grads[cv.param], cv.Ci, 0, stream));
             }
             RC(vince_bn3_bwd_prepare(grads[cv.param], wk, c.sums(bn), bn.R, c.consts(bn, 2), c.consts(bn, 3), params[bn.gamma], rows_out,
-                                     cv.Co, cv.Ci, ap.coef, ap.wd, ap.nq, ap.nr, grads[bn.gamma], grads[bn.beta], stream));
+                                     cv.Co, cv.Ci, ap.coef, ap.w2, 2 * cv.Co, (unsigned char*)ap.w2 + (size_t)cv.Co * 2, 2 * cv.Co, ap.nr,
+                                     grads[bn.gamma], grads[bn.beta], stream));
             RC(vince_bn3_bwd_finish_dw(grads[cv.param], wk, (const float*)at(workspace, b.gram), (const double*)at(workspace, b.colsum),
                                        GRAM_R, ap.coef, c.consts(bn, 2), c.consts(bn, 3), cv.Co, cv.Ci, stream));
-            // da = (W^T diag(s)) g + nr, then da += nq a (with the fused reduction of the BatchNorm below, as the plain dgrad has it)
+            // da = (W^T diag(s)) g + nq a + nr in ONE launch: the reduction runs over g's 4w channels (tap 0) and then over a's w
+            // channels (tap 1 = vince_conv_epi.in2), with the fused reduction of the BatchNorm below as the plain dgrad has it
             {
                 vince_conv_desc ds1[4];
                 const int n1 = dgrad_descs(t, cv, ds1);
@@ -1032,18 +1032,17 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                     vince_set_error("vince_trunk_backward: the BatchNorm-backward algebra expects a stride-1 1x1 convolution");
                     return VINCE_E_UNSUPPORTED;
                 }
+                vince_conv_desc dq = ds1[0];
+                dq.TA = 1; dq.TB = 2; dq.dh0 = dq.dw0 = 0; dq.dhs = 1; dq.dws = 0;
+                dq.wt0 = 0; dq.wta = 0; dq.wtb = 1; dq.WT = 2;
                 vince_conv_epi e1;
                 memset(&e1, 0, sizeof(e1));
                 e1.bias = ap.nr;
-                RC(vince_conv_igemm(&ds1[0], c.dtype, Z, ap.wd, DA, &e1, stream));
-                vince_conv_desc dq = fwd_desc(t, cv);
-                dq.Co = cv.Ci;
-                vince_conv_epi e2;
-                memset(&e2, 0, sizeof(e2));
-                e2.flags = VINCE_EPI_ACCUMULATE;
-                if (fuse_red) e2.bnred = bn_reduce_of(c, b.b[L - 1], nullptr, true, b.y[L - 1]);
-                e2.replicas = b.b[L - 1].R;
-                RC(vince_conv_igemm(&dq, c.dtype, a_in, ap.nq, DA, &e2, stream));
+                e1.in2 = a_in;
+                e1.in2_channels = cv.Ci;
+                if (fuse_red) e1.bnred = bn_reduce_of(c, b.b[L - 1], nullptr, true, b.y[L - 1]);
+                e1.replicas = b.b[L - 1].R;
+                RC(vince_conv_igemm(&dq, c.dtype, Z, ap.w2, DA, &e1, stream));
             }
             {
                 const int64_t rows = (int64_t)N * b.c[L - 1].Ho * b.c[L - 1].Wo;
@@ -1057,7 +1056,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             // bn_L's backward apply also accumulates the downsample BatchNorm's reduction (same g, its own y): one pass
             // over dz instead of two.  Its dY keeps ring slot A for the main chain below; the downsample branch (apply,
             // wgrad, dgrad -> DX) runs in the next slot first.  (VINCE_FUSE_DS_REDUCE=0: separate reduce pass)
-            static const bool fuse_ds = !(getenv("VINCE_FUSE_DS_REDUCE") && atoi(getenv("VINCE_FUSE_DS_REDUCE")) == 0);
+            static const bool fuse_ds = (VINCE_MEASURE_KNOB("fuse_ds_reduce", 1) != 0);
             vince_bn_reduce2 r2;
             r2.y = at(workspace, b.yd);
             r2.mean = c.consts(b.bd, 2);
@@ -1162,7 +1161,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         const BnL& sb = t->stem_bn;
         const uint8_t* amax = (const uint8_t*)at(workspace, t->off_amax);
         const void* ys = at(workspace, t->off_ystem);
-        static const bool fused_stem = !(getenv("VINCE_FUSE_STEM_BWD") && atoi(getenv("VINCE_FUSE_STEM_BWD")) == 0);
+        static const bool fused_stem = (VINCE_MEASURE_KNOB("fuse_stem_bwd", 1) != 0);
         if (fused_stem) {
             RC(vince_stem_bwd_reduce(c.dtype, Z, amax, ys, c.consts(sb, 2), c.consts(sb, 3), c.sums(sb), N, t->sH, t->sW, 64, stream));
             RC(vince_stem_bwd_apply(c.dtype, Z, amax, ys, c.consts(sb, 2), c.consts(sb, 3), params[sb.gamma], c.sums(sb), DY,

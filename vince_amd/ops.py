@@ -116,9 +116,9 @@ def bn_reduce_arg(y, mean, invstd, sums, mask_bits=None, mask_scale=None, mask_s
 
 
 def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None, replicas=0, out_scale=None,
-               id_scale=None, id_shift=None, out_mask=None):
+               id_scale=None, id_shift=None, out_mask=None, in2=None):
     """vince_conv_igemm with the epilogue options of vince_conv_epi."""
-    require_gpu(x, w, out, bias, stats, acc_mask, out_scale, id_scale, id_shift, out_mask)
+    require_gpu(x, w, out, bias, stats, acc_mask, out_scale, id_scale, id_shift, out_mask, in2)
     e = ConvEpi()
     e.flags = flags
     e.bias = None if bias is None else bias.data_ptr()
@@ -131,6 +131,8 @@ def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, b
     e.id_scale = None if id_scale is None else id_scale.data_ptr()
     e.id_shift = None if id_shift is None else id_shift.data_ptr()
     e.out_mask = None if out_mask is None else out_mask.data_ptr()
+    if in2 is not None:     # the last tap reads this tensor (vince_conv_epi.in2)
+        e.in2, e.in2_channels = in2.data_ptr(), in2.shape[-1]
     check(lib().vince_conv_igemm(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(w), _ptr(out), ctypes.byref(e),
                                  stream_ptr()))
     return out
@@ -194,17 +196,19 @@ def conv_expand_dgrad_masked(dy, wt, out, out_mask, gsums, accumulate=False, acc
 
 def bn3_bwd_prepare(R, w, gsums, mean, invstd, gamma, count, dgamma, dbeta):
     """vince_bn3_bwd_prepare (csrc/bn_algebra.hip): R float[Co][K] = g^T a, w bf16 [Co][K], gsums double[replicas][Co][2].
-    Returns coef float[4][Co], wd bf16 [K][Co], nq bf16 [K][K], nr float[K]; dgamma / dbeta are accumulated in place."""
+    Returns coef float[4][Co], w2 bf16 [K][2][Co] -- tap 0 = wd = W^T diag(s), tap 1 = nq = -W^T diag(t) W in its first K entries: the
+    weights of the one-launch input gradient da = wd g + nq a + nr (conv_igemm(..., in2=a)) -- and nr float[K]; dgamma / dbeta are
+    accumulated in place."""
     require_gpu(R, w, gsums, mean, invstd, gamma, dgamma, dbeta)
     Co, K = w.shape[0], w.shape[-1]
     dev = w.device
     coef = torch.empty(4, Co, device=dev, dtype=torch.float32)
-    wd = torch.empty(K, Co, device=dev, dtype=torch.bfloat16)
-    nq = torch.empty(K, K, device=dev, dtype=torch.bfloat16)
+    w2 = torch.zeros(K, 2, Co, device=dev, dtype=torch.bfloat16)
     nr = torch.empty(K, device=dev, dtype=torch.float32)
     check(lib().vince_bn3_bwd_prepare(_ptr(R), _ptr(w), _ptr(gsums), gsums.shape[0], _ptr(mean), _ptr(invstd), _ptr(gamma), int(count),
-                                      Co, K, _ptr(coef), _ptr(wd), _ptr(nq), _ptr(nr), _ptr(dgamma), _ptr(dbeta), stream_ptr()))
-    return coef, wd, nq, nr
+                                      Co, K, _ptr(coef), w2.data_ptr(), 2 * Co, w2.data_ptr() + 2 * Co, 2 * Co, _ptr(nr), _ptr(dgamma),
+                                      _ptr(dbeta), stream_ptr()))
+    return coef, w2, nr
 
 
 def bn3_bwd_finish_dw(RdW, w, gram, colsum, coef, mean, invstd):
