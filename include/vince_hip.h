@@ -207,6 +207,14 @@ int vince_conv_expand_dgrad_masked(int dtype, const void* dy, const void* wt, in
 int vince_conv_wgrad(const vince_conv_desc* d, int dtype, const void* in, const void* dy, float* dw,
                      int32_t Ci_dw, int variant, void* stream);
 
+/* The same weight gradient, REPRODUCIBLE: every pixel-range split stores its partial result into `scratch` (plain stores, dw layout per
+ * split) and one reduction launch adds the splits into dw in a fixed order -- no fp32 atomics, so two runs give identical bits (and the
+ * Gram matrices / BatchNorm constants derived from them likewise).  scratch: vince_conv_wgrad_scratch_bytes() bytes (16-byte aligned;
+ * a shorter buffer lowers the split count); NULL = the atomic path of vince_conv_wgrad.  Needs the plain forward tap order. */
+int vince_conv_wgrad_det(const vince_conv_desc* d, int dtype, const void* in, const void* dy, float* dw, int32_t Ci_dw,
+                         void* scratch, size_t scratch_bytes, void* stream);
+size_t vince_conv_wgrad_scratch_bytes(const vince_conv_desc* d, int dtype, int32_t Ci_dw);
+
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm2d (K4/K5; resnet.py:69,72,110,112,171; eps 1e-5, momentum 0.1)
  */

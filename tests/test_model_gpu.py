@@ -910,6 +910,22 @@ def test_gram_statistics_join_in_the_training_forward_equals_separate_passes(mon
             assert c_new > c_old - 0.05, (n, c_new, c_old)
 
 
+def test_bf16_trunk_forward_is_reproducible():
+    """the Gram-statistics join feeds bn3 from a Gram matrix that used to be summed with fp32 atomics, so the key encoder's
+    keys varied from run to run.  The Gram matrices now take the reproducible weight-gradient path (vince_conv_wgrad_det: per-split
+    slabs + a fixed-order reduction), and the trunk output of two identical train-mode forwards is identical to the bit -- no-grad
+    (key encoder) and grad-enabled (query encoder) alike."""
+    _, model = build("ResNet50", 128, "bf16", 11)
+    model.train()
+    x = vo.structured_frames(8, 96, 96, seed=5).to(DEV)
+    outs = []
+    for grad in (False, False, True, True):
+        with torch.set_grad_enabled(grad):
+            o = model.get_embeddings({"data": x})
+        outs.append(o["spatial_features"].detach().float().clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
+
+
 def test_bn3_backward_algebra_in_the_model_vs_separate_passes(monkeypatch):
     """The default bf16 training route since round 3 (csrc/bn_algebra.hip; VINCE_KNOBS=bn3_algebra=0 restores the separate passes): layer1 /
     layer2 bottlenecks run conv3 + bn3 + join in one streaming launch that does NOT store conv3's output, and backward gets bn3's

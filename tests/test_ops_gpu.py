@@ -214,6 +214,14 @@ def test_conv_dgrad_wgrad(cfg, dtype):
         dw = torch.zeros(Co, k * k, Ci, device=DEV)
         ops.conv_wgrad(fd, to_nhwc(x.detach(), dtype), dyg, dw, variant=variant)
         assert_close(dw, ref_dw, dtype, f32=1e-4, what="wgrad variant %d" % variant)
+    # the reproducible path (per-split slabs + fixed-order reduction): same values, and two runs agree to the bit
+    dets = []
+    for _ in range(2):
+        dw = torch.zeros(Co, k * k, Ci, device=DEV)
+        ops.conv_wgrad_det(fd, to_nhwc(x.detach(), dtype), dyg, dw)
+        dets.append(dw)
+    assert_close(dets[0], ref_dw, dtype, f32=1e-4, what="deterministic wgrad")
+    assert torch.equal(dets[0], dets[1])
 
 
 def _random_conv_cases(n=14, seed=20260929):

@@ -66,6 +66,8 @@ PROTOTYPES = {
                                         c_void_p]),
     "vince_conv_expand_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_void_p, P(BnReduce),
                                         c_int32, c_void_p]),
+    "vince_conv_wgrad_det": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "vince_conv_wgrad_scratch_bytes": (c_size_t, [P(ConvDesc), c_int, c_int32]),
     "vince_conv_wgrad": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_void_p]),
     "vince_bn_finalize": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                   c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -29,6 +29,9 @@ struct WgradParams {
     int linear_x;                  // 1x1 / stride 1 / no padding: the input pixel IS the output pixel
     int xcd_group;                 // remap workgroups so that the tiles of one pixel range share an XCD
     int cs;                        // element stride between input pixels (= Ci unless the descriptor packs row taps)
+    float* slab;                   // deterministic mode: split `by` STORES its partial tile into slab + by * slab_stride (dw layout) and
+    size_t slab_stride;            // wgrad_reduce_kernel adds the slabs into dw in split order; null = fp32 atomics straight into dw
+    int ablate;                    // measurement build only (VINCE_WGRAD_ABLATE): 1 no atomics, 2 no main loop
 };
 
 constexpr int KP = 64;  // pixels per K tile
@@ -226,7 +229,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = c0 + wc * (CT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < d.Co) unsafeAtomicAdd(p.dw + ((size_t)co * wtn + widx) * p.Ci_dw + cdst, acc[j][i][r]);
+                if (co < d.Co) {
+                    const size_t idx = ((size_t)co * wtn + widx) * p.Ci_dw + cdst;
+                    if (p.slab) p.slab[(size_t)by * p.slab_stride + idx] = acc[j][i][r];
+                    else unsafeAtomicAdd(p.dw + idx, acc[j][i][r]);
+                }
             }
         }
     }
@@ -311,7 +318,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
     const int kt_begin = by * p.kt_per_split;
     const int kt_end = min(kt_begin + p.kt_per_split, p.nkt_total);
     if (kt_begin >= kt_end) return;
+#ifdef VINCE_MEASURE
+    const int nkt = (p.ablate & 2) ? 0 : kt_end - kt_begin;
+#else
     const int nkt = kt_end - kt_begin;
+#endif
 
     const v4i_t rsrc_y = make_rsrc(p.dy, p.dy_bytes);
     const v4i_t rsrc_x = make_rsrc(p.in, p.in_bytes);
@@ -399,6 +410,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
         nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
     }
     wait_vmcnt<0>();
+#ifdef VINCE_MEASURE
+    if (p.ablate & 1) {   // measurement build: no atomics (one dummy store keeps the accumulators alive)
+        float t_ = 0.f;
+        for (int j = 0; j < CJ; ++j) for (int i = 0; i < NJ; ++i) t_ += acc[j][i][0];
+        if (t_ == 1.2345f) p.dw[0] = t_;
+        return;
+    }
+#endif
 
     const int T_ = d.TA * d.TB;
 #pragma unroll
@@ -422,9 +441,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = c0 + wc * (CT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < d.Co) unsafeAtomicAdd(p.dw + ((size_t)co * wtn + widx) * p.Ci_dw + cdst, acc[j][i][r]);
+                if (co < d.Co) {
+                    const size_t idx = ((size_t)co * wtn + widx) * p.Ci_dw + cdst;
+                    if (p.slab) p.slab[(size_t)by * p.slab_stride + idx] = acc[j][i][r];
+                    else unsafeAtomicAdd(p.dw + idx, acc[j][i][r]);
+                }
             }
         }
+    }
+}
+
+// dw[i] += slab[0][i] + slab[1][i] + ... in split order (fixed -> run-to-run identical).  Thread = (float4 column, split lane): the
+// 256 threads of a workgroup cover 64 float4 columns x 4 split lanes, folded through LDS in lane order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, size_t stride, float* __restrict__ dw, size_t n4) {
+    __shared__ float4 red[4][64];
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const size_t i4 = (size_t)blockIdx.x * 64 + col;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < n4) {
+        // lane sl sums splits sl*q .. (sl+1)*q - 1 in order; the four partial sums are then added in lane order
+        const int q = (splits + 3) / 4, s0 = sl * q, s1 = min(splits, s0 + q);
+        for (int s_ = s0; s_ < s1; ++s_) {
+            const float4 v = *(const float4*)(slab + (size_t)s_ * stride + i4 * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[sl][col] = acc;
+    __syncthreads();
+    if (sl == 0 && i4 < n4) {
+        float4 o = *(float4*)(dw + i4 * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o.x += red[k][col].x; o.y += red[k][col].y; o.z += red[k][col].z; o.w += red[k][col].w; }
+        *(float4*)(dw + i4 * 4) = o;
     }
 }
 
@@ -444,8 +492,10 @@ int launch(const WgradParams& p, int splits, hipStream_t stream) {
     return VINCE_OK;
 }
 
+// scratch / scratch_bytes: the slab buffer of the deterministic mode (null: atomics); need_out: when non-null only the bytes the
+// default split count wants are computed, nothing is launched
 template <typename T>
-int dispatch(WgradParams& p, hipStream_t stream) {
+int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t scratch_bytes = 0, size_t* need_out = nullptr) {
     const vince_conv_desc& d = p.d;
     const int ntot = d.TA * d.TB * d.Ci;
     const int CT = d.Co <= 64 ? 64 : 128, NT = ntot <= 64 ? 64 : 128;
@@ -460,7 +510,11 @@ int dispatch(WgradParams& p, hipStream_t stream) {
     // is cut 3x finer.  At least 8 K-tiles per split.
     static int target_blocks = VINCE_MEASURE_KNOB("wgrad_blocks", 512);
     const int tiles = p.ctiles * p.ntiles;
-    int splits = (target_blocks + tiles - 1) / tiles;
+    // a multi-tap layer with a small output (layer1's 3x3: 64 x 576 floats in 5 tiles) is bound by its loop, not by atomics: twice
+    // the workgroups hide twice the latency (192 -> 134 us timed alone; every other shape is best at 512)
+    int target = target_blocks;
+    if (d.TA * d.TB > 1 && (long)d.Co * ntot <= 65536) target *= 2;
+    int splits = (target + tiles - 1) / tiles;
     const int max_splits = (p.nkt_total * kp / 64 + 7) / 8;   // at least 512 pixels per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -470,16 +524,66 @@ int dispatch(WgradParams& p, hipStream_t stream) {
     // tiles; in the overlapped step always-on measured best, so the threshold stays a measurement knob)
     static const int xcd_min_tiles = VINCE_MEASURE_KNOB("wgrad_xcd_min_tiles", 1);
     p.xcd_group = p.xcd_group && tiles >= xcd_min_tiles;
-    if (CT == 64 && NT == 64) return launch<T, 64, 64>(p, splits, stream);
-    if (CT == 64) return launch<T, 64, 128>(p, splits, stream);
-    if (NT == 64) return launch<T, 128, 64>(p, splits, stream);
-    return launch<T, 128, 128>(p, splits, stream);
+    p.slab = nullptr;
+    p.slab_stride = 0;
+    // deterministic mode: plain forward tap order (every [Co][WT][Ci_dw] position is produced by exactly one tile), float4-sized
+    const size_t dw_floats = (size_t)d.Co * d.WT * (d.Cs > 0 ? d.Kw : 1) * p.Ci_dw;
+    const bool plain_taps = d.wt0 == 0 && d.wtb == 1 && d.wta == d.TB && d.WT == d.TA * d.TB;
+    const bool det_ok = plain_taps && dw_floats % 4 == 0 && ((uintptr_t)p.dw & 15) == 0;
+    if (need_out) {
+        *need_out = det_ok ? (size_t)splits * dw_floats * sizeof(float) : 0;
+        return VINCE_OK;
+    }
+    if (scratch && det_ok) {
+        while (splits > 1 && (size_t)splits * dw_floats * sizeof(float) > scratch_bytes) {   // a short scratch buffer: fewer, longer splits
+            --splits;
+            p.kt_per_split = (p.nkt_total + splits - 1) / splits;
+            splits = (p.nkt_total + p.kt_per_split - 1) / p.kt_per_split;
+        }
+        if ((size_t)splits * dw_floats * sizeof(float) <= scratch_bytes) {
+            p.slab = (float*)scratch;
+            p.slab_stride = dw_floats;
+        }
+    }
+    int rc;
+    if (CT == 64 && NT == 64) rc = launch<T, 64, 64>(p, splits, stream);
+    else if (CT == 64) rc = launch<T, 64, 128>(p, splits, stream);
+    else if (NT == 64) rc = launch<T, 128, 64>(p, splits, stream);
+    else rc = launch<T, 128, 128>(p, splits, stream);
+    if (rc == VINCE_OK && p.slab) {
+        const size_t n4 = dw_floats / 4;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, (const float*)p.slab, splits, p.slab_stride,
+                           p.dw, n4);
+        VINCE_CHECK_LAUNCH();
+    }
+    return rc;
 }
 
 }  // namespace
 
+static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, const void* dy, float* dw, int32_t Ci_dw, int variant,
+                        void* scratch, size_t scratch_bytes, size_t* need_out, void* stream);
+
 extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void* in, const void* dy, float* dw,
                                 int32_t Ci_dw, int variant, void* stream) {
+    return wgrad_common(dd, dtype, in, dy, dw, Ci_dw, variant, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int vince_conv_wgrad_det(const vince_conv_desc* dd, int dtype, const void* in, const void* dy, float* dw, int32_t Ci_dw,
+                                    void* scratch, size_t scratch_bytes, void* stream) {
+    VINCE_CHECK_ARG(!scratch || ((uintptr_t)scratch & 15) == 0, VINCE_E_ALIGN, "vince_conv_wgrad_det: scratch must be 16-byte aligned");
+    return wgrad_common(dd, dtype, in, dy, dw, Ci_dw, 0, scratch, scratch_bytes, nullptr, stream);
+}
+
+extern "C" size_t vince_conv_wgrad_scratch_bytes(const vince_conv_desc* dd, int dtype, int32_t Ci_dw) {
+    size_t need = 0;
+    static float dummy_dw[4] __attribute__((aligned(16)));
+    if (wgrad_common(dd, dtype, dummy_dw, dummy_dw, dummy_dw, Ci_dw, 0, nullptr, 0, &need, nullptr) != VINCE_OK) return 0;
+    return need;
+}
+
+static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, const void* dy, float* dw, int32_t Ci_dw, int variant,
+                        void* scratch, size_t scratch_bytes, size_t* need_out, void* stream) {
     VINCE_CHECK_ARG(dd && in && dy && dw, VINCE_E_ARG, "vince_conv_wgrad: null pointer");
     VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_wgrad: bad dtype %d", dtype);
     const vince_conv_desc& d = *dd;
@@ -524,6 +628,7 @@ extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.dy = dy; p.dw = dw; p.Ci_dw = Ci_dw; p.variant = variant;
     p.cs = d.Cs > 0 ? d.Cs : d.Ci;
+    p.ablate = (int)VINCE_MEASURE_KNOB("wgrad_ablate", 0);
     static const int xcd_group = (VINCE_MEASURE_KNOB("wgrad_xcd", 1) != 0);
     p.xcd_group = xcd_group;
     {
@@ -535,12 +640,12 @@ extern "C" int vince_conv_wgrad(const vince_conv_desc* dd, int dtype, const void
     }
     hipStream_t s = (hipStream_t)stream;
     void* tok = nullptr;
-    if (vince_profile_enabled())
+    if (vince_profile_enabled() && !need_out)
     {
         vince_profile_begin_launch(dtype == VINCE_F32 ? 16 : 17, 2.0 * p.M * d.Co * T * (double)Ci_dw * (d.Cs > 0 ? d.Kw : 1), stream, &tok);
         vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh, 0);
     }
-    const int rc = dtype == VINCE_F32 ? dispatch<float>(p, s) : dispatch<bf16_t>(p, s);
+    const int rc = dtype == VINCE_F32 ? dispatch<float>(p, s, scratch, scratch_bytes, need_out) : dispatch<bf16_t>(p, s, scratch, scratch_bytes, need_out);
     if (tok) vince_profile_end_launch(tok, stream);
     return rc;
 }

@@ -81,6 +81,8 @@ struct vince_trunk {
     hipStream_t ds_stream = nullptr;
     hipEvent_t ev_ds_start = nullptr, ev_ds_dy = nullptr, ev_ds_wg = nullptr, ev_ds_done = nullptr;
     size_t off_dyd = 0;
+    // slab buffers of the reproducible weight gradient (vince_conv_wgrad_det): [0] launches on the caller's stream, [1] on the side stream
+    size_t off_wg_scratch[2] = {0, 0}, wg_scratch_bytes = 0;
     // the last grad-enabled forward took the Gram join WITHOUT storing conv3's output for the eligible blocks (alg_block): its
     // backward must run the BatchNorm-backward algebra for exactly those blocks
     bool fwd_alg = false;
@@ -334,6 +336,22 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     for (int i = 0; i < 3; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     for (int i = 0; i < 3; ++i) { t->off_dy[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     t->off_dyd = P.ws; P.ws = align_up(P.ws + t->max_act);
+    {   // the largest slab set any weight gradient (or Gram matrix) of this trunk wants
+        size_t need = 0;
+        auto want = [&](const vince_conv_desc& d, int ci_dw) { need = std::max(need, vince_conv_wgrad_scratch_bytes(&d, t->cfg.dtype, ci_dw)); };
+        want(stem_desc(t), 3);
+        for (const Blk& b : t->blocks) {
+            for (int ci = 0; ci < b.nconv; ++ci) want(fwd_desc(t, b.c[ci]), b.c[ci].Ci);
+            if (b.has_ds) want(fwd_desc(t, b.cd), b.cd.Ci);
+            if (b.gram != NONE) {
+                vince_conv_desc dg = fwd_desc(t, b.c[2]);
+                dg.Co = b.c[2].Ci;
+                want(dg, b.c[2].Ci);
+            }
+        }
+        t->wg_scratch_bytes = align_up(need);
+        for (int i = 0; i < 2; ++i) { t->off_wg_scratch[i] = P.ws; P.ws = align_up(P.ws + t->wg_scratch_bytes); }
+    }
     t->ws_bytes = P.ws;
     t->off_prep_table = P.wc;
     t->off_fold = align_up(P.wc + 128 * sizeof(vince_prep_entry));
@@ -555,9 +573,22 @@ int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, co
     return VINCE_OK;
 }
 
+// Weight-gradient launches.  VINCE_KNOBS wgrad_det: 1 (default) = the GRAM matrices (in = dy = a: BatchNorm constants of the fused joins and
+// of the BatchNorm-backward algebra) take the reproducible path -- per-split slabs in the workspace + a fixed-order reduction, so the
+// forward is bit-reproducible at no measurable cost; 2 = every weight gradient does (+0.45 ms per step: the slabs are extra HBM traffic,
+// 25.38 against 24.92 ms); 0 = fp32 atomics everywhere.  which: 0 = a launch on the caller's stream, 1 = on the engine's side stream
+// (each has its own slab buffer).
+int wgrad_launch(vince_trunk* t, void* ws, int dtype, const vince_conv_desc& d, const void* in, const void* dy, float* dw, int ci_dw,
+                 int which, void* stream) {
+    static const int det = (int)vince_knob("wgrad_det", 1);
+    const bool gram = in == dy;
+    if (!(det >= 2 || (det == 1 && gram)) || !t->wg_scratch_bytes) return vince_conv_wgrad(&d, dtype, in, dy, dw, ci_dw, 0, stream);
+    return vince_conv_wgrad_det(&d, dtype, in, dy, dw, ci_dw, at(ws, t->off_wg_scratch[which]), t->wg_scratch_bytes, stream);
+}
+
 int wgrad(Ctx& c, const ConvL& cv, const void* in, const void* dy, float* dw) {
     vince_conv_desc d = fwd_desc(c.t, cv);
-    return vince_conv_wgrad(&d, c.dtype, in, dy, dw, cv.Ci, 0, c.stream);
+    return wgrad_launch(c.t, c.ws, c.dtype, d, in, dy, dw, cv.Ci, 0, c.stream);
 }
 
 // BN backward for y (conv output) given the gradient dz wrt the activation that followed this BatchNorm.
@@ -840,7 +871,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             // Gram matrix of conv3's input through the weight-gradient kernel (in = dy = a): sum over pixels of a a^T
             vince_conv_desc dg = fwd_desc(t, cv);
             dg.Co = cv.Ci;
-            RC(vince_conv_wgrad(&dg, c.dtype, at(workspace, in), at(workspace, in), (float*)at(workspace, b.gram), cv.Ci, 0, stream));
+            RC(wgrad_launch(t, workspace, c.dtype, dg, at(workspace, in), at(workspace, in), (float*)at(workspace, b.gram), cv.Ci, 0, stream));
             RC(vince_bn_gram_finalize(c.dtype, (const float*)at(workspace, b.gram), (const double*)at(workspace, b.colsum), GRAM_R,
                                       rows, at((void*)wcache, cv.wk), cv.Ci, cv.Co, params[bn.gamma], params[bn.beta],
                                       bn_running[2 * bn.index], bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr,
@@ -945,10 +976,10 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         return VINCE_OK;
     };
     auto wgrad_async = [&](const vince_conv_desc& d, const void* in, float* dw, int ci_dw) -> int {
-        if (!overlap) return vince_conv_wgrad(&d, c.dtype, in, DY, dw, ci_dw, 0, stream);
+        if (!overlap) return wgrad_launch(t, workspace, c.dtype, d, in, DY, dw, ci_dw, 0, stream);
         VINCE_CHECK_HIP(hipEventRecord(t->ev_dy[slot], main_s));
         VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_dy[slot], 0));
-        RC(vince_conv_wgrad(&d, c.dtype, in, DY, dw, ci_dw, 0, (void*)t->side));
+        RC(wgrad_launch(t, workspace, c.dtype, d, in, DY, dw, ci_dw, 1, (void*)t->side));
         VINCE_CHECK_HIP(hipEventRecord(t->ev_wg[slot], t->side));
         t->wg_pending[slot] = true;
         return VINCE_OK;
@@ -994,7 +1025,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                     VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_ds_dy, 0));
                     {
                         const vince_conv_desc dd = fwd_desc(t, b.cd);
-                        RC(vince_conv_wgrad(&dd, c.dtype, x_in, DYD, grads[b.cd.param], b.cd.Ci, 0, (void*)t->side));
+                        RC(wgrad_launch(t, workspace, c.dtype, dd, x_in, DYD, grads[b.cd.param], b.cd.Ci, 1, (void*)t->side));
                     }
                     VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_wg, t->side));
                     ds_wg_pending = true;
@@ -1016,7 +1047,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             // R = g^T a straight into the weight-gradient buffer (on this stream: the algebra below needs it before the dgrad)
             {
                 const vince_conv_desc dw = fwd_desc(t, cv);
-                RC(vince_conv_wgrad(&dw, c.dtype, a_in, Z, grads[cv.param], cv.Ci, 0, stream));
+                RC(wgrad_launch(t, workspace, c.dtype, dw, a_in, Z, grads[cv.param], cv.Ci, 0, stream));
             }
             RC(vince_bn3_bwd_prepare(grads[cv.param], wk, c.sums(bn), bn.R, c.consts(bn, 2), c.consts(bn, 3), params[bn.gamma], rows_out,
                                      cv.Co, cv.Ci, ap.coef, ap.w2, 2 * cv.Co, (unsigned char*)ap.w2 + (size_t)cv.Co * 2, 2 * cv.Co, ap.nr,
@@ -1077,7 +1108,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                 VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_ds_dy, 0));
                 {
                     const vince_conv_desc dd = fwd_desc(t, b.cd);
-                    RC(vince_conv_wgrad(&dd, c.dtype, x_in, DYD, grads[b.cd.param], b.cd.Ci, 0, (void*)t->side));
+                    RC(wgrad_launch(t, workspace, c.dtype, dd, x_in, DYD, grads[b.cd.param], b.cd.Ci, 1, (void*)t->side));
                 }
                 VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_wg, t->side));
                 ds_wg_pending = true;

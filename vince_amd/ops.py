@@ -229,6 +229,18 @@ def conv_wgrad(desc, x, dy, dw, ci_dw=None, variant=0):
     return dw
 
 
+def conv_wgrad_det(desc, x, dy, dw, ci_dw=None, scratch=None):
+    """vince_conv_wgrad_det: the reproducible weight gradient (per-split slabs + a fixed-order reduction instead of fp32 atomics)."""
+    require_gpu(x, dy, dw, scratch)
+    ci = desc.Ci if ci_dw is None else ci_dw
+    if scratch is None:
+        need = lib().vince_conv_wgrad_scratch_bytes(ctypes.byref(desc), dtype_code(x), ci)
+        scratch = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    check(lib().vince_conv_wgrad_det(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(dy), _ptr(dw), ci, _ptr(scratch), scratch.numel(),
+                                     stream_ptr()))
+    return dw
+
+
 # ------------------------------------------------------------------------------------------------ linear layer helpers (fp32)
 def linear_fwd(x, weight, bias, relu=False):
     """y = [relu](x @ weight.T + bias) on the fp32 MFMA path (vince_model.py:38-42)."""
