@@ -288,21 +288,24 @@ template <int ROWBYTES> struct FragD<float, ROWBYTES> {
     }
 };
 
-template <typename T, int CT, int NT, int STAGES>
-__global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams p) {
+// NW wavefronts as 2 (channel halves) x NW/2 (reduction-side column groups): 4 = the 128 x 128 tile of 2 x 2 MFMA tiles per wavefront,
+// 8 = the 256 x 256 tile of the long multi-tap layers (4 x 2 MFMA tiles per wavefront: half the operand bytes per FLOP through L2 -> LDS)
+template <typename T, int CT, int NT, int STAGES, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad_dlds_kernel(const WgradParams p) {
     constexpr int CH = Elem<T>::CH;
     using S = WSmemD<T, CT, NT, STAGES>;
     constexpr int SPRY = S::YRB / 16, SPRX = S::XRB / 16;          // 16-byte slots per row
-    constexpr int RPPY = 256 / SPRY, RPPX = 256 / SPRX;           // rows per pass of the 4 waves
+    constexpr int NTHR = NW * 64, WNN = NW / 2;
+    constexpr int RPPY = NTHR / SPRY, RPPX = NTHR / SPRX;         // rows per pass of the NW waves
     constexpr int NY = KPD / RPPY, NX = KPD / RPPX;                // DMA instructions per thread per stage
     constexpr int PER_STAGE = NY + NX;
-    constexpr int CJ = CT / 64, NJ = NT / 64;
+    constexpr int CJ = CT / 64, NJ = NT / (32 * WNN);
     constexpr uint32_t OOB = 0x80000000u;
     __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave & 1, wn = wave >> 1;
+    const int wc = wave & 1, wn = wave >> 1;    // wn in [0, WNN)
     // All (channel, tap) tiles of one pixel range read the same dY / X rows: keep them on ONE XCD (one L2) and adjacent
     // in launch order.  The hardware deals workgroups to the 8 XCDs round-robin by linear id, so the linear id is
     // remapped to "XCD x gets a contiguous run of (split, tile) pairs" (VINCE_WGRAD_XCD=0: plain order, measurement aid).
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
         for (int e = 0; e < NY; ++e) {
             const uint32_t pix = pix0 + yrow + e * RPPY;
             const uint32_t off = (live && yvalid_c && pix < (uint32_t)p.M) ? pix * (uint32_t)d.Co * (uint32_t)sizeof(T) + ycol_off : OOB;
-            lds_dma16(ys + e * 4096, off, rsrc_y);
+            lds_dma16(ys + e * (NW * 1024), off, rsrc_y);
         }
 #pragma unroll
         for (int e = 0; e < NX; ++e) {
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
                         off = ((n * (uint32_t)d.Hi + hi) * (uint32_t)d.Wi + wi) * (uint32_t)p.cs * (uint32_t)sizeof(T) + xcol_off;
                 }
             }
-            lds_dma16(xs + e * 4096, off, rsrc_x);
+            lds_dma16(xs + e * (NW * 1024), off, rsrc_x);
         }
     };
 
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
 #pragma unroll
             for (int j = 0; j < CJ; ++j) af[j] = FragD<T, S::YRB>::load(ys, wc * (CT / 2) + j * 32, ks, lane);
 #pragma unroll
-            for (int i = 0; i < NJ; ++i) bf[i] = FragD<T, S::XRB>::load(xs, wn * (NT / 2) + i * 32, ks, lane);
+            for (int i = 0; i < NJ; ++i) bf[i] = FragD<T, S::XRB>::load(xs, wn * (NT / WNN) + i * 32, ks, lane);
 #pragma unroll
             for (int j = 0; j < CJ; ++j)
 #pragma unroll
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dlds_kernel(const WgradParams 
     const int T_ = d.TA * d.TB;
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
-        const int n = n0 + wn * (NT / 2) + i * 32 + (lane & 31);
+        const int n = n0 + wn * (NT / WNN) + i * 32 + (lane & 31);
         const int tp = (T_ == 1) ? 0 : (n >> p.log2_ci);
         const int ci = (T_ == 1) ? n : (n & ((1 << p.log2_ci) - 1));
         if (tp >= T_ || (T_ == 1 && n >= d.Ci)) continue;
@@ -499,6 +502,9 @@ int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t
     const vince_conv_desc& d = p.d;
     const int ntot = d.TA * d.TB * d.Ci;
     const int CT = d.Co <= 64 ? 64 : 128, NT = ntot <= 64 ? 64 : 128;
+    // (Measured and not kept, round 3: the same kernel as 8 wavefronts on a 256 x 256 tile for layer3 / layer4's 3x3 -- half the operand
+    // bytes per FLOP, one workgroup per CU -- 175 against 122 us: without a staggered schedule the lone lock-step workgroup loses more
+    // than the traffic gives back.  The template keeps its NW parameter.)
     p.ctiles = (d.Co + CT - 1) / CT;
     p.ntiles = (ntot + NT - 1) / NT;
     static int use_dlds_d = vince_knob("wgrad_dlds", 1);
