@@ -13,7 +13,6 @@ What is different underneath
     vince_solver.py:463-468; parameter gradients are written straight into the flat gradient buffer.
 There is no CPU path: tensors must be on the GPU.
 """
-import copy
 import ctypes
 import os
 from typing import Dict, Optional, Tuple
@@ -213,37 +212,28 @@ class _EncodeFn(torch.autograd.Function):
 
 class VinceModel(BaseModel):
     def __init__(self, args):
-        super(VinceModel, self).__init__(args)
-        self.args = args
-        self.num_frames = self.args.num_frames
+        super().__init__(args)
+        self.args, self.num_frames = args, args.num_frames
         self.compute_dtype = _compute_dtype(args)
 
-        # Network stuff (vince_model.py:25-49)
-        self.feature_extractor = self.args.backbone(self.args, -2)
-        self.feature_extractor.bind_owner(self)
-        resnet_output_channels = self.feature_extractor.output_channels
-        self.output_channels = resnet_output_channels
+        # Modules (vince_model.py:25-49).  Attribute names and nesting ARE the state-dict layout of the reference's checkpoints:
+        # feature_extractor.*, embedding.{0,2}.*, jigsaw_linear.*, jigsaw_embedding.{0,2}.*, imagenet_decoders.{0,1.0,1.2}.*
+        trunk = self.feature_extractor = args.backbone(args, -2)       # everything up to (not including) avgpool / fc
+        trunk.bind_owner(self)
+        width = self.output_channels = trunk.output_channels
+
+        def two_layer_head(n_in, n_out):
+            return nn.Sequential(nn.Linear(n_in, width), constants.NONLINEARITY(), nn.Linear(width, n_out))
+
         if getattr(self.args, "use_attention", False):
             raise NotImplementedError("--use-attention (dg_util AttentionPool2D) is not part of the HIP path")
-        self.embedding = nn.Sequential(
-            nn.Linear(self.output_channels, self.output_channels),
-            constants.NONLINEARITY(),
-            nn.Linear(self.output_channels, self.args.vince_embedding_size),
-        )
-        if self.args.jigsaw:
-            self.jigsaw_linear = nn.Linear(self.output_channels, self.output_channels)
-            self.jigsaw_embedding = nn.Sequential(
-                nn.Linear(self.output_channels * 9, self.output_channels),
-                constants.NONLINEARITY(),
-                nn.Linear(self.output_channels, self.args.vince_embedding_size),
-            )
-        if getattr(self.args, "use_imagenet", False):   # vince_model.py:79-90: plain torch side heads on detached features
-            self.imagenet_decoders = nn.ModuleList([
-                nn.Linear(self.output_channels, 1000),
-                nn.Sequential(nn.Linear(self.output_channels, self.output_channels), constants.NONLINEARITY(),
-                              nn.Linear(self.output_channels, 1000)),
-            ])
-            self.num_imagenet_decoders = len(self.imagenet_decoders)
+        self.embedding = two_layer_head(width, args.vince_embedding_size)
+        if args.jigsaw:                                 # nine tile features -> one embedding (vince_model.py:44-49)
+            self.jigsaw_linear = nn.Linear(width, width)
+            self.jigsaw_embedding = two_layer_head(9 * width, args.vince_embedding_size)
+        if getattr(args, "use_imagenet", False):        # vince_model.py:79-90: plain torch side heads on detached features
+            self.imagenet_decoders = nn.ModuleList([nn.Linear(width, 1000), two_layer_head(width, 1000)])
+            self.num_imagenet_decoders = 2
 
         self._anchor = torch.zeros((), requires_grad=True)
         self._trunks = {}
@@ -333,7 +323,7 @@ class VinceModel(BaseModel):
         return self
 
     def to(self, device):
-        super(VinceModel, self).to(device)   # the reference's VinceModel.to returns None (vince_model.py:92-94); we return self
+        super().to(device)   # the reference's VinceModel.to returns None (vince_model.py:92-94); we return self
         return self
 
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -524,19 +514,19 @@ class VinceModel(BaseModel):
     @staticmethod
     def split_dict_by_type(batch_types, batch_sizes, dict_to_split):
         # vince_model.py:106-121
-        num_total = 0
-        mini_batch_list = []
+        # One dict per batch type.  An entry with one element per type (lists like data_source, num_frames -- the reference tells
+        # them apart by LENGTH, a quirk kept: a tensor whose first dimension happens to equal the number of types is indexed too)
+        # is indexed by type; anything else is a row-wise concatenation and is sliced by the running row offset.
         assert "queue_vectors" not in dict_to_split
-        for ind, (batch_type, batch_size) in enumerate(zip(batch_types, batch_sizes)):
-            mini_batch = {
-                key: (val[ind] if len(val) == len(batch_types) else val[num_total: num_total + batch_size])
-                for key, val in dict_to_split.items()
-            }
-            mini_batch["batch_type"] = batch_type
-            mini_batch.pop("batch_types", None)
-            mini_batch_list.append(mini_batch)
-            num_total += batch_size
-        return mini_batch_list
+        n_types = len(batch_types)
+        starts = [sum(batch_sizes[:i]) for i in range(n_types)]
+        pieces = []
+        for i, (kind, rows, lo) in enumerate(zip(batch_types, batch_sizes, starts)):
+            piece = {name: (v[i] if len(v) == n_types else v[lo: lo + rows]) for name, v in dict_to_split.items()}
+            piece.pop("batch_types", None)
+            piece["batch_type"] = kind
+            pieces.append(piece)
+        return pieces
 
     def extract_features(self, inputs, run_average_layer=True):
         # vince_model.py:123-133
@@ -560,27 +550,22 @@ class VinceModel(BaseModel):
             if orders is None:   # vince_model.py:166: an independent random tile order per sample
                 orders = torch.rand(data.shape[0], 9, device=data.device).argsort(dim=1)
         spatial, pooled, pre, emb = self._run_encoder(data, jigsaw, orders)
-        return_val = {
-            "spatial_features": spatial,
-            "extracted_features": pre if jigsaw else pooled,   # vince_model.py:171-172 overwrites it in jigsaw mode
-            "prenorm_features": pre,
-            "embeddings": emb,
-        }
-        if "batch_types" in inputs:
-            return_val = self.split_dict_by_type(inputs["batch_types"], inputs["batch_sizes"], return_val)
-        return return_val
+        # vince_model.py:171-172 overwrites extracted_features with the nine-tile feature in jigsaw mode
+        feats = dict(spatial_features=spatial, extracted_features=pre if jigsaw else pooled, prenorm_features=pre, embeddings=emb)
+        if "batch_types" not in inputs:
+            return feats
+        return self.split_dict_by_type(inputs["batch_types"], inputs["batch_sizes"], feats)
 
     def forward(self, inputs: Dict[str, torch.Tensor]):
         # vince_model.py:198-250
-        return_val = copy.copy(inputs)
-        features = return_val["extracted_features"]
-        if inputs["data_source"] == "IN":
-            imagenet_features = features.clone().detach()
+        result = dict(inputs)             # shallow: the caller's dict is left as it was
+        from_imagenet = inputs["data_source"] == "IN"
+        if from_imagenet:                 # side heads see the features, the trunk sees none of their gradient
+            side_in = result["extracted_features"].detach().clone()
 
-        output = return_val["embeddings"]
+        output = result["embeddings"]
         if "queue_embeddings" in inputs and "vince_similarities" not in inputs:
-            queue_embeddings = inputs["queue_embeddings"]
-            queue_vectors = inputs["queue_vectors"]
+            q_emb, q_vec = inputs["queue_embeddings"], inputs["queue_vectors"]
             B = output.shape[0]
             if self.args.inter_batch_comparison:
                 if B != self.args.batch_size:
@@ -590,46 +575,40 @@ class VinceModel(BaseModel):
                 if self.args.self_batch_comparison:
                     loss_s, scal_s, dists_s, sw_s, _ = _InfoNCEFn.apply(
                         output, None, None, self.args.vince_self_temperature, frames, True, True)
-                    return_val.update(dict(
+                    result.update(dict(
                         vince_self_similarities=LazySimilarities(output, output.detach(), None, False),
                         vince_self_similarities_mask=("block_diag", frames, B, 0),
                         _vince_nce_self=dict(loss=loss_s, scalars=scal_s, dists=dists_s, softmax_weights=sw_s),
                     ))
-                loss, scal, dists, sw, pos = _InfoNCEFn.apply(output, queue_embeddings, queue_vectors,
+                loss, scal, dists, sw, pos = _InfoNCEFn.apply(output, q_emb, q_vec,
                                                               self.args.vince_temperature, frames, True, False)
-                sims = LazySimilarities(output, queue_embeddings.detach(), queue_vectors, False)
-                mask = ("block_diag", frames, B, queue_vectors.shape[0])
-                return_val["vince_l_neg"] = sims
+                sims = LazySimilarities(output, q_emb.detach(), q_vec, False)
+                mask = ("block_diag", frames, B, q_vec.shape[0])
+                result["vince_l_neg"] = sims
             else:
-                loss, scal, dists, sw, pos = _InfoNCEFn.apply(output, queue_embeddings, queue_vectors,
+                loss, scal, dists, sw, pos = _InfoNCEFn.apply(output, q_emb, q_vec,
                                                               self.args.vince_temperature, 1, False, False)
-                sims = LazySimilarities(output, queue_embeddings.detach(), queue_vectors, True)
-                mask = ("first_column", 1, B, queue_vectors.shape[0])
-                return_val["vince_l_pos"] = pos
-                return_val["vince_l_neg"] = LazySimilarities(output, queue_embeddings.detach(), queue_vectors, False,
-                                                             include_inb=False)
-            return_val.update(dict(
+                sims = LazySimilarities(output, q_emb.detach(), q_vec, True)
+                mask = ("first_column", 1, B, q_vec.shape[0])
+                result["vince_l_pos"] = pos
+                result["vince_l_neg"] = LazySimilarities(output, q_emb.detach(), q_vec, False, include_inb=False)
+            result.update(dict(
                 vince_similarities=sims,
                 vince_similarities_mask=mask,
                 _vince_nce=dict(loss=loss, scalars=scal, dists=dists, softmax_weights=sw),
             ))
 
-        if inputs["data_source"] == "IN":
-            imagenet_features = imagenet_features[: inputs["imagenet_labels"].shape[0]]
-            for ii, imagenet_decoder in enumerate(self.imagenet_decoders):
-                return_val["imagenet_decoder_%d" % ii] = imagenet_decoder(imagenet_features)
-        return return_val
+        if from_imagenet:                 # vince_model.py:245-249: only the labelled rows (the first of each clip) are decoded
+            side_in = side_in[: inputs["imagenet_labels"].shape[0]]
+            result.update(("imagenet_decoder_%d" % i, head(side_in)) for i, head in enumerate(self.imagenet_decoders))
+        return result
 
     def loss(self, network_outputs: Optional[Dict]) -> Dict[str, Optional[Tuple[float, torch.Tensor]]]:
         # vince_model.py:252-290
-        if network_outputs is None:
-            losses = {"nce_loss": None}
-            if self.args.self_batch_comparison:
-                losses["nce_loss_self"] = None
-            if hasattr(self, "num_imagenet_decoders"):
-                for ii in range(self.num_imagenet_decoders):
-                    losses["imagenet_loss_%d" % ii] = None
-            return losses
+        if network_outputs is None:       # the solver asks for the NAMES first (meters): vince_model.py:253-261
+            names = ["nce_loss"] + (["nce_loss_self"] if self.args.self_batch_comparison else [])
+            names += ["imagenet_loss_%d" % i for i in range(getattr(self, "num_imagenet_decoders", 0))]
+            return dict.fromkeys(names)
 
         losses = {}
         for key, lkey in (("", "nce_loss"), ("self_", "nce_loss_self")):
@@ -661,16 +640,12 @@ class VinceModel(BaseModel):
         # vince_model.py:292-349
         with torch.no_grad():
             metrics = {}
-            if network_outputs is None:
-                metrics.update({"nce_accuracy_mean": None, "nce_softmax_weight_mean": None, "cosine_sim": None,
-                                "cosine_sim_neg_max": None})
+            if network_outputs is None:   # names only (vince_model.py:294-311)
+                names = ["nce_accuracy_mean", "nce_softmax_weight_mean", "cosine_sim", "cosine_sim_neg_max"]
                 if self.args.self_batch_comparison:
-                    metrics.update({"nce_accuracy_self_mean": None, "nce_softmax_weight_self_mean": None,
-                                    "cosine_self_sim": None})
-                if hasattr(self, "num_imagenet_decoders"):
-                    for ii in range(self.num_imagenet_decoders):
-                        metrics["imagenet_accuracy_%d" % ii] = None
-                return metrics
+                    names += ["nce_accuracy_self_mean", "nce_softmax_weight_self_mean", "cosine_self_sim"]
+                names += ["imagenet_accuracy_%d" % i for i in range(getattr(self, "num_imagenet_decoders", 0))]
+                return dict.fromkeys(names)
 
             for key in ["", "self_"]:
                 fused = network_outputs.get("_vince_nce" if key == "" else "_vince_nce_self")
@@ -708,7 +683,7 @@ class VinceQueueModel(BaseModel):
     """Momentum (key) encoder, vince_model.py:573-613."""
 
     def __init__(self, args, encoder: VinceModel):
-        super(VinceQueueModel, self).__init__(args)
+        super().__init__(args)
         # the reference deep-copies the encoder (:576); here a fresh model is built and the state copied, which is the
         # same thing without cloning engine handles / workspaces
         self.queue_network = VinceModel(args)
@@ -721,7 +696,7 @@ class VinceQueueModel(BaseModel):
         self.queue_network._build_flat()   # drop the gradient views of the frozen copy
 
     def to(self, device):
-        super(VinceQueueModel, self).to(device)
+        super().to(device)
         self._device = device
         return self
 
@@ -745,12 +720,6 @@ class VinceQueueModel(BaseModel):
             if "queue_jigsaw_orders" in inputs:
                 sub["jigsaw_orders"] = inputs["queue_jigsaw_orders"]
             output_mini_batches = self.queue_network.get_embeddings(sub, jigsaw=jigsaw, shuffle=shuffle)
-            return_vals = []
-            for outputs in output_mini_batches:
-                return_val = {}
-                for key, val in outputs.items():
-                    if isinstance(val, torch.Tensor):
-                        val = val.detach()
-                    return_val["queue_" + key] = val
-                return_vals.append(return_val)
-            return return_vals
+            # every output of the key encoder re-keyed "queue_<name>", tensors cut from any graph
+            return [{"queue_" + name: (v.detach() if isinstance(v, torch.Tensor) else v) for name, v in part.items()}
+                    for part in output_mini_batches]

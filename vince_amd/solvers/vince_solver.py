@@ -45,15 +45,11 @@ def stack_dicts_in_list(dicts, concat=False):
 
 class VinceSolver(BaseSolver):
     def __init__(self, args, train_logger=None, val_logger=None):
-        self.num_frames = args.num_frames
-        self.train_batch_fns = []
-        self.val_batch_fns = []
-        self.vince_queue: StorageQueue = None
-        self.queue_model: VinceQueueModel = None
-        self.batch_count = 0
-        self.batch_queue = Queue(2)
-        self.prefetch_thread = None
-        self.kill_thread = False
+        # (attribute names are the reference's: end-task code and drivers reach into them)
+        self.num_frames, self.batch_count = args.num_frames, 0
+        self.train_batch_fns, self.val_batch_fns = [], []
+        self.vince_queue, self.queue_model = None, None      # StorageQueue / VinceQueueModel, built by setup_model
+        self.batch_queue, self.prefetch_thread, self.kill_thread = Queue(2), None, False
         self.drawn_this_epoch = False
         self.reducer = None
         self._dp_step = 0
@@ -61,7 +57,7 @@ class VinceSolver(BaseSolver):
         self._key_stream = None
         self._jigsaw_rng = None
         self.overlap_key_encoder = bool(int(os.environ.get("VINCE_OVERLAP_KEY", "1")))
-        super(VinceSolver, self).__init__(args, train_logger, val_logger)
+        super().__init__(args, train_logger, val_logger)
 
     # ------------------------------------------------------------------------------------------ setup
     def _torch_device(self):
@@ -123,66 +119,67 @@ class VinceSolver(BaseSolver):
             if getattr(args, "long_save_checkpoint_dir", None):
                 args.long_save_checkpoint_dir = os.path.join(
                     base, args.title, *(args.long_save_checkpoint_dir.split(os.sep)[2:-1]), constants.TIME_STR)
-        self.model = VinceModel(args)
-        self.iteration = self.model.restore()
-        self.model.to(device)
+        model = self.model = VinceModel(args)
+        self.iteration = model.restore()      # the checkpoint's sample counter (0: fresh start)
+        model.to(device)
         w, _ = dp.world()
         if w > 1:   # replicas must start identical (the reference re-broadcasts parameters every forward)
             torch.distributed.broadcast(self.model._flat, src=0)
             self.model._touch()
-        self.queue_model = VinceQueueModel(args, self.model)
+        key_model = self.queue_model = VinceQueueModel(args, model)
         # the training loop never reads spatial_features after the next forward: skip the per-forward copy (51 MB at R50/B=256)
         self.model.clone_spatial = False
         self.queue_model.queue_network.clone_spatial = False
-        self.queue_model.to(device)
+        key_model.to(device)
         self.vince_queue = StorageQueue(args.vince_queue_size, args.vince_embedding_size, device=device,
                                         keep_images=getattr(args, "keep_queue_images", False))
         if w > 1:
             torch.distributed.broadcast(self.vince_queue.vector_queue, src=0)
-        self.epoch = self.iteration // (self.args.iterations_per_epoch * self.args.batch_size)
-        if self.iteration > 0:
+        samples_per_epoch = self.args.iterations_per_epoch * self.args.batch_size
+        self.epoch = self.iteration // samples_per_epoch
+        if self.iteration:
             print("Resuming epoch", self.epoch)
         if getattr(self.args, "prefetch_thread", False):
             self.start_prefetch()
         self.fill_queue_repeat()
 
     # ------------------------------------------------------------------------------------------ queue fill
+    @torch.no_grad()
     def fill_queue_repeat(self):
         # vince_solver.py:315-333: hard-copy the parameters, encode ONE batch, enqueue it repeatedly up to K, then reset
         # tail = 0 / full = False so the first real enqueue overwrites row 0 (App. D item 6).
         self.queue_model.param_update(self.model, 0)
-        num_added = 0
-        self.vince_queue.clear()
-        with torch.no_grad():
-            batches_concat, batches = self.get_batch()
-            outputs = self.queue_model(batches_concat)
-            while num_added < self.vince_queue.maxsize:
-                for batch, output in zip(batches, outputs):
-                    keys = dp.gather_keys(output["queue_embeddings"])
-                    self.vince_queue.enqueue(keys, None, batch["data_source"])
-                    num_added += keys.shape[0]
-                    if num_added >= self.vince_queue.maxsize:
-                        break
-        self.vince_queue.current_tail = 0
-        self.vince_queue.full = False
+        queue = self.vince_queue
+        queue.clear()
+        concat, parts = self.get_batch()
+        encoded = [(part["data_source"], dp.gather_keys(out["queue_embeddings"]))
+                   for part, out in zip(parts, self.queue_model(concat))]
+        written = 0
+        while written < queue.maxsize:
+            for source, keys in encoded:
+                queue.enqueue(keys, None, source)
+                written += keys.shape[0]
+                if written >= queue.maxsize:
+                    break
+        queue.current_tail, queue.full = 0, False
         print("Queue filled with repeats")
 
+    @torch.no_grad()
     def fill_queue(self):
         """vince_solver.py:293-313: the other way to warm the queue -- keys of as many DIFFERENT batches as it takes to write
         K rows (the last batch may wrap the ring, so the queue ends up full with the tail wherever the overshoot left it)."""
+        queue, written = self.vince_queue, 0
         self.queue_model.param_update(self.model, 0)
-        self.vince_queue.clear()
-        written = 0
+        queue.clear()
         print("Filling queue")
-        with torch.no_grad():
-            while written < self.vince_queue.maxsize:
-                concat, parts = self.get_batch()
-                for part, out in zip(parts, self.queue_model(concat)):
-                    keys = dp.gather_keys(out["queue_embeddings"])
-                    self.vince_queue.enqueue(keys, part.get("queue_data_cpu"), part["data_source"])
-                    written += keys.shape[0]
-                    if written >= self.vince_queue.maxsize:
-                        break
+        while written < queue.maxsize:
+            concat, parts = self.get_batch()
+            for part, out in zip(parts, self.queue_model(concat)):
+                keys = dp.gather_keys(out["queue_embeddings"])
+                queue.enqueue(keys, part.get("queue_data_cpu"), part["data_source"])
+                written += keys.shape[0]
+                if written >= queue.maxsize:
+                    break
         print("Queue filled")
 
     # ------------------------------------------------------------------------------------------ loader output -> batch dict
@@ -210,24 +207,23 @@ class VinceSolver(BaseSolver):
                 "num_frames": num_frames, "batch_type": "images", "batch_size": data.shape[0]}
 
     def reset_epoch(self):
-        super(VinceSolver, self).reset_epoch()
+        super().reset_epoch()
         self.queue_model.train()   # the key encoder never leaves train mode (vince_solver.py:337)
         self.drawn_this_epoch = False
 
     # ------------------------------------------------------------------------------------------ batches
     def _next_batches(self):
-        batches = []
-        for _ in range(len(self.train_batch_fns)):
-            loader_id = self.batch_count % len(self.train_batch_fns)
-            batch = self.train_batch_fns[loader_id](loader_id)
-            if batch is None:
+        batches, n_loaders, device = [], len(self.train_batch_fns), self.model.device
+        for _ in range(n_loaders):
+            which = self.batch_count % n_loaders
+            raw = self.train_batch_fns[which](which)
+            if raw is None:
                 return None
-            self.batch_count += 1
-            device = self.model.device
-            batch = {k: (v.to(device) if isinstance(v, (torch.Tensor, U8Frames)) else v) for k, v in batch.items()}
-            batch.setdefault("queue_data_cpu", None)
-            batches.append(batch)
-        if len(batches) == 1:
+            self.batch_count = self.batch_count + 1
+            moved = {k: (v.to(device) if isinstance(v, (torch.Tensor, U8Frames)) else v) for k, v in raw.items()}
+            moved.setdefault("queue_data_cpu", None)
+            batches.append(moved)
+        if n_loaders == 1:
             concat = {k: v if isinstance(v, (torch.Tensor, U8Frames)) else [v] for k, v in batches[0].items()}
         else:
             concat = stack_dicts_in_list(batches, concat=True)
@@ -247,20 +243,17 @@ class VinceSolver(BaseSolver):
         self.kill_thread = True
 
     def get_batch(self):
-        if self.prefetch_thread is not None:
-            batches = self.batch_queue.get()
-            while batches is None:
-                self.fill_queue_repeat()
-                batches = self.batch_queue.get()
-            return batches
-        batches = self._next_batches()
-        while batches is None:   # loader epoch ended: refill the queue with repeats (vince_solver.py:379-384)
+        # vince_solver.py:372-384: from the prefetch thread's queue when there is one; a None (the loaders' epoch ended) refills the
+        # negative queue with repeats and draws again
+        draw = self.batch_queue.get if self.prefetch_thread is not None else self._next_batches
+        while True:
+            drawn = draw()
+            if drawn is not None:
+                return drawn
             self.fill_queue_repeat()
-            batches = self._next_batches()
-        return batches
 
     # ------------------------------------------------------------------------------------------ cross-rank shuffle-BN
-    def _encode_keys(self, image_batch_concat, jig_key):
+    def _encode_keys(self, concat_batch, jig_key):
         """Key-encoder forward.  With `args.dp_shuffle_bn` (data parallel only) the key IMAGES are permuted across ranks
         first, so the batch each rank's key BatchNorms see is a random mix of the global batch -- MoCo's shuffle-BN, which
         the reference gets from permuting before the DataParallel scatter (vince_model.py:137-142).  Every rank then
@@ -268,14 +261,14 @@ class VinceSolver(BaseSolver):
         reused for the enqueue.  Off by default: it costs an all_to_all of the key images per step."""
         w, r = dp.world()
         shuffle_dp = (getattr(self.args, "dp_shuffle_bn", False) and self.reducer is not None and not jig_key
-                      and len(image_batch_concat["batch_sizes"]) == 1)
+                      and len(concat_batch["batch_sizes"]) == 1)
         if not shuffle_dp:
-            return self.queue_model(image_batch_concat, jigsaw=jig_key, shuffle=True), None
-        B = image_batch_concat["queue_data"].shape[0]
+            return self.queue_model(concat_batch, jigsaw=jig_key, shuffle=True), None
+        B = concat_batch["queue_data"].shape[0]
         perm = dp.global_permutation(w * B, step=self._dp_step, seed=17)
         self._dp_step += 1
-        mixed = dict(image_batch_concat)
-        mixed["queue_data"] = dp.exchange_rows(image_batch_concat["queue_data"], perm)
+        mixed = dict(concat_batch)
+        mixed["queue_data"] = dp.exchange_rows(concat_batch["queue_data"], perm)
         out = self.queue_model(mixed, jigsaw=False, shuffle=True)
         natural = dp.unpermute_gathered(dp.gather_keys(out[0]["queue_embeddings"]), perm)
         mine = {"queue_embeddings": natural[r * B:(r + 1) * B].contiguous()}
@@ -322,12 +315,16 @@ class VinceSolver(BaseSolver):
                                  % (n, first - 1, "" if context is None else " (now: %r)" % (context,)))
 
     def run_train_iteration(self):
-        total_t_start = time.time()
-        t_start = time.time()
-        image_batch_concat, image_batches = self.get_batch()
-        t_end = time.time()
-        self.time_meters["data_cache_time"].update(t_end - t_start)
-        t_start = time.time()
+        began = time.time()
+        clock = [began]
+
+        def lap(meter):      # the reference's four host-side timers: time since the previous lap into self.time_meters[meter]
+            now = time.time()
+            self.time_meters[meter].update(now - clock[0])
+            clock[0] = now
+
+        concat_batch, batch_parts = self.get_batch()
+        lap("data_cache_time")
 
         # key encoder (no grad) and query encoder (vince_solver.py:397-406).  The two forwards are independent (different
         # weights, different workspaces), so the key encoder runs on a side HIP stream and its kernels fill the launch
@@ -344,8 +341,8 @@ class VinceSolver(BaseSolver):
                 self._key_stream = torch.cuda.Stream()
             self._key_stream.wait_stream(main)
             with torch.cuda.stream(self._key_stream):
-                queue_batches, gathered_keys = self._encode_keys(image_batch_concat, jig_key)
-            outputs = self.model.get_embeddings(image_batch_concat, jigsaw=jig_query, shuffle=True)
+                queue_batches, gathered_keys = self._encode_keys(concat_batch, jig_key)
+            outputs = self.model.get_embeddings(concat_batch, jigsaw=jig_query, shuffle=True)
             main.wait_stream(self._key_stream)
             for qb in queue_batches:      # produced on the side stream, consumed (and later freed) on the main one
                 for v in qb.values():
@@ -354,25 +351,21 @@ class VinceSolver(BaseSolver):
             if gathered_keys is not None:
                 gathered_keys.record_stream(main)
         else:
-            queue_batches, gathered_keys = self._encode_keys(image_batch_concat, jig_key)
-            outputs = self.model.get_embeddings(image_batch_concat, jigsaw=jig_query, shuffle=True)
+            queue_batches, gathered_keys = self._encode_keys(concat_batch, jig_key)
+            outputs = self.model.get_embeddings(concat_batch, jigsaw=jig_query, shuffle=True)
 
-        t_end = time.time()
-        self.time_meters["forward_time"].update(t_end - t_start)
-        t_start = time.time()
+        lap("forward_time")
 
         loss_list, metrics_list = [], []
-        image_batches = self.model.split_dict_by_type(image_batch_concat["batch_types"], image_batch_concat["batch_sizes"],
-                                                      image_batch_concat)
-        for image_batch, queue_batch, output in zip(image_batches, queue_batches, outputs):
-            output.update(self.vince_queue.dequeue())
-            output.update(image_batch)
-            output.update(queue_batch)
+        batch_parts = self.model.split_dict_by_type(concat_batch["batch_types"], concat_batch["batch_sizes"],
+                                                      concat_batch)
+        for image_batch, queue_batch, output in zip(batch_parts, queue_batches, outputs):
+            # one dict per batch type, later entries win as in the reference's chain of updates: queue view, batch fields, keys
+            output.update({**self.vince_queue.dequeue(), **image_batch, **queue_batch})
             output.update(self.model(output))
-            loss_dict = self.model.loss(output)
-            metrics = self.model.get_metrics(output)
-            loss_list.append({key: val[0] * val[1] for key, val in loss_dict.items()})
-            metrics_list.append(metrics)
+            weighted = {name: weight * value for name, (weight, value) in self.model.loss(output).items()}
+            loss_list.append(weighted)
+            metrics_list.append(self.model.get_metrics(output))
 
         if len(loss_list) == 1:
             # one batch type (the usual case): the mean over a stack of one is the value itself -- skip the ~10 tiny
@@ -390,48 +383,46 @@ class VinceSolver(BaseSolver):
         # latch is read wherever the host synchronises anyway (log iterations, save, end of epoch) and raises there
         self._watch_loss(loss)
 
-        t_end = time.time()
-        self.time_meters["metrics_time"].update(t_end - t_start)
-        t_start = time.time()
+        lap("metrics_time")
         self.optimizer.zero_grad()
         loss.backward()
         if self.reducer is not None:
             self.reducer.reduce_after_backward()
         self.optimizer.step()
-        t_end = time.time()
-        self.time_meters["backward_time"].update(t_end - t_start)
+        lap("backward_time")
 
-        for image_batch, output in zip(image_batches, outputs):
+        for image_batch, output in zip(batch_parts, outputs):
             # update queue (after the optimizer step, before the EMA, vince_solver.py:497-499); with several ranks
             # every rank enqueues the same world*B block in rank order
             keys = gathered_keys if gathered_keys is not None else dp.gather_keys(output["queue_embeddings"])
             self.vince_queue.enqueue(keys, image_batch.get("queue_data_cpu"), image_batch["data_source"])
         self.queue_model.vince_update(self.model)
 
-        if self.logger_iteration % self.args.save_frequency == 0:
+        step_no = self.logger_iteration
+        if step_no % self.args.save_frequency == 0:
             self.save(5, sync=True)
 
-        if self.logger_iteration % self.args.log_frequency == 0:
+        if step_no % self.args.log_frequency == 0:
             # the only host synchronisation of the step: scalar read-back for the meters (the reference's
             # assert torch.isfinite(loss), vince_solver.py:446, synchronises every step)
             vals = {k: float(v.detach()) for k, v in loss_dict.items()}
-            total = sum(vals.values())
             self.check_loss_latch(vals)
-            for key, v in vals.items():
-                self.loss_meters[key].update(v)
-            if "total_loss" in self.loss_meters:
-                self.loss_meters["total_loss"].update(total)
+            for name, v in vals.items():
+                self.loss_meters[name].update(v)
+            if "total_loss" in self.loss_meters:       # (a meter the reference keeps beside the named terms)
+                self.loss_meters["total_loss"].update(sum(vals.values()))
                 updated_loss_meters.add("total_loss")
-            for key, val in metrics.items():
-                self.metric_meters[key].update(float(val))
+            for name, value in metrics.items():
+                self.metric_meters[name].update(float(value))
             if self.train_logger is not None:
-                log_dict = {"times/%s/%s" % (self.full_name, k): v.val for k, v in self.time_meters.items()}
-                log_dict.update({"losses/%s/%s" % (self.full_name, k): self.loss_meters[k].val for k in updated_loss_meters})
-                log_dict.update({"metrics/%s/%s" % (self.full_name, k): self.metric_meters[k].val for k in metrics})
-                self.train_logger.dict_log(log_dict, self.iteration)
+                tag = self.full_name
+                record = {"times/%s/%s" % (tag, k): m.val for k, m in self.time_meters.items()}
+                record.update({"losses/%s/%s" % (tag, k): self.loss_meters[k].val for k in updated_loss_meters})
+                record.update({"metrics/%s/%s" % (tag, k): self.metric_meters[k].val for k in metrics})
+                self.train_logger.dict_log(record, self.iteration)
 
-        self.iteration += self.args.batch_size
-        self.time_meters["total_time"].update(time.time() - total_t_start)
+        self.iteration += int(self.args.batch_size)       # the reference counts SAMPLES (vince_solver.py:514)
+        self.time_meters["total_time"].update(time.time() - began)
         self.logger_iteration += 1
         return loss_dict, metrics
 
@@ -470,11 +461,9 @@ class VinceSolver(BaseSolver):
                     concat["batch_sizes"] = concat.pop("batch_size")
                     queue_batches = self.queue_model(concat, shuffle=False)
                     outputs = self.model.get_embeddings(concat)
-                    image_batches = self.model.split_dict_by_type(concat["batch_types"], concat["batch_sizes"], concat)
-                    for image_batch, queue_batch, output in zip(image_batches, queue_batches, outputs):
-                        output.update(self.vince_queue.dequeue())
-                        output.update(image_batch)
-                        output.update(queue_batch)
+                    batch_parts = self.model.split_dict_by_type(concat["batch_types"], concat["batch_sizes"], concat)
+                    for image_batch, queue_batch, output in zip(batch_parts, queue_batches, outputs):
+                        output.update({**self.vince_queue.dequeue(), **image_batch, **queue_batch})
                         output.update(self.model(output))
                         for k, v in self.model.loss(output).items():
                             loss_meters[k].update(float(v[0] * v[1]), batch["batch_size"])

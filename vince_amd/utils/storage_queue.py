@@ -10,12 +10,10 @@ import torch
 from .. import ops
 
 
-class StorageQueue(object):
+class StorageQueue:
     def __init__(self, maxsize, feat_size, device=None, dtype=torch.float32, keep_images=False):
-        self.maxsize = maxsize
-        self.feat_size = feat_size
-        self.device = device
-        self.dtype = dtype
+        self.maxsize, self.feat_size = maxsize, feat_size
+        self.device, self.dtype = device, dtype
         self.keep_images = keep_images
         self.vector_queue = None
         self.clear()
@@ -24,17 +22,16 @@ class StorageQueue(object):
         return self.maxsize
 
     def clear(self):
-        # storage_queue.py:10-12,21-29: normalised Gaussian rows (K21)
-        fresh = torch.nn.functional.normalize(
-            torch.randn((self.maxsize, self.feat_size), device=self.device, requires_grad=False, dtype=self.dtype), dim=-1)
+        # storage_queue.py:10-12,21-29: rows drawn from a Gaussian and normalised; tail back at slot 0 (K21)
+        rows = torch.randn(self.maxsize, self.feat_size, device=self.device, dtype=self.dtype)
+        rows = torch.nn.functional.normalize(rows, dim=-1)
         if self.vector_queue is None:
-            self.vector_queue = fresh
+            self.vector_queue = rows
         else:
-            self.vector_queue.copy_(fresh)   # keep the storage: dequeue() views must stay valid
-        self.image_queue = [None for _ in range(self.maxsize)]
-        self.data_source_queue = [None for _ in range(self.maxsize)]
-        self.current_tail = 0
-        self.full = False
+            self.vector_queue.copy_(rows)    # keep the storage: dequeue() views must stay valid
+        self.image_queue = [None] * self.maxsize
+        self.data_source_queue = [None] * self.maxsize
+        self.current_tail, self.full = 0, False
 
     def enqueue(self, items, item_images=None, data_source=None):
         if item_images is not None:
@@ -53,8 +50,5 @@ class StorageQueue(object):
             self.data_source_queue[dst:dst + ln] = [data_source] * ln
 
     def dequeue(self):
-        return {
-            "queue_vectors": self.vector_queue.detach(),
-            "queue_images": self.image_queue,
-            "queue_data_sources": self.data_source_queue,
-        }
+        # views, not copies (storage_queue.py:51-56): the next enqueue shows through them
+        return dict(queue_vectors=self.vector_queue.detach(), queue_images=self.image_queue, queue_data_sources=self.data_source_queue)
