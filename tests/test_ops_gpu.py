@@ -320,6 +320,16 @@ def test_conv_suite_through_the_8_wavefront_core():
     _rerun_conv_tests({"VINCE_KNOBS": "m8=0"}, "test_conv_fwd_stats or test_conv_dgrad_wgrad")
 
 
+def test_wgrad_suite_through_every_tile_of_the_transposing_kernel():
+    """conv_wgrad_tr (csrc/conv_wgrad_tr.hip) picks its tile from the layer (128 wide wherever the side divides, else 64): every member
+    is re-run by forcing `wgrad_tile = ct * 1000 + nt` onto every test shape the tile divides, and the LDS-DMA kernel it replaced for
+    bf16 once with `wgrad_tr=0` (it still serves fp32)."""
+    sel = "test_conv_dgrad_wgrad or test_conv_random_shapes_fwd_dgrad_wgrad or test_bn3_backward_algebra_vs_autograd"
+    for tile in (64064, 64128, 128064):
+        _rerun_conv_tests({"VINCE_KNOBS": "wgrad_tile=%d" % tile}, sel)
+    _rerun_conv_tests({"VINCE_KNOBS": "wgrad_tr=0"}, sel)
+
+
 def test_conv_suite_through_whole_line_k_rows():
     """128-byte K rows (KC = 8) are taken by 1x1 reductions of at least kc8_min_k (VINCE_KNOBS) elements (2048 by default): re-run
     with the threshold at 64 so that every 1x1 test shape goes through them, forward and input gradient."""

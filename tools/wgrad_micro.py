@@ -1,5 +1,6 @@
 """Weight-gradient launches of the ResNet-50 layers at the benchmark batch, timed alone (bf16).  Usage: wgrad_micro.py [label]
-Measurement build: VINCE_HIP_LIB=.../libvince_hip_measure.so VINCE_WGRAD_ABLATE=1 (no atomics) / 2 (no main loop) / VINCE_WGRAD_BLOCKS=n."""
+Measurement build: VINCE_HIP_LIB=.../libvince_hip_measure.so VINCE_WGRAD_ABLATE=<bits> (1 no atomics, 2 no main loop, 4 no DMA, 8 no LDS
+fragment reads, 16 no MFMA) / VINCE_WGRAD_BLOCKS=n.  WGRAD_SHAPES=0,3 restricts the list; WGRAD_REPS=n launches per shape (PMC runs: no warm-up needed)."""
 import sys
 import torch
 sys.path.insert(0, ".")
@@ -8,13 +9,15 @@ N = 256
 # hw, ci, co, k
 SHAPES = [(14, 256, 256, 3), (28, 128, 128, 3), (56, 64, 64, 3), (7, 512, 512, 3), (14, 256, 1024, 1), (14, 1024, 256, 1),
           (28, 128, 512, 1), (28, 512, 128, 1), (56, 64, 256, 1), (56, 256, 64, 1), (7, 512, 2048, 1), (7, 2048, 512, 1)]
+import os
+if os.environ.get("WGRAD_SHAPES"):
+    SHAPES = [SHAPES[int(i)] for i in os.environ["WGRAD_SHAPES"].split(",")]
 res = []
 for hw, ci, co, k in SHAPES:
     x = torch.randn(N, hw, hw, ci, device="cuda").bfloat16()
     dy = torch.randn(N, hw, hw, co, device="cuda").bfloat16()
     dw = torch.zeros(co, k * k, ci, device="cuda")
     d = ops.conv_desc(N, hw, hw, ci, co, k, 1, k // 2)
-    import os
     det = os.environ.get("WGRAD_DET") == "1"
     scratch = None
     if det:
@@ -27,7 +30,7 @@ for hw, ci, co, k in SHAPES:
         run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
+    n = int(os.environ.get("WGRAD_REPS", "20"))
     e0.record()
     for _ in range(n):
         run()

@@ -13,26 +13,13 @@
 // fp32 atomics straight into the gradient buffer (rows of 32 consecutive floats per wave instruction).
 #include <stdlib.h>
 
-#include "common.h"
+#include <type_traits>
+
+#include "conv_wgrad.h"
 
 namespace {
 
-struct WgradParams {
-    vince_conv_desc d;
-    int log2_cpt, cpt_mask, log2_ci, total_nchunks, M, nkt_total, kt_per_split, ctiles, ntiles, Ci_dw, variant;
-    uint32_t tb_mul;
-    FastDiv div_howo, div_wo;
-    const void* in;
-    const void* dy;
-    float* dw;
-    uint32_t in_bytes, dy_bytes;   // descriptor ranges for the direct-to-LDS variant (0 = tensor too large)
-    int linear_x;                  // 1x1 / stride 1 / no padding: the input pixel IS the output pixel
-    int xcd_group;                 // remap workgroups so that the tiles of one pixel range share an XCD
-    int cs;                        // element stride between input pixels (= Ci unless the descriptor packs row taps)
-    float* slab;                   // deterministic mode: split `by` STORES its partial tile into slab + by * slab_stride (dw layout) and
-    size_t slab_stride;            // wgrad_reduce_kernel adds the slabs into dw in split order; null = fp32 atomics straight into dw
-    int ablate;                    // measurement build only (VINCE_WGRAD_ABLATE): 1 no atomics, 2 no main loop
-};
+using vince_wgrad::WgradParams;
 
 constexpr int KP = 64;  // pixels per K tile
 
@@ -290,8 +277,16 @@ template <int ROWBYTES> struct FragD<float, ROWBYTES> {
 
 // NW wavefronts as 2 (channel halves) x NW/2 (reduction-side column groups): 4 = the 128 x 128 tile of 2 x 2 MFMA tiles per wavefront,
 // 8 = the 256 x 256 tile of the long multi-tap layers (4 x 2 MFMA tiles per wavefront: half the operand bytes per FLOP through L2 -> LDS)
+// workgroups per CU the register allocation is held to (the LDS ring allows as many): the 128 x 128 bf16 tile sat 3 registers above three
+template <typename T, int CT, int NT, int STAGES, int NW>
+constexpr int wgrad_min_blocks() {
+    const int by_lds = 163840 / (STAGES * KPD * (CT + NT) * (int)sizeof(T));
+    const int want = (CT * NT / (NW * 64)) >= 128 ? 2 : (CT * NT / (NW * 64)) >= 64 ? 3 : 4;   // accumulator registers per lane: 128 / 64 / fewer
+    return by_lds < want ? (by_lds < 1 ? 1 : by_lds) : want;
+}
+
 template <typename T, int CT, int NT, int STAGES, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void conv_wgrad_dlds_kernel(const WgradParams p) {
+__global__ __launch_bounds__(NW * 64, (wgrad_min_blocks<T, CT, NT, STAGES, NW>())) void conv_wgrad_dlds_kernel(const WgradParams p) {
     constexpr int CH = Elem<T>::CH;
     using S = WSmemD<T, CT, NT, STAGES>;
     constexpr int SPRY = S::YRB / 16, SPRX = S::XRB / 16;          // 16-byte slots per row
@@ -392,16 +387,38 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_dlds_kernel(const WgradPar
     __syncthreads();
     int buf = 0, nbuf = STAGES - 1;
     for (int it = 0; it < nkt; ++it) {
+#ifdef VINCE_MEASURE
+        if (!(p.ablate & 4))      // 4: no DMA in the loop (stale tiles)
+#endif
         issue_slice(kt_begin + it + STAGES - 1, nbuf);
         const unsigned char* ys = smem + buf * S::STAGE;
         const unsigned char* xs = ys + S::YB;
 #pragma unroll
         for (int ks = 0; ks < FragD<T, S::YRB>::KSTEPS; ++ks) {
             uint4 af[CJ], bf[NJ];
+#ifdef VINCE_MEASURE
+            if (p.ablate & 8) {   // 8: no LDS fragment reads
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) af[j] = make_uint4(it + j, lane, ks, 1);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) bf[i] = make_uint4(it, lane + i, ks, 2);
+            } else
+#endif
+            {
 #pragma unroll
             for (int j = 0; j < CJ; ++j) af[j] = FragD<T, S::YRB>::load(ys, wc * (CT / 2) + j * 32, ks, lane);
 #pragma unroll
             for (int i = 0; i < NJ; ++i) bf[i] = FragD<T, S::XRB>::load(xs, wn * (NT / WNN) + i * 32, ks, lane);
+            }
+#ifdef VINCE_MEASURE
+            if (p.ablate & 16) {  // 16: no MFMA (fragments consumed by one add)
+#pragma unroll
+                for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < NJ; ++i) acc[j][i][0] += __uint_as_float(af[j].x ^ bf[i].y ^ af[j].z ^ bf[i].w ^ af[j].y ^ bf[i].x ^ af[j].w ^ bf[i].z);
+                continue;
+            }
+#endif
 #pragma unroll
             for (int j = 0; j < CJ; ++j)
 #pragma unroll
@@ -454,18 +471,28 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_dlds_kernel(const WgradPar
     }
 }
 
-// dw[i] += slab[0][i] + slab[1][i] + ... in split order (fixed -> run-to-run identical).  Thread = (float4 column, split lane): the
-// 256 threads of a workgroup cover 64 float4 columns x 4 split lanes, folded through LDS in lane order.
+// dw[i] += slab[0][i] + slab[1][i] + ... in a fixed order (-> run-to-run identical).  Thread = (float4 column, split lane): the 256
+// threads of a workgroup cover 16 float4 columns x 16 split lanes; lane l sums splits [l*q, (l+1)*q) in order, the 16 partial sums are
+// then added in lane order.  (16 lanes per column, not 4: a Gram matrix of layer1 is 1024 float4 columns under up to 512 slabs -- 16
+// workgroups walking 128 slabs each took 40 us on the forward's critical path, twice the GEMM that produced them.)
+constexpr int RED_COLS = 16, RED_LANES = 16;
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, size_t stride, float* __restrict__ dw, size_t n4) {
-    __shared__ float4 red[4][64];
-    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const size_t i4 = (size_t)blockIdx.x * 64 + col;
+    __shared__ float4 red[RED_LANES][RED_COLS];
+    const int col = threadIdx.x % RED_COLS, sl = threadIdx.x / RED_COLS;
+    const size_t i4 = (size_t)blockIdx.x * RED_COLS + col;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i4 < n4) {
-        // lane sl sums splits sl*q .. (sl+1)*q - 1 in order; the four partial sums are then added in lane order
-        const int q = (splits + 3) / 4, s0 = sl * q, s1 = min(splits, s0 + q);
-        for (int s_ = s0; s_ < s1; ++s_) {
-            const float4 v = *(const float4*)(slab + (size_t)s_ * stride + i4 * 4);
+        const int q = (splits + RED_LANES - 1) / RED_LANES, s0 = sl * q, s1 = min(splits, s0 + q);
+        const float* src = slab + (size_t)s0 * stride + i4 * 4;
+        int s_ = s0;
+        for (; s_ + 4 <= s1; s_ += 4, src += 4 * stride) {     // four loads in flight, added in split order
+            const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + stride), v2 = *(const float4*)(src + 2 * stride),
+                         v3 = *(const float4*)(src + 3 * stride);
+            acc.x = (((acc.x + v0.x) + v1.x) + v2.x) + v3.x; acc.y = (((acc.y + v0.y) + v1.y) + v2.y) + v3.y;
+            acc.z = (((acc.z + v0.z) + v1.z) + v2.z) + v3.z; acc.w = (((acc.w + v0.w) + v1.w) + v2.w) + v3.w;
+        }
+        for (; s_ < s1; ++s_, src += stride) {
+            const float4 v = *(const float4*)src;
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
@@ -474,7 +501,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (sl == 0 && i4 < n4) {
         float4 o = *(float4*)(dw + i4 * 4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { o.x += red[k][col].x; o.y += red[k][col].y; o.z += red[k][col].z; o.w += red[k][col].w; }
+        for (int k = 0; k < RED_LANES; ++k) { o.x += red[k][col].x; o.y += red[k][col].y; o.z += red[k][col].z; o.w += red[k][col].w; }
         *(float4*)(dw + i4 * 4) = o;
     }
 }
@@ -501,15 +528,23 @@ template <typename T>
 int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t scratch_bytes = 0, size_t* need_out = nullptr) {
     const vince_conv_desc& d = p.d;
     const int ntot = d.TA * d.TB * d.Ci;
-    const int CT = d.Co <= 64 ? 64 : 128, NT = ntot <= 64 ? 64 : 128;
-    // (Measured and not kept, round 3: the same kernel as 8 wavefronts on a 256 x 256 tile for layer3 / layer4's 3x3 -- half the operand
+    int CT = d.Co <= 64 ? 64 : 128, NT = ntot <= 64 ? 64 : 128;
+    // bf16: the transposing-read kernel of conv_wgrad_tr.hip with its own tile choice, whenever the layer qualifies (`wgrad_tr=0`: the
+    // LDS-DMA kernel of this file, cross-check switch)
+    static const int use_tr = (int)vince_knob("wgrad_tr", 1);
+    int tr_ct = 0, tr_nt = 0;
+    if (use_tr && std::is_same<T, bf16_t>::value) vince_wgrad::wgrad_tr_tile(p, &tr_ct, &tr_nt);
+    const bool tr = tr_ct > 0;
+    if (tr) { CT = tr_ct; NT = tr_nt; }
+    // (Measured and not kept, round 3: the LDS-DMA kernel as 8 wavefronts on a 256 x 256 tile for layer3 / layer4's 3x3 -- half the operand
     // bytes per FLOP, one workgroup per CU -- 175 against 122 us: without a staggered schedule the lone lock-step workgroup loses more
     // than the traffic gives back.  The template keeps its NW parameter.)
     p.ctiles = (d.Co + CT - 1) / CT;
     p.ntiles = (ntot + NT - 1) / NT;
     static int use_dlds_d = vince_knob("wgrad_dlds", 1);
-    const bool dlds = use_dlds_d && p.in_bytes && p.dy_bytes && p.variant == 0;
+    const bool dlds = tr || (use_dlds_d && p.in_bytes && p.dy_bytes && p.variant == 0);
     const int kp = dlds ? KPD : KP;                 // pixels per K slice of the kernel that will run
+    static_assert(KPD == vince_wgrad::TR_SLICE, "slice");
     p.nkt_total = (p.M + kp - 1) / kp;
     // Split the pixel range so that the grid is about one resident wave of workgroups (256 CUs x 2): every extra split
     // costs Co*T*Ci fp32 atomics in the epilogue, and the L2 atomic rate -- not MFMA -- bounds this kernel when the grid
@@ -552,13 +587,14 @@ int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t
         }
     }
     int rc;
-    if (CT == 64 && NT == 64) rc = launch<T, 64, 64>(p, splits, stream);
+    if (tr) rc = vince_wgrad::wgrad_tr_launch(p, CT, NT, splits, stream);
+    else     if (CT == 64 && NT == 64) rc = launch<T, 64, 64>(p, splits, stream);
     else if (CT == 64) rc = launch<T, 64, 128>(p, splits, stream);
     else if (NT == 64) rc = launch<T, 128, 64>(p, splits, stream);
     else rc = launch<T, 128, 128>(p, splits, stream);
     if (rc == VINCE_OK && p.slab) {
         const size_t n4 = dw_floats / 4;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, (const float*)p.slab, splits, p.slab_stride,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + RED_COLS - 1) / RED_COLS)), dim3(256), 0, stream, (const float*)p.slab, splits, p.slab_stride,
                            p.dw, n4);
         VINCE_CHECK_LAUNCH();
     }
@@ -591,6 +627,13 @@ extern "C" size_t vince_conv_wgrad_scratch_bytes(const vince_conv_desc* dd, int 
 static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, const void* dy, float* dw, int32_t Ci_dw, int variant,
                         void* scratch, size_t scratch_bytes, size_t* need_out, void* stream) {
     VINCE_CHECK_ARG(dd && in && dy && dw, VINCE_E_ARG, "vince_conv_wgrad: null pointer");
+#if defined(VINCE_MEASURE) || defined(VINCE_STEP_ABLATE)
+    {   // measurement builds (-DVINCE_STEP_ABLATE: the product kernels + this switch): 1 = no weight-gradient launch at all, 2 = only
+        // the Gram matrices (in == dy) run -- what the family costs inside the overlapped step
+        static const long skip = getenv("VINCE_WGRAD_SKIP") ? atol(getenv("VINCE_WGRAD_SKIP")) : 0;
+        if (!need_out && (skip == 1 || (skip == 2 && in != dy))) return VINCE_OK;
+    }
+#endif
     VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_wgrad: bad dtype %d", dtype);
     const vince_conv_desc& d = *dd;
     const int CH = dtype == VINCE_F32 ? 4 : 8;
@@ -635,6 +678,12 @@ static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, co
     p.in = in; p.dy = dy; p.dw = dw; p.Ci_dw = Ci_dw; p.variant = variant;
     p.cs = d.Cs > 0 ? d.Cs : d.Ci;
     p.ablate = (int)VINCE_MEASURE_KNOB("wgrad_ablate", 0);
+#ifdef VINCE_STEP_ABLATE
+    {
+        static const int abl = getenv("VINCE_WGRAD_ABLATE") ? atoi(getenv("VINCE_WGRAD_ABLATE")) : 0;
+        p.ablate = in != dy ? abl : 0;     // the Gram matrices stay exact: the forward's statistics depend on them
+    }
+#endif
     static const int xcd_group = (VINCE_MEASURE_KNOB("wgrad_xcd", 1) != 0);
     p.xcd_group = xcd_group;
     {

@@ -49,6 +49,7 @@ struct Blk {
 constexpr size_t NONE = (size_t)-1;
 // Gram-statistics residual join: conv3 reductions up to this length; replicas of the column sums
 constexpr int GRAM_MAX_K = 128, GRAM_R = 4;
+constexpr int NDY_MAX = 8;          // most slots the dY ring of the backward pass can be given (VINCE_KNOBS=dy_slots)
 
 }  // namespace
 
@@ -67,7 +68,7 @@ struct vince_trunk {
     std::vector<std::array<int, 4>> pshape;
     std::vector<std::string> bnnames;
     std::vector<int> bnC;
-    size_t off_x0, off_ystem, off_amax, off_p0, off_stats, off_sums, off_consts, off_g[3], off_dy[3];
+    size_t off_x0, off_ystem, off_amax, off_p0, off_stats, off_sums, off_consts, off_g[3], off_dy[NDY_MAX];
     size_t n_stats_doubles, n_consts_floats, max_act, ws_bytes, wc_bytes, off_prep_table;
     size_t off_gram = 0, gram_bytes = 0;      // Gram matrices + column sums of the eligible blocks (zeroed per forward)
     std::vector<vince_prep_entry> prep_table[2];   // last uploaded batched weight-prep descriptors (training / folded)
@@ -75,8 +76,9 @@ struct vince_trunk {
     size_t off_fold;      // fold constants (scale, bias per BN channel + ones/zeros) inside a weight cache
     // weight-gradient side stream (created on first backward) + per-slot events of the dY ring
     hipStream_t side = nullptr;
-    hipEvent_t ev_dy[3] = {nullptr, nullptr, nullptr}, ev_wg[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr;
-    bool wg_pending[3] = {false, false, false};
+    hipEvent_t ev_dy[NDY_MAX] = {}, ev_wg[NDY_MAX] = {}, ev_join = nullptr;
+    bool wg_pending[NDY_MAX] = {};
+    int ndy = 3;                     // slots of the dY ring in use (knob `dy_slots`, 3 .. NDY_MAX)
     // downsample-branch stream of the 4 stage-entry blocks (backward): its own dY buffer and events
     hipStream_t ds_stream = nullptr;
     hipEvent_t ev_ds_start = nullptr, ev_ds_dy = nullptr, ev_ds_wg = nullptr, ev_ds_done = nullptr;
@@ -334,7 +336,10 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
         }
     }
     for (int i = 0; i < 3; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
-    for (int i = 0; i < 3; ++i) { t->off_dy[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
+    t->ndy = (int)vince_knob("dy_slots", 3);
+    if (t->ndy < 3) t->ndy = 3;
+    if (t->ndy > NDY_MAX) t->ndy = NDY_MAX;
+    for (int i = 0; i < t->ndy; ++i) { t->off_dy[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     t->off_dyd = P.ws; P.ws = align_up(P.ws + t->max_act);
     {   // the largest slab set any weight gradient (or Gram matrix) of this trunk wants
         size_t need = 0;
@@ -364,7 +369,7 @@ extern "C" void vince_trunk_destroy(vince_trunk_t t) {
     if (!t) return;
     if (t->side) {
         hipStreamSynchronize(t->side);
-        for (int i = 0; i < 3; ++i) { hipEventDestroy(t->ev_dy[i]); hipEventDestroy(t->ev_wg[i]); }
+        for (int i = 0; i < t->ndy; ++i) { hipEventDestroy(t->ev_dy[i]); hipEventDestroy(t->ev_wg[i]); }
         hipEventDestroy(t->ev_join);
         hipStreamDestroy(t->side);
     }
@@ -944,7 +949,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             VINCE_CHECK_HIP(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, side_prio > 0 ? least : greatest));
         } else
         VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < t->ndy; ++i) {
             VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_dy[i], hipEventDisableTiming));
             VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_wg[i], hipEventDisableTiming));
         }
@@ -963,11 +968,11 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_done, hipEventDisableTiming));
     }
     bool ds_wg_pending = false, ds_done_pending = false;
-    for (int i = 0; i < 3; ++i) t->wg_pending[i] = false;
+    for (int i = 0; i < t->ndy; ++i) t->wg_pending[i] = false;
     int slot = 0;
     void* DY = nullptr;
     auto next_dy = [&]() -> int {      // claim the next ring slot for writing on the main stream
-        slot = (slot + 1) % 3;
+        slot = (slot + 1) % t->ndy;
         if (overlap && t->wg_pending[slot]) {
             VINCE_CHECK_HIP(hipStreamWaitEvent(main_s, t->ev_wg[slot], 0));
             t->wg_pending[slot] = false;
@@ -1206,7 +1211,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     if (overlap) {   // the caller's stream continues only after every weight gradient has landed
         VINCE_CHECK_HIP(hipEventRecord(t->ev_join, t->side));
         VINCE_CHECK_HIP(hipStreamWaitEvent(main_s, t->ev_join, 0));
-        for (int i = 0; i < 3; ++i) t->wg_pending[i] = false;
+        for (int i = 0; i < t->ndy; ++i) t->wg_pending[i] = false;
     }
     return VINCE_OK;
 }
