@@ -967,6 +967,29 @@ def test_bn3_backward_algebra_in_the_model_vs_separate_passes(monkeypatch):
             assert c_new > c_old - 0.05, (n, c_new, c_old)
 
 
+def test_backward_with_a_deeper_dy_ring_and_the_old_wgrad_kernel_gives_the_same_gradients(monkeypatch):
+    """Two engine switches that must not change results: `dy_slots` (how many layer gradients the backward pass keeps alive for the
+    weight-gradient stream; 3 by default, up to 8) and `wgrad_tr=0` (bf16 weight gradients through the LDS-DMA kernel that
+    conv_wgrad_tr replaced).  Same model, same batch: every parameter gradient agrees to the fp32-atomics noise of the split-K sums."""
+    grads = {}
+    for knobs in ("", "dy_slots=6", "wgrad_tr=0"):
+        monkeypatch.setenv("VINCE_KNOBS", knobs)
+        _, model = build("ResNet50", 128, "bf16", 11)
+        model.train()
+        x = vo.structured_frames(8, 128, 128, seed=78).to(DEV)
+        o = model.get_embeddings({"data": x})
+        w = torch.randn(8, 128, generator=torch.Generator().manual_seed(4)).to(DEV)
+        model.zero_grad()
+        (o["embeddings"] * w).sum().backward()
+        torch.cuda.synchronize()
+        grads[knobs] = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+    for knobs in ("dy_slots=6", "wgrad_tr=0"):
+        for n, g0 in grads[""].items():
+            g1 = grads[knobs][n]
+            scale = float(g0.abs().max()) + 1e-12
+            assert float((g1 - g0).abs().max()) / scale < 2e-4, (knobs, n, float((g1 - g0).abs().max()), scale)
+
+
 def test_bench_multi_rank_launch_contract_on_one_gpu():
     """The driver's N > 1 launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) with four
     ranks sharing this GPU through gloo (VINCE_BENCH_ONE_GPU=1): rendezvous from the environment, bucketed gradient

@@ -9,11 +9,15 @@ timeout 60 python tools/layer_roofline.py $O/layers.csv 3 > $O/layer_roofline.tx
 # the no-grad forward alone (the forward + InfoNCE leg's trunk)
 bash tools/fwd_kstats.sh VINCE_KNOBS=gram_join=1 VINCE_KNOBS=gram_join=0 > $O/fwd_ms.txt 2>&1; cp gpurun_out/r2/fwd_kstats_1.txt $O/fwd_kernel_stats.txt; cp gpurun_out/r2/fwd_kstats_2.txt $O/fwd_kernel_stats_separate_passes.txt
 timeout 600 rocprofv3 --kernel-trace -d $O/kt -o kt -- python bench.py --no-extras > $O/kt.log 2>&1
-DB=$(find $O/kt -name '*.db' | head -1); timeout 60 python tools/rocpd_stats.py $DB 45 > $O/kernel_stats.txt 2>&1; rm -rf $O/kt
+DB=$(find $O/kt -name '*.db' | head -1); timeout 60 python tools/rocpd_stats.py $DB 45 > $O/kernel_stats.txt 2>&1
+# which stream is busy when (per queue, kernels in flight, per-millisecond bins) of one overlapped step of the same trace
+timeout 60 python tools/rocpd_overlap.py $DB > $O/step_overlap.txt 2>&1; rm -rf $O/kt
 # the same with every stream serialised (one kernel at a time, like the instrumented steps behind bench.py's `roofline`): the
 # per-kernel average durations of THIS file are the ones that agree with roofline.avg_us
 VINCE_OVERLAP_KEY=0 VINCE_KNOBS=wgrad_stream=0,ds_stream=0 timeout 600 rocprofv3 --kernel-trace -d $O/kts -o kt -- python bench.py --no-extras > $O/kts.log 2>&1
 DB=$(find $O/kts -name '*.db' | head -1); timeout 60 python tools/rocpd_stats.py $DB 45 > $O/kernel_stats_serialised.txt 2>&1; rm -rf $O/kts
+# the weight-gradient kernels layer by layer, timed alone: conv_wgrad_tr against the kernel it replaced
+(timeout 200 python tools/wgrad_micro.py conv_wgrad_tr; VINCE_KNOBS=wgrad_tr=0 timeout 200 python tools/wgrad_micro.py conv_wgrad_dlds) 2>&1 | grep "14x14" | sed 's/ | /\n    /g' > $O/wgrad_micro.txt
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --steps 2 --warmup 1 --no-extras > $O/pmc_$C.log 2>&1
 done

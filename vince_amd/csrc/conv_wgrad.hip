@@ -531,7 +531,7 @@ int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t
     int CT = d.Co <= 64 ? 64 : 128, NT = ntot <= 64 ? 64 : 128;
     // bf16: the transposing-read kernel of conv_wgrad_tr.hip with its own tile choice, whenever the layer qualifies (`wgrad_tr=0`: the
     // LDS-DMA kernel of this file, cross-check switch)
-    static const int use_tr = (int)vince_knob("wgrad_tr", 1);
+    const int use_tr = (int)vince_knob_live("wgrad_tr", 1);
     int tr_ct = 0, tr_nt = 0;
     if (use_tr && std::is_same<T, bf16_t>::value) vince_wgrad::wgrad_tr_tile(p, &tr_ct, &tr_nt);
     const bool tr = tr_ct > 0;
