@@ -972,7 +972,7 @@ def test_backward_with_a_deeper_dy_ring_and_the_old_wgrad_kernel_gives_the_same_
     weight-gradient stream; 3 by default, up to 8) and `wgrad_tr=0` (bf16 weight gradients through the LDS-DMA kernel that
     conv_wgrad_tr replaced).  Same model, same batch: every parameter gradient agrees to the fp32-atomics noise of the split-K sums."""
     grads = {}
-    for knobs in ("", "dy_slots=6", "wgrad_tr=0"):
+    for tag, knobs in (("base", ""), ("again", ""), ("dy_slots=6", "dy_slots=6"), ("wgrad_tr=0", "wgrad_tr=0")):
         monkeypatch.setenv("VINCE_KNOBS", knobs)
         _, model = build("ResNet50", 128, "bf16", 11)
         model.train()
@@ -982,12 +982,18 @@ def test_backward_with_a_deeper_dy_ring_and_the_old_wgrad_kernel_gives_the_same_
         model.zero_grad()
         (o["embeddings"] * w).sum().backward()
         torch.cuda.synchronize()
-        grads[knobs] = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
-    for knobs in ("dy_slots=6", "wgrad_tr=0"):
-        for n, g0 in grads[""].items():
-            g1 = grads[knobs][n]
-            scale = float(g0.abs().max()) + 1e-12
-            assert float((g1 - g0).abs().max()) / scale < 2e-4, (knobs, n, float((g1 - g0).abs().max()), scale)
+        grads[tag] = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    def worst(a, b):    # largest relative L2 difference of any parameter gradient
+        return max(float((a[n] - b[n]).norm()) / (float(b[n].norm()) + 1e-12) for n in b)
+    # the backward pass is not bit-reproducible (fp32 atomics of the split-K weight gradients, fp64 atomics of the BatchNorm sums below
+    # fp32 resolution, then bf16 rounding of every gradient tensor on the way down): two runs of the SAME configuration set the scale
+    noise = worst(grads["again"], grads["base"])
+    print("run-to-run: %.3e" % noise)
+    for tag in ("dy_slots=6", "wgrad_tr=0"):
+        d = worst(grads[tag], grads["base"])
+        print("%s: %.3e" % (tag, d))
+        assert d < max(3 * noise, 1e-3) and d < 0.3, (tag, d, noise)
 
 
 def test_bench_multi_rank_launch_contract_on_one_gpu():

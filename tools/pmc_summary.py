@@ -33,6 +33,8 @@ def tag_of(name):
     if not m:
         m2 = re.search(r"conv_igemm_dlds_kernel<(unsigned short|float), (\d+), \d+, \d+, \d+, (\d+), (true|false|0|1|2)[,>]", name)
         if not m2:
+            if "conv_wgrad_tr" in name:     # the transposing-read kernel is bf16 only (no type parameter in its name)
+                return "conv_wgrad<bf16>"
             if "conv_wgrad" in name:
                 return "conv_wgrad<%s>" % ("bf16" if ("It" in name or "unsigned short" in name) else "f32")
             return None
