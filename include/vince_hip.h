@@ -251,6 +251,16 @@ int vince_bn_train_apply(int dtype, const void* y, const vince_bn_train* bt, con
                          const float* id_shift, void* out, uint8_t* mask_out, int64_t rows, int32_t C, int relu,
                          void* stream);
 
+/* vince_bn_train_apply (relu, no identity) for a narrow bf16 tensor -- a = relu(bn2(y)), resnet.py:119-121 -- that also returns what
+ * vince_bn_gram_finalize needs of the tensor it stores: gram[C][C] += sum over rows of a a^T (float, zeroed by the caller) beside
+ * bt->out_sum.  C = 64 or 128, bf16 only (VINCE_E_SHAPE / VINCE_E_DTYPE otherwise: the caller then runs vince_bn_train_apply and
+ * vince_conv_wgrad(in = dy = a)).  Each workgroup keeps the 64-row slices it writes in LDS and multiplies them on the matrix
+ * pipe; partial matrices go to per-workgroup slabs in `scratch` (vince_bn_train_apply_gram_scratch_bytes) and are added in a fixed
+ * order: the result is run-to-run identical.  Saves the extra read of `a` and two launches per bottleneck. */
+size_t vince_bn_train_apply_gram_scratch_bytes(int64_t rows, int32_t C);
+int vince_bn_train_apply_gram(int dtype, const void* y, const vince_bn_train* bt, void* out, int64_t rows, int32_t C, float* gram,
+                              void* scratch, size_t scratch_bytes, void* stream);
+
 /* Train-mode BatchNorm constants of a 1x1 convolution's output WITHOUT running the convolution first (resnet.py:125-126:
  * bn3(conv3(a))).  For y = W a per pixel, mean_y = W mean_a and var_y[c] = w_c^T Cov(a) w_c, so the batch statistics of y follow
  * from the Gram matrix of the conv INPUT:  gram = sum_pix a a^T  (float[K][K]; vince_conv_wgrad with in = dy = a) and its column

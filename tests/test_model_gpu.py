@@ -926,6 +926,29 @@ def test_bf16_trunk_forward_is_reproducible():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
 
 
+def test_gram_matrix_from_the_pass_that_writes_the_tensor_vs_the_weight_gradient_launch(monkeypatch):
+    """Since round 3 the Gram matrix of conv3's input comes out of the BatchNorm + ReLU pass that writes it (csrc/bn_gram.hip);
+    `VINCE_KNOBS=gram_fused=0` restores the weight-gradient launch over the stored tensor.  Both sum exact bf16 products in fp32, in
+    different orders: the trunk outputs agree to bf16 resolution, in the key encoder's no-grad forward and in the training forward,
+    and each route is reproducible on its own."""
+    _, model = build("ResNet50", 128, "bf16", 11)
+    model.train()
+    x = vo.structured_frames(8, 96, 96, seed=6).to(DEV)
+    for grad in (False, True):
+        outs = {}
+        for knobs in ("gram_fused=1", "gram_fused=0", "gram_fused=1"):
+            monkeypatch.setenv("VINCE_KNOBS", knobs)
+            with torch.set_grad_enabled(grad):
+                o = model.get_embeddings({"data": x})
+            cur = o["spatial_features"].detach().float().clone()
+            if knobs in outs:
+                assert torch.equal(outs[knobs], cur)
+            outs[knobs] = cur
+        d = rel(outs["gram_fused=1"], outs["gram_fused=0"])
+        print("grad %s: fused vs weight-gradient route %.3e" % (grad, d))
+        assert d < 2e-2, d
+
+
 def test_bn3_backward_algebra_in_the_model_vs_separate_passes(monkeypatch):
     """The default bf16 training route since round 3 (csrc/bn_algebra.hip; VINCE_KNOBS=bn3_algebra=0 restores the separate passes): layer1 /
     layer2 bottlenecks run conv3 + bn3 + join in one streaming launch that does NOT store conv3's output, and backward gets bn3's

@@ -688,6 +688,46 @@ def test_gram_statistics_join_vs_separate_passes(dtype, N, hw, K, Co, ds):
     assert_close(z.view(rows, Co), want.float(), dtype, f32=5e-5, bf16=3e-2, what="join")
 
 
+@pytest.mark.parametrize("rows,K", [(4 * 14 * 14, 64), (3 * 9 * 9, 128), (64 * 37 + 5, 64), (64 * 700 + 17, 128), (33, 128), (200704, 128)])
+def test_bn_train_apply_gram_vs_separate_launches(rows, K):
+    """vince_bn_train_apply_gram (csrc/bn_gram.hip): a = relu(bn2(y)) written once, with the column sums and the Gram matrix a^T a of
+    exactly the stored bf16 values -- against vince_bn_train_apply (bit-equal output, constants, running statistics), fp64 sums of the
+    stored tensor, and the Gram matrix the weight-gradient kernel computes from it; ragged row counts, one to 512 workgroups, and
+    two runs that agree to the bit (slabs added in a fixed order)."""
+    ops = _ops()
+    y = (rnd(rows, K, seed=1) * (0.5 + torch.rand(K, generator=torch.Generator().manual_seed(2))) + rnd(K, seed=3) * 0.5).to(DEV).bfloat16()
+    g, b = (torch.rand(K, generator=torch.Generator().manual_seed(4)) + 0.5).to(DEV), (rnd(K, seed=5) * 0.3).to(DEV)
+    st = torch.stack([y.double().sum(0), (y.double() ** 2).sum(0)], 1)[None].contiguous()     # double[1][K][2]
+    rm0, rv0 = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+    nbt0 = torch.zeros(1, device=DEV, dtype=torch.int64)
+    cs0 = torch.zeros(4, K, device=DEV, dtype=torch.float64)
+    want, _, sc0, sh0, mu0, is0 = ops.bn_train_apply(y, st, rows, g, b, rm0, rv0, nbt0, replicas=1, out_sum=cs0)
+    outs = []
+    for _ in range(2):
+        rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+        nbt = torch.zeros(1, device=DEV, dtype=torch.int64)
+        cs = torch.zeros(4, K, device=DEV, dtype=torch.float64)
+        gram = torch.zeros(K, K, device=DEV)
+        a, sc, sh, mu, isd = ops.bn_train_apply_gram(y, st, rows, g, b, gram, cs, rm, rv, nbt, replicas=1)
+        outs.append((a, gram, cs.sum(0)))
+        assert torch.equal(a.view(torch.int16), want.view(torch.int16))
+        for got, ref in ((sc, sc0), (sh, sh0), (mu, mu0), (isd, is0), (rm, rm0), (rv, rv0)):
+            assert torch.equal(got, ref)
+        assert int(nbt) == 1
+        np.testing.assert_allclose(cs.sum(0).cpu().numpy(), a.double().sum(0).cpu().numpy(), rtol=1e-6, atol=1e-6)
+        ref_gram = a.double().t() @ a.double()
+        scale = float(ref_gram.abs().max())
+        assert float((gram.double() - ref_gram).abs().max()) / scale < 2e-6, float((gram.double() - ref_gram).abs().max()) / scale
+    assert torch.equal(outs[0][1], outs[1][1])
+    # and next to the route it replaces: the weight-gradient kernel over the stored tensor
+    if rows % (14 * 14) == 0:
+        n = rows // 196
+        old = torch.zeros(K, 1, K, device=DEV)
+        x4 = outs[0][0].view(n, 14, 14, K)
+        ops.conv_wgrad(ops.conv_desc(n, 14, 14, K, K, 1, 1, 0), x4, x4, old)
+        assert float((old.view(K, K) - outs[0][1]).abs().max()) / float(outs[0][1].abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("rows,K,Co,ds", [(4 * 14 * 14, 64, 256, False), (1000, 64, 256, True), (3 * 9 * 9, 128, 512, True),
                                           (128 * 40 + 5, 128, 512, False), (37, 64, 512, False)])
 def test_conv_expand_join_streaming_kernel(rows, K, Co, ds):

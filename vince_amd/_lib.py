@@ -75,6 +75,9 @@ PROTOTYPES = {
                                c_int64, c_int32, c_int, c_void_p]),
     "vince_bn_train_apply": (c_int, [c_int, c_void_p, P(BnTrain), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_int32, c_int, c_void_p]),
+    "vince_bn_train_apply_gram_scratch_bytes": (ctypes.c_size_t, [c_int64, c_int32]),
+    "vince_bn_train_apply_gram": (c_int, [c_int, c_void_p, P(BnTrain), c_void_p, c_int64, c_int32, c_void_p, c_void_p, ctypes.c_size_t,
+                                          c_void_p]),
     "vince_bn_gram_finalize": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p]),

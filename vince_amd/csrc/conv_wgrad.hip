@@ -592,16 +592,17 @@ int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t
     else if (CT == 64) rc = launch<T, 64, 128>(p, splits, stream);
     else if (NT == 64) rc = launch<T, 128, 64>(p, splits, stream);
     else rc = launch<T, 128, 128>(p, splits, stream);
-    if (rc == VINCE_OK && p.slab) {
-        const size_t n4 = dw_floats / 4;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + RED_COLS - 1) / RED_COLS)), dim3(256), 0, stream, (const float*)p.slab, splits, p.slab_stride,
-                           p.dw, n4);
-        VINCE_CHECK_LAUNCH();
-    }
+    if (rc == VINCE_OK && p.slab) rc = vince_wgrad::slab_reduce(p.slab, splits, p.slab_stride, p.dw, dw_floats / 4, stream);
     return rc;
 }
 
 }  // namespace
+
+int vince_wgrad::slab_reduce(const float* slab, int splits, size_t stride, float* dst, size_t n4, hipStream_t stream) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + RED_COLS - 1) / RED_COLS)), dim3(256), 0, stream, slab, splits, stride, dst, n4);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
 
 static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, const void* dy, float* dw, int32_t Ci_dw, int variant,
                         void* scratch, size_t scratch_bytes, size_t* need_out, void* stream);

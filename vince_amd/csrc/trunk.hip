@@ -352,6 +352,7 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
                 vince_conv_desc dg = fwd_desc(t, b.c[2]);
                 dg.Co = b.c[2].Ci;
                 want(dg, b.c[2].Ci);
+                need = std::max(need, vince_bn_train_apply_gram_scratch_bytes((int64_t)t->cfg.N * b.c[2].Hi * b.c[2].Wi, b.c[2].Ci));
             }
         }
         t->wg_scratch_bytes = align_up(need);
@@ -520,6 +521,32 @@ int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const voi
     bt.out_sum = out_sum;
     bt.out_sum_replicas = GRAM_R;
     return vince_bn_train_apply(c.dtype, at(c.ws, y_off), &bt, idn, ids, idt, out, mask_out, rows, cv.Co, 1, c.stream);
+}
+
+// the same for the pass that writes conv3's input in a Gram block: train-mode BatchNorm + ReLU + column sums + the Gram matrix of what
+// it stores, in one launch (csrc/bn_gram.hip)
+int bn_apply_gram_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, void* out, float* const* bn_running, int64_t* const* bn_nbt,
+                      double* out_sum, float* gram, void* scratch, size_t scratch_bytes) {
+    const int64_t rows = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
+    vince_bn_train bt;
+    memset(&bt, 0, sizeof(bt));
+    bt.stats = c.stats(bn);
+    bt.replicas = bn.R;
+    bt.count = rows;
+    bt.gamma = c.params[bn.gamma];
+    bt.beta = c.params[bn.beta];
+    bt.running_mean = bn_running[2 * bn.index];
+    bt.running_var = bn_running[2 * bn.index + 1];
+    bt.num_batches_tracked = bn_nbt ? bn_nbt[bn.index] : nullptr;
+    bt.momentum = 0.1f;
+    bt.eps = 1e-5f;
+    bt.scale = c.consts(bn, 0);
+    bt.shift = c.consts(bn, 1);
+    bt.save_mean = c.consts(bn, 2);
+    bt.save_invstd = c.consts(bn, 3);
+    bt.out_sum = out_sum;
+    bt.out_sum_replicas = GRAM_R;
+    return vince_bn_train_apply_gram(c.dtype, at(c.ws, y_off), &bt, out, rows, cv.Co, gram, scratch, scratch_bytes, c.stream);
 }
 
 // BatchNorm-backward algebra (csrc/bn_algebra.hip): bf16 bottlenecks whose conv3 reduction fits the Gram scratch and the streaming
@@ -837,6 +864,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
                             train_bn && save && !ds_side && c.dtype == VINCE_BF16;
     if (save) t->fwd_alg = alg_fwd;
     const bool gram_on = gram_nograd || gram_train;
+    const bool gram_fused = vince_knob_live("gram_fused", 1) != 0;
     if (gram_on && t->gram_bytes)
         RC(vince_zero_async(at(workspace, t->off_gram), t->gram_bytes, stream));
     size_t cur = t->off_p0;   // where the running block input lives (gram blocks update it in place, so b.x_in may be stale)
@@ -857,11 +885,19 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_done, t->ds_stream));
         }
         const int nplain = gram_blk ? b.nconv - 1 : b.nconv;   // convs that run with their own statistics epilogue
+        bool gram_done = false;
         for (int ci = 0; ci < nplain; ++ci) {
             RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, false));
             if (ci < b.nconv - 1) {
-                // (the pass that writes conv3's input also sums it per channel when the Gram path follows)
+                // (the pass that writes conv3's input also sums it per channel when the Gram path follows -- and, for the bf16
+                // K = 64 / 128 blocks, multiplies what it writes into the Gram matrix itself: csrc/bn_gram.hip, `gram_fused=0` restores the
+                // weight-gradient launch over the stored tensor)
                 double* osum = (gram_blk && ci == b.nconv - 2) ? (double*)at(workspace, b.colsum) : nullptr;
+                if (osum && gram_fused && c.dtype == VINCE_BF16 && (b.c[ci].Co == 64 || b.c[ci].Co == 128) && t->wg_scratch_bytes) {
+                    RC(bn_apply_gram_fwd(c, b.c[ci], b.b[ci], b.y[ci], at(workspace, b.a[ci]), bn_running, bn_nbt, osum,
+                                         (float*)at(workspace, b.gram), at(workspace, t->off_wg_scratch[0]), t->wg_scratch_bytes));
+                    gram_done = true;
+                } else
                 RC(bn_apply_fwd(c, b.c[ci], b.b[ci], b.y[ci], nullptr, nullptr, nullptr, at(workspace, b.a[ci]), nullptr,
                                 bn_running, bn_nbt, train_bn, osum));
                 in = b.a[ci];
@@ -876,7 +912,8 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             // Gram matrix of conv3's input through the weight-gradient kernel (in = dy = a): sum over pixels of a a^T
             vince_conv_desc dg = fwd_desc(t, cv);
             dg.Co = cv.Ci;
-            RC(wgrad_launch(t, workspace, c.dtype, dg, at(workspace, in), at(workspace, in), (float*)at(workspace, b.gram), cv.Ci, 0, stream));
+            if (!gram_done)
+                RC(wgrad_launch(t, workspace, c.dtype, dg, at(workspace, in), at(workspace, in), (float*)at(workspace, b.gram), cv.Ci, 0, stream));
             RC(vince_bn_gram_finalize(c.dtype, (const float*)at(workspace, b.gram), (const double*)at(workspace, b.colsum), GRAM_R,
                                       rows, at((void*)wcache, cv.wk), cv.Ci, cv.Co, params[bn.gamma], params[bn.beta],
                                       bn_running[2 * bn.index], bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr,

@@ -342,6 +342,32 @@ def bn_train_apply(y, stats, count, gamma, beta, running_mean=None, running_var=
     return out, mask, scale, shift, mean, invstd
 
 
+def bn_train_apply_gram(y, stats, count, gamma, beta, gram, out_sum, running_mean=None, running_var=None, nbt=None, replicas=0,
+                        momentum=0.1, eps=1e-5):
+    """Train-mode BatchNorm + ReLU of a bf16 [rows][C] tensor (C = 64 / 128) that also accumulates the Gram matrix of what it stores
+    into `gram` (zeroed float[C][C]) and its column sums into `out_sum` (zeroed double[R][C]): vince_bn_train_apply_gram.
+    Returns (out, scale, shift, mean, invstd)."""
+    require_gpu(y, stats, gamma, beta, gram, out_sum, running_mean, running_var, nbt)
+    C = y.shape[-1]
+    rows = y.numel() // C
+    out = torch.empty_like(y)
+    scale, shift, mean, invstd = (torch.empty(C, device=y.device) for _ in range(4))
+    bt = BnTrain()
+    bt.stats, bt.replicas, bt.count = stats.data_ptr(), replicas, count
+    bt.gamma, bt.beta = gamma.data_ptr(), beta.data_ptr()
+    bt.running_mean = None if running_mean is None else running_mean.data_ptr()
+    bt.running_var = None if running_var is None else running_var.data_ptr()
+    bt.num_batches_tracked = None if nbt is None else nbt.data_ptr()
+    bt.momentum, bt.eps = momentum, eps
+    bt.scale, bt.shift, bt.save_mean, bt.save_invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    bt.out_sum, bt.out_sum_replicas = out_sum.data_ptr(), out_sum.shape[0]
+    need = lib().vince_bn_train_apply_gram_scratch_bytes(rows, C)
+    scratch = torch.empty(max(int(need), 16), dtype=torch.uint8, device=y.device)
+    check(lib().vince_bn_train_apply_gram(dtype_code(y), _ptr(y), ctypes.byref(bt), _ptr(out), rows, C, _ptr(gram), _ptr(scratch),
+                                          scratch.numel(), stream_ptr()))
+    return out, scale, shift, mean, invstd
+
+
 def bn_gram_finalize(gram, colsum, count, w, gamma, beta, running_mean=None, running_var=None, nbt=None, momentum=0.1, eps=1e-5):
     """BatchNorm constants of the 1x1 conv y = w a from the Gram matrix of a (vince_bn_gram_finalize).
     gram float[K][K], colsum double[R][K], w [Co][K] in the compute dtype.  Returns consts [4][Co]: scale, shift, mean, invstd."""
