@@ -940,7 +940,7 @@ def test_gram_matrix_from_the_pass_that_writes_the_tensor_vs_the_weight_gradient
             monkeypatch.setenv("VINCE_KNOBS", knobs)
             with torch.set_grad_enabled(grad):
                 o = model.get_embeddings({"data": x})
-            cur = o["spatial_features"].detach().float().clone()
+            cur = o["spatial_features"].detach().float().cpu()
             if knobs in outs:
                 assert torch.equal(outs[knobs], cur)
             outs[knobs] = cur

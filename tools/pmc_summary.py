@@ -23,7 +23,7 @@ def tag_of(name):
         return "bn_bwd_apply"
     if "bn_bwd_reduce_kernel" in name:
         return "bn_bwd_reduce"
-    if "bn_apply_kernel" in name:
+    if "bn_apply_kernel" in name or "bn_apply_gram_kernel" in name:
         return "bn_apply"
     if "stem_pool_fwd_kernel" in name:
         return "stem_pool_fwd"
