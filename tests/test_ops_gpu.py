@@ -66,6 +66,10 @@ CONVS = [
     (3, 14, 14, 256, 256, 3, 1, 1),
     (5, 9, 9, 512, 256, 1, 1, 0),
     (3, 13, 15, 256, 512, 3, 2, 1),
+    # enough pixels for several pixel-range splits of the weight gradient with a ragged last 32-pixel slice (M = 3703), and a 1x1 whose
+    # pixel count is not a multiple of anything (M = 3 * 19 * 21 = 1197)
+    (7, 23, 23, 64, 128, 3, 1, 1),
+    (3, 19, 21, 128, 64, 1, 1, 0),
 ]
 
 
