@@ -549,11 +549,7 @@ int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t
     // Split the pixel range so that the grid is about one resident wave of workgroups (256 CUs x 2): every extra split
     // costs Co*T*Ci fp32 atomics in the epilogue, and the L2 atomic rate -- not MFMA -- bounds this kernel when the grid
     // is cut 3x finer.  At least 8 K-tiles per split.
-#ifdef VINCE_STEP_ABLATE
-    static int target_blocks = getenv("VINCE_WGRAD_BLOCKS") ? atoi(getenv("VINCE_WGRAD_BLOCKS")) : 512;
-#else
     static int target_blocks = VINCE_MEASURE_KNOB("wgrad_blocks", 512);
-#endif
     const int tiles = p.ctiles * p.ntiles;
     // a multi-tap layer with a small output (layer1's 3x3: 64 x 576 floats in 5 tiles) is bound by its loop, not by atomics: twice
     // the workgroups hide twice the latency (192 -> 134 us timed alone; every other shape is best at 512)
