@@ -36,6 +36,16 @@ extern "C" {
 
 #define VINCE_F32 0
 #define VINCE_BF16 1
+/* Split-half products: the tensors are fp32 exactly as with VINCE_F32; the matrix kernels split every operand element into
+ * hi + lo half-precision halves in registers and run hi*hi + hi*lo + lo*hi on the half-precision matrix pipe with fp32 accumulation
+ * (3 MFMAs per block instead of fp32's 8 at 1/16 the rate).  H: IEEE half halves, products good to ~2^-22 -- the forward launches
+ * (operands of order one; the reference's config-3 script runs fp32, vince/train_moco_v2.sh:40, and this is the mode that meets its
+ * 1e-3 bar at bf16-class speed).  B: bfloat16 halves, ~2^-16 with fp32's exponent range -- the gradient launches.  Accepted by
+ * vince_conv_igemm, vince_conv_wgrad(_det) and, as VINCE_F32X3 (= H forward / B backward), by vince_trunk_cfg.dtype; everywhere else
+ * such tensors are passed as VINCE_F32. */
+#define VINCE_F32X3H 2
+#define VINCE_F32X3B 3
+#define VINCE_F32X3 VINCE_F32X3H
 
 const char* vince_last_error(void);
 int vince_abi_version(void);
@@ -503,7 +513,7 @@ typedef struct vince_trunk* vince_trunk_t;
 typedef struct vince_trunk_cfg {
     int32_t arch;   /* 18 or 50 */
     int32_t N, H, W;
-    int32_t dtype;  /* VINCE_F32 / VINCE_BF16 */
+    int32_t dtype;  /* VINCE_F32 / VINCE_BF16 / VINCE_F32X3 (fp32 tensors, convolutions as split-half products) */
 } vince_trunk_cfg;
 
 int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out);

@@ -1,7 +1,8 @@
 """Helper of tests/test_full_size_gpu.py: ONE grad-enabled forward + InfoNCE + backward of BASELINE config 3 (ResNet-50,
 B=256, 224x224, K=65536, D=128, T=0.2) on the G9 inputs, dumped as an .npz.  Run as a child process so that the engine's
 environment switches (VINCE_KNOBS="wgrad_stream=0,ds_stream=0,...", VINCE_OVERLAP_KEY -- read once per process) can differ between two runs.
-usage: full_size_grad_dump.py <out.npz> <bf16|fp32>"""
+VINCE_DUMP_FIXTURE=g12: the centred-head state of fixture G12 (seed 12, the stored head-bias shift, its own frames and queue).
+usage: full_size_grad_dump.py <out.npz> <bf16|fp32|x3> [gradient tensors to dump in full ...]"""
 import os
 import sys
 
@@ -21,14 +22,23 @@ def main():
     args = make_args(backbone="ResNet50", vince_embedding_size=128, compute_dtype=dtype, batch_size=256,
                      vince_queue_size=65536, vince_temperature=0.2, base_lr=0.03, input_size=(224, 224))
     model = VinceModel(args)
-    model.load_state_dict(vo.seeded_state(vo.model_spec("ResNet50", 128, False), 9))
+    g12 = os.environ.get("VINCE_DUMP_FIXTURE", "g9") == "g12"
+    state = vo.seeded_state(vo.model_spec("ResNet50", 128, False), vo.G12["seed"] if g12 else 9)
+    if g12:
+        shift = np.load(os.path.join(ROOT, "tests", "golden", "g12_full_centred.npz"))["shift"]
+        state["embedding.2.bias"] = state["embedding.2.bias"] + torch.from_numpy(shift)
+    model.load_state_dict(state)
     model.to(dev)
     model.train()
     qm = VinceQueueModel(args, model)
     qm.to(dev)
     qm.train()
-    queue = torch.nn.functional.normalize(torch.randn(65536, 128, generator=torch.Generator().manual_seed(9 + 77)), dim=-1).to(dev)
-    data, qdata = vo.g9_inputs()
+    if g12:
+        queue = vo.g12_queue().to(dev)
+        data, qdata = vo.g12_inputs()
+    else:
+        queue = torch.nn.functional.normalize(torch.randn(65536, 128, generator=torch.Generator().manual_seed(9 + 77)), dim=-1).to(dev)
+        data, qdata = vo.g9_inputs()
     batch = {"data": data.to(dev), "queue_data": qdata.to(dev), "batch_types": ["images"], "batch_sizes": [256],
              "data_source": ["XX"], "num_frames": [1]}
     if os.environ.get("VINCE_OVERLAP_KEY", "1") != "0":   # the solver's arrangement: key encoder on its own stream

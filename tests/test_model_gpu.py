@@ -37,10 +37,12 @@ def rel(a, b):
 @pytest.mark.parametrize("arch,embed", [("ResNet18", 64), ("ResNet50", 128)])
 @pytest.mark.parametrize("hw", [64, 224])
 @pytest.mark.parametrize("train", [True, False])
-def test_g3_trunk_head_fp32(arch, embed, hw, train):
+@pytest.mark.parametrize("dtype", ["fp32", "x3"])
+def test_g3_trunk_head_fp32(arch, embed, hw, train, dtype):
+    """fp32 trunk, and the same fp32 tensors with every convolution as split-half products (compute_dtype="x3"), at the same bounds."""
     g = load("g3_trunk.npz")
     p = "%s_%d_%s_" % (arch, hw, "train" if train else "eval")
-    _, model = build(arch, embed, "fp32", 11)
+    _, model = build(arch, embed, dtype, 11)
     model.train(train)
     x = vo.structured_frames(2, hw, hw, seed=500 + hw).to(DEV)
     with torch.no_grad():
@@ -336,7 +338,7 @@ def _g11_step(stack, data, qdata):
 G11_BF16_BOUNDS = {"centred": dict(loss=5e-2, emb=0.9, cos=0.65), "after20": dict(loss=1e-3, emb=7e-3, cos=0.9999)}
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "x3", "bf16"])
 def test_g11_centred_head_vs_reference_golden(dtype):
     """G11c (oracle/make_golden_g11.py): ONE iteration of the REFERENCE from the seeded ResNet-50 whose head bias is shifted so that the
     batch's embeddings are spread over the sphere (mean pairwise cosine -0.06): nothing hides trunk error behind the L2 normalisation.
@@ -358,7 +360,7 @@ def test_g11_centred_head_vs_reference_golden(dtype):
     worst = max(abs(vo.tensor_checksum(grads[n])[2] / g["c_grad_checksums"][names.index(n)][2] - 1.0) for n in names if n in grads)
     print("G11 centred head, %s trunk: loss rel %.3e  embeddings %.3e  keys %.3e  min cosine %.5f  worst sum|grad| rel %.3e"
           % (dtype, e_loss, e_emb, e_key, cos, worst))
-    if dtype == "fp32":
+    if dtype in ("fp32", "x3"):   # x3 (split-half products on fp32 tensors) is held to the SAME bars as the fp32 trunk
         assert e_loss < 1e-3 and e_emb < 1e-3 and e_key < 1e-3
         np.testing.assert_allclose([float(met[k]) for k in ("nce_accuracy_mean", "cosine_sim", "cosine_sim_neg_max")], g["c_metrics"],
                                    rtol=1e-3, atol=1e-4)

@@ -1,0 +1,114 @@
+"""Split-half products (VINCE_F32X3H / VINCE_F32X3B, compute_dtype="x3"): fp32 tensors whose convolutions run as three half-precision
+MFMAs of hi / lo halves.  Op level against fp64 convolutions on the CPU -- held to what the claim is: forward launches (IEEE half
+halves) at fp32's own error, gradient launches (bfloat16 halves) at 2^-16 -- and the model against the reference's goldens at the
+north-star bar (1e-3 on embeddings and loss).  Run with -m gpu on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vince_oracle as vo  # noqa: E402
+from tests.test_ops_gpu import CONVS, DEV, from_nhwc, rnd, to_nhwc, weights_krsc  # noqa: E402
+
+
+def _ops():
+    from vince_amd import ops
+    return ops
+
+
+def _err(got, want):
+    got, want = got.double().cpu(), want.double().cpu()
+    return float((got - want).abs().max() / (want.abs().max() + 1e-300))
+
+
+@pytest.mark.parametrize("xscale", [1.0, 1e-3, 300.0])
+@pytest.mark.parametrize("cfg", CONVS)
+def test_x3h_forward_conv_is_as_good_as_fp32(cfg, xscale):
+    """The forward convolution through IEEE-half hi / lo halves against an fp64 convolution of the same fp32 operands: within 4e-6 of
+    max |y| (the exact-fp32 MFMA kernel of the same layer is measured beside it: ~1e-6), at activations of order one, at 1e-3 (the
+    lo halves of the activations are subnormal half numbers there: the matrix pipe must not flush them) and at 300."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, p = cfg
+    x = rnd(N, Ci, H, W, seed=1) * xscale
+    w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k)) ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), None, s, p)
+    wk, _ = weights_krsc(w, torch.float32)
+    d = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
+    xg = to_nhwc(x, torch.float32)
+    out = torch.empty(N, d.Ho, d.Wo, Co, device=DEV)
+    stats = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
+    ops.conv_igemm(d, xg, wk, out, stats=stats, x3="h")
+    e3 = _err(from_nhwc(out), ref)
+    out32 = torch.empty_like(out)
+    ops.conv_igemm(d, xg, wk, out32)
+    e32 = _err(from_nhwc(out32), ref)
+    print("x3h conv %s x%g: err %.2e (fp32 MFMA kernel %.2e)" % (cfg, xscale, e3, e32))
+    assert e3 < 4e-6, (e3, e32)
+    o = out.cpu().reshape(-1, Co).double()
+    np.testing.assert_allclose(stats.sum(0)[:, 0].cpu().numpy(), o.sum(0).numpy(), rtol=1e-5, atol=1e-3 * xscale)
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_x3b_gradients_vs_fp64(cfg):
+    """Input and weight gradients through bfloat16 hi / lo halves (fp32's exponent range: dy of order 1e-6 here) against fp64 autograd:
+    2^-16 per product, held at 1e-4 of the largest entry; the accumulate / masked epilogues run on the same instantiation."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, p = cfg
+    x = rnd(N, Ci, H, W, seed=6).double().requires_grad_(True)
+    w = rnd(Co, Ci, k, k, seed=7, scale=(2.0 / (Ci * k * k)) ** 0.5).double().requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = rnd(*y.shape, seed=8) * 1e-6
+    y.backward(dy.double())
+    wk, wt = weights_krsc(w.detach().float(), torch.float32)
+    dyg = to_nhwc(dy, torch.float32)
+    dx = torch.full((N, H, W, Ci), float("nan"), device=DEV)
+    descs = ops.dgrad_descs(N, H, W, Ci, Co, k, s, p)
+    if len(descs) < s * s:
+        dx.zero_()
+    for d in descs:
+        ops.conv_igemm(d, dyg, wt, dx, x3="b")
+    e = _err(from_nhwc(dx), x.grad)
+    for d in descs:
+        ops.conv_igemm(d, dyg, wt, dx, flags=ops.EPI_ACCUMULATE, x3="b")
+    e2 = _err(from_nhwc(dx), 2 * x.grad)
+    fd = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(Co, k * k, Ci)
+    dw = torch.zeros(Co, k * k, Ci, device=DEV)
+    ops.conv_wgrad(fd, to_nhwc(x.detach().float(), torch.float32), dyg, dw, x3="b")
+    ew = _err(dw, ref_dw)
+    dets = []
+    for _ in range(2):
+        dwd = torch.zeros(Co, k * k, Ci, device=DEV)
+        ops.conv_wgrad_det(fd, to_nhwc(x.detach().float(), torch.float32), dyg, dwd, x3="b")
+        dets.append(dwd)
+    print("x3b %s: dgrad %.2e (accumulated %.2e), wgrad %.2e, deterministic wgrad %.2e" % (cfg, e, e2, ew, _err(dets[0], ref_dw)))
+    assert e < 1e-4 and e2 < 1e-4 and ew < 1e-4 and _err(dets[0], ref_dw) < 1e-4
+    assert torch.equal(dets[0], dets[1])
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (45, 51)])
+def test_x3_stem_packed_rows(hw):
+    """The engine's stem (7 packed row taps over the [N][H][Wp][4] layout) through the split-half forward and weight gradient."""
+    ops = _ops()
+    H, W = hw
+    N = 2
+    x = rnd(N, 3, H, W, seed=3).double()
+    w = rnd(64, 3, 7, 7, seed=4, scale=(2.0 / 147) ** 0.5).double().requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 3)
+    dy = rnd(*y.shape, seed=5)
+    y.backward(dy.double())
+    xin = ops.input_nchw_to_rows(x.float().to(DEV), torch.float32)
+    wp = torch.zeros(64, 7, 8, 4)
+    wp[:, :, :7, :3] = w.detach().float().permute(0, 2, 3, 1)
+    wk = wp.reshape(64, 7, 32).to(DEV).contiguous()
+    d = ops.stem_desc(N, H, W)
+    out = torch.empty(N, d.Ho, d.Wo, 64, device=DEV)
+    ops.conv_igemm(d, xin, wk, out, x3="h")
+    assert _err(from_nhwc(out), y.detach()) < 4e-6
+    dw = torch.zeros(64, 49, 3, device=DEV)
+    ops.conv_wgrad(d, xin, to_nhwc(dy, torch.float32), dw, ci_dw=3, x3="b")
+    assert _err(dw, w.grad.permute(0, 2, 3, 1).reshape(64, 49, 3)) < 1e-4

@@ -6,6 +6,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvince_hip.so")
 
 VINCE_F32, VINCE_BF16 = 0, 1
+# fp32 tensors, matrix products as three half-precision MFMAs of hi / lo halves (include/vince_hip.h): H = IEEE half halves (forward),
+# B = bfloat16 halves (gradients); VINCE_F32X3 is what vince_trunk_cfg.dtype takes
+VINCE_F32X3H, VINCE_F32X3B = 2, 3
+VINCE_F32X3 = VINCE_F32X3H
 EPI_ACCUMULATE, EPI_RELU = 1, 2
 
 c_void_p, c_int, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,

@@ -144,6 +144,77 @@ template <> struct Chunk<bf16_t> {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Split-half products (VINCE_F32X3H / VINCE_F32X3B): tensors stay fp32 in HBM and LDS; inside the MFMA loops every operand
+// element x is split into hi = half(x) and lo = half(x - hi) and the product runs as hi*hi + hi*lo + lo*hi on the half-precision
+// matrix pipe (3 x v_mfma_f32_32x32x16 = 96 cycles per 32x32x16 block against 512 for 8 x v_mfma_f32_32x32x2_f32), fp32 accumulate.
+//   x3h_t: IEEE half halves (11 + 11 significand bits: products to ~2^-22, the forward's precision; the WEIGHT operand is scaled by
+//          2^X3_WSHIFT before the split so that its lo half stays a normal half number, the accumulators are scaled back once);
+//   x3b_t: bfloat16 halves (8 + 8 bits, fp32's exponent range: the gradient launches, whose operands span many decades).
+// Both are tags over float: same chunk / element traits, same layouts, same epilogues.
+// ---------------------------------------------------------------------------------------------
+struct x3h_t { float v; };
+struct x3b_t { float v; };
+template <> struct Elem<x3h_t> : Elem<float> {};
+template <> struct Elem<x3b_t> : Elem<float> {};
+template <> struct Chunk<x3h_t> : Chunk<float> {};
+template <> struct Chunk<x3b_t> : Chunk<float> {};
+template <typename T> struct X3 { static constexpr bool on = false, half = false; };
+template <> struct X3<x3h_t> { static constexpr bool on = true, half = true; };
+template <> struct X3<x3b_t> { static constexpr bool on = true, half = false; };
+constexpr int X3_WSHIFT = 8;   // |w| < 2^(16 - 8) keeps hi finite; lo is a normal half number down to |w| ~ 5e-4
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) __fp16 fp16x2_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16v8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16v2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+// 8 floats (two 16-byte fragments) -> 8 hi halves + 8 lo halves, each one MFMA operand register quad.
+template <typename T, bool WEIGHT> __device__ __forceinline__ void x3_split(const uint4& f0, const uint4& f1, uint4& hi, uint4& lo) {
+    const float x[8] = {__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
+                        __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if constexpr (X3<T>::half) {
+            constexpr float K = WEIGHT ? (float)(1 << X3_WSHIFT) : 1.f;
+            const float a = x[2 * p] * K, b = x[2 * p + 1] * K;
+            const fp16x2_t hp = __builtin_amdgcn_cvt_pkrtz(a, b);          // hi by truncation: a - hi is exact in fp32
+            const fp16x2_t lp = __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]);
+            __builtin_memcpy(&h[p], &hp, 4);
+            __builtin_memcpy(&l[p], &lp, 4);
+        } else {
+            const f32x2_t v = {x[2 * p], x[2 * p + 1]};
+            const bf16v2_t hp = __builtin_convertvector(v, bf16v2_t);       // v_cvt_pk_bf16_f32, round to nearest even
+            uint32_t hb;
+            __builtin_memcpy(&hb, &hp, 4);
+            const f32x2_t r = {x[2 * p] - __uint_as_float(hb << 16), x[2 * p + 1] - __uint_as_float(hb & 0xffff0000u)};
+            const bf16v2_t lp = __builtin_convertvector(r, bf16v2_t);
+            h[p] = hb;
+            __builtin_memcpy(&l[p], &lp, 4);
+        }
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// c += a*b with a = ah + al, b = bh + bl, the lo*lo term dropped; small terms first
+template <typename T> __device__ __forceinline__ void x3_mma(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16_t& c) {
+    if constexpr (X3<T>::half) {
+        f16x8_t a0, a1, b0, b1;
+        __builtin_memcpy(&a0, &ah, 16); __builtin_memcpy(&a1, &al, 16); __builtin_memcpy(&b0, &bh, 16); __builtin_memcpy(&b1, &bl, 16);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
+    } else {
+        bf16v8_t a0, a1, b0, b1;
+        __builtin_memcpy(&a0, &ah, 16); __builtin_memcpy(&a1, &al, 16); __builtin_memcpy(&b0, &bh, 16); __builtin_memcpy(&b1, &bl, 16);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // division by a runtime constant (host precomputes); exact for n < 2^31, d < 2^31
 // ---------------------------------------------------------------------------------------------
 struct FastDiv {

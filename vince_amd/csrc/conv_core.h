@@ -30,6 +30,8 @@ struct ConvParams {
 
 // conv_m8.hip: the 8-wavefront 256 x 256 core (bf16).  -1 = shape does not qualify, the caller keeps its own tiles.
 int vince_conv_m8_launch(vince_conv::ConvParams& p, int mode, hipStream_t stream);
+// conv_igemm_x3.hip: the conv_igemm kernels instantiated for the split-half element types (dtype VINCE_F32X3H / VINCE_F32X3B)
+int vince_conv_igemm_x3_launch(vince_conv::ConvParams& p, int dtype, int mode, bool narrow, hipStream_t stream);
 
 namespace {
 using vince_conv::ConvParams;
@@ -59,6 +61,18 @@ template <> struct Mma<float> {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
     }
 };
+
+// x3h_t scales the weight operand by 2^X3_WSHIFT before splitting it (common.h): the accumulators go back by the same power of two
+template <typename T, int A, int B> __device__ __forceinline__ void x3_unscale(f32x16_t (&acc)[A][B]) {
+    if constexpr (X3<T>::on && X3<T>::half) {
+#pragma unroll
+        for (int j = 0; j < A; ++j)
+#pragma unroll
+            for (int i = 0; i < B; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][i][e] *= 1.f / (float)(1 << X3_WSHIFT);
+    }
+}
 
 // MODE: 0 = forward (bias / ReLU / statistics), 1 = gradient epilogues (residual-gradient join through acc_mask, fused BatchNorm-
 // backward reduction), 2 = forward residual join with known BatchNorm constants (out_scale / bias / id_scale / id_shift / ReLU,

@@ -81,6 +81,10 @@ template <> struct FragT<float> {
     }
 };
 
+// split-half products (bfloat16 halves: gradients need fp32's exponent range): the fp32 tiles and fetches, two fetches (8 pixels per
+// lane and column) split into hi / lo halves in registers feed three v_mfma_f32_32x32x16_bf16 per block
+template <> struct FragT<x3b_t> : FragT<float> {};
+
 template <typename T, int CT, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int CH = Elem<T>::CH;
@@ -177,6 +181,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         if (kt + 1 < kt_end) load_tile(kt + 1);
         const unsigned char* ys = smem + buf * S::BUF;
         const unsigned char* xs = ys + KP * S::YRS;
+        if constexpr (X3<T>::on) {
+#pragma unroll
+            for (int ks = 0; ks < FragT<T>::KSTEPS; ks += 2) {
+                uint4 ah[CJ], al[CJ], bh[NJ], bl[NJ];
+#pragma unroll
+                for (int j = 0; j < CJ; ++j)
+                    x3_split<T, false>(FragT<T>::load(ys, S::YRS, wc * (CT / 2) + j * 32, ks, lane, p.variant),
+                                       FragT<T>::load(ys, S::YRS, wc * (CT / 2) + j * 32, ks + 1, lane, p.variant), ah[j], al[j]);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i)
+                    x3_split<T, false>(FragT<T>::load(xs, S::XRS, wn * (NT / 2) + i * 32, ks, lane, p.variant),
+                                       FragT<T>::load(xs, S::XRS, wn * (NT / 2) + i * 32, ks + 1, lane, p.variant), bh[i], bl[i]);
+#pragma unroll
+                for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < NJ; ++i) x3_mma<T>(ah[j], al[j], bh[i], bl[i], acc[j][i]);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < FragT<T>::KSTEPS; ++ks) {
             uint4 af[CJ], bf[NJ];
@@ -275,13 +297,16 @@ template <int ROWBYTES> struct FragD<float, ROWBYTES> {
     }
 };
 
+template <int ROWBYTES> struct FragD<x3b_t, ROWBYTES> : FragD<float, ROWBYTES> {};
+
 // NW wavefronts as 2 (channel halves) x NW/2 (reduction-side column groups): 4 = the 128 x 128 tile of 2 x 2 MFMA tiles per wavefront,
 // 8 = the 256 x 256 tile of the long multi-tap layers (4 x 2 MFMA tiles per wavefront: half the operand bytes per FLOP through L2 -> LDS)
 // workgroups per CU the register allocation is held to (the LDS ring allows as many): the 128 x 128 bf16 tile sat 3 registers above three
 template <typename T, int CT, int NT, int STAGES, int NW>
 constexpr int wgrad_min_blocks() {
     const int by_lds = 163840 / (STAGES * KPD * (CT + NT) * (int)sizeof(T));
-    const int want = (CT * NT / (NW * 64)) >= 128 ? 2 : (CT * NT / (NW * 64)) >= 64 ? 3 : 4;   // accumulator registers per lane: 128 / 64 / fewer
+    const int want0 = (CT * NT / (NW * 64)) >= 128 ? 2 : (CT * NT / (NW * 64)) >= 64 ? 3 : 4;   // accumulator registers per lane: 128 / 64 / fewer
+    const int want = (X3<T>::on && want0 > 2) ? want0 - 1 : want0;   // the split-half types also hold raw + split fragments
     return by_lds < want ? (by_lds < 1 ? 1 : by_lds) : want;
 }
 
@@ -394,7 +419,7 @@ __global__ __launch_bounds__(NW * 64, (wgrad_min_blocks<T, CT, NT, STAGES, NW>()
         const unsigned char* ys = smem + buf * S::STAGE;
         const unsigned char* xs = ys + S::YB;
 #pragma unroll
-        for (int ks = 0; ks < FragD<T, S::YRB>::KSTEPS; ++ks) {
+        for (int ks = 0; ks < FragD<T, S::YRB>::KSTEPS; ks += (X3<T>::on ? 2 : 1)) {
             uint4 af[CJ], bf[NJ];
 #ifdef VINCE_MEASURE
             if (p.ablate & 8) {   // 8: no LDS fragment reads
@@ -419,10 +444,22 @@ __global__ __launch_bounds__(NW * 64, (wgrad_min_blocks<T, CT, NT, STAGES, NW>()
                 continue;
             }
 #endif
+            if constexpr (X3<T>::on) {   // two fetches -> one split-half block (ks advances by 2 below)
+                uint4 ah[CJ], al[CJ], bh[NJ], bl[NJ];
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) x3_split<T, false>(af[j], FragD<T, S::YRB>::load(ys, wc * (CT / 2) + j * 32, ks + 1, lane), ah[j], al[j]);
+#pragma unroll
+                for (int i = 0; i < NJ; ++i) x3_split<T, false>(bf[i], FragD<T, S::XRB>::load(xs, wn * (NT / WNN) + i * 32, ks + 1, lane), bh[i], bl[i]);
+#pragma unroll
+                for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < NJ; ++i) x3_mma<T>(ah[j], al[j], bh[i], bl[i], acc[j][i]);
+            } else {
 #pragma unroll
             for (int j = 0; j < CJ; ++j)
 #pragma unroll
                 for (int i = 0; i < NJ; ++i) FragT<T>::mma(af[j], bf[i], acc[j][i]);
+            }
         }
         wait_vmcnt<(STAGES - 2) * PER_STAGE>();
         __syncthreads();
@@ -635,16 +672,18 @@ static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, co
         if (!need_out && (skip == 1 || (skip == 2 && in != dy))) return VINCE_OK;
     }
 #endif
-    VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_wgrad: bad dtype %d", dtype);
+    if (dtype == VINCE_F32X3H) dtype = VINCE_F32X3B;   // weight gradients always split into bfloat16 halves (the operand dy spans many decades)
+    VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16 || dtype == VINCE_F32X3B, VINCE_E_DTYPE, "vince_conv_wgrad: bad dtype %d", dtype);
     const vince_conv_desc& d = *dd;
-    const int CH = dtype == VINCE_F32 ? 4 : 8;
+    const bool f32_store = dtype != VINCE_BF16;
+    const int CH = f32_store ? 4 : 8;
     VINCE_CHECK_ARG(d.N > 0 && d.Hi > 0 && d.Wi > 0 && d.Ho > 0 && d.Wo > 0 && d.Co > 0 && d.Ci > 0, VINCE_E_SHAPE,
                     "vince_conv_wgrad: non-positive dimension");
     VINCE_CHECK_ARG(d.Ci % CH == 0 && d.Co % CH == 0, VINCE_E_SHAPE, "vince_conv_wgrad: Ci=%d / Co=%d not multiples of %d",
                     d.Ci, d.Co, CH);
     VINCE_CHECK_ARG(Ci_dw >= 1 && Ci_dw <= (d.Cs > 0 ? d.Cs : d.Ci), VINCE_E_SHAPE, "vince_conv_wgrad: Ci_dw=%d out of range", Ci_dw);
     if (d.Cs > 0) {
-        const int eb = dtype == VINCE_F32 ? 4 : 2;
+        const int eb = f32_store ? 4 : 2;
         VINCE_CHECK_ARG(d.TB == 1 && d.Cs < d.Ci && d.Ci % d.Cs == 0 && d.Kw > 0 && d.Kw <= d.Ci / d.Cs, VINCE_E_SHAPE,
                         "vince_conv_wgrad: packed row taps need TB=1, Cs | Ci, 0 < Kw <= Ci/Cs");
         VINCE_CHECK_ARG((d.Cs * eb) % 8 == 0 && (d.sw * d.Cs * eb) % 16 == 0 && (d.dw0 * d.Cs * eb) % 16 == 0 &&
@@ -669,7 +708,7 @@ static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, co
         while ((1 << l) < cpt) ++l;
         p.log2_cpt = l;
         p.cpt_mask = cpt - 1;
-        p.log2_ci = l + (dtype == VINCE_F32 ? 2 : 3);
+        p.log2_ci = l + (f32_store ? 2 : 3);
     }
     p.total_nchunks = T * cpt;
     p.M = d.N * d.Ho * d.Wo;
@@ -688,7 +727,7 @@ static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, co
     static const int xcd_group = (VINCE_MEASURE_KNOB("wgrad_xcd", 1) != 0);
     p.xcd_group = xcd_group;
     {
-        const unsigned long long esz = dtype == VINCE_F32 ? 4 : 2;
+        const unsigned long long esz = f32_store ? 4 : 2;
         const unsigned long long ib = (unsigned long long)d.N * d.Hi * d.Wi * p.cs * esz, yb = (unsigned long long)p.M * d.Co * esz;
         p.in_bytes = ib < 0x7ff00000ull ? (uint32_t)ib : 0;
         p.dy_bytes = yb < 0x7ff00000ull ? (uint32_t)yb : 0;
@@ -698,10 +737,12 @@ static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, co
     void* tok = nullptr;
     if (vince_profile_enabled() && !need_out)
     {
-        vince_profile_begin_launch(dtype == VINCE_F32 ? 16 : 17, 2.0 * p.M * d.Co * T * (double)Ci_dw * (d.Cs > 0 ? d.Kw : 1), stream, &tok);
+        vince_profile_begin_launch(f32_store ? 16 : 17, 2.0 * p.M * d.Co * T * (double)Ci_dw * (d.Cs > 0 ? d.Kw : 1), stream, &tok);
         vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh, 0);
     }
-    const int rc = dtype == VINCE_F32 ? dispatch<float>(p, s, scratch, scratch_bytes, need_out) : dispatch<bf16_t>(p, s, scratch, scratch_bytes, need_out);
+    const int rc = dtype == VINCE_F32 ? dispatch<float>(p, s, scratch, scratch_bytes, need_out)
+                 : dtype == VINCE_F32X3B ? dispatch<x3b_t>(p, s, scratch, scratch_bytes, need_out)
+                                         : dispatch<bf16_t>(p, s, scratch, scratch_bytes, need_out);
     if (tok) vince_profile_end_launch(tok, stream);
     return rc;
 }

@@ -56,6 +56,7 @@ constexpr int NDY_MAX = 8;          // most slots the dY ring of the backward pa
 struct vince_trunk {
     vince_trunk_cfg cfg;
     int esize, CH, Cp;
+    int sdtype, cf, cb;   // storage dtype of the activations; dtype of forward / gradient convolution launches (differ for VINCE_F32X3)
     std::vector<Blk> blocks;
     ConvL stem;
     BnL stem_bn;
@@ -234,12 +235,17 @@ inline unsigned char* at(void* ws, size_t off) { return (unsigned char*)ws + off
 extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out) {
     VINCE_CHECK_ARG(cfg && out, VINCE_E_ARG, "vince_trunk_create: null pointer");
     VINCE_CHECK_ARG(cfg->arch == 18 || cfg->arch == 50, VINCE_E_UNSUPPORTED, "vince_trunk_create: arch %d (18 or 50)", cfg->arch);
-    VINCE_CHECK_ARG(cfg->dtype == VINCE_F32 || cfg->dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_trunk_create: bad dtype");
+    VINCE_CHECK_ARG(cfg->dtype == VINCE_F32 || cfg->dtype == VINCE_BF16 || cfg->dtype == VINCE_F32X3, VINCE_E_DTYPE, "vince_trunk_create: bad dtype");
     VINCE_CHECK_ARG(cfg->N > 0 && cfg->H >= 8 && cfg->W >= 8, VINCE_E_SHAPE, "vince_trunk_create: bad input shape");
     vince_trunk* t = new vince_trunk();
     t->cfg = *cfg;
-    t->esize = cfg->dtype == VINCE_F32 ? 4 : 2;
-    t->CH = cfg->dtype == VINCE_F32 ? 4 : 8;
+    // VINCE_F32X3: fp32 tensors everywhere; only the convolution launches differ (split-half products: IEEE half halves forward,
+    // bfloat16 halves for the gradients)
+    t->sdtype = cfg->dtype == VINCE_BF16 ? VINCE_BF16 : VINCE_F32;
+    t->cf = cfg->dtype == VINCE_F32X3 ? VINCE_F32X3H : t->sdtype;
+    t->cb = cfg->dtype == VINCE_F32X3 ? VINCE_F32X3B : t->sdtype;
+    t->esize = t->sdtype == VINCE_F32 ? 4 : 2;
+    t->CH = t->sdtype == VINCE_F32 ? 4 : 8;
     t->Cp = t->CH;
     t->max_act = 0;
     Planner P{t};
@@ -343,7 +349,7 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     t->off_dyd = P.ws; P.ws = align_up(P.ws + t->max_act);
     {   // the largest slab set any weight gradient (or Gram matrix) of this trunk wants
         size_t need = 0;
-        auto want = [&](const vince_conv_desc& d, int ci_dw) { need = std::max(need, vince_conv_wgrad_scratch_bytes(&d, t->cfg.dtype, ci_dw)); };
+        auto want = [&](const vince_conv_desc& d, int ci_dw) { need = std::max(need, vince_conv_wgrad_scratch_bytes(&d, t->cb, ci_dw)); };
         want(stem_desc(t), 3);
         for (const Blk& b : t->blocks) {
             for (int ci = 0; ci < b.nconv; ++ci) want(fwd_desc(t, b.c[ci]), b.c[ci].Ci);
@@ -475,7 +481,7 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
         RC(vince_conv3x3_strip(c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), c.t->cfg.N, cv.Ho, cv.Wo, cv.Ci, cv.Co, nullptr,
                                at(c.ws, y_off), e.stats, e.replicas, c.stream));
     } else {
-        RC(vince_conv_igemm(&d, c.dtype, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), &e, c.stream));
+        RC(vince_conv_igemm(&d, c.t->cf, at(c.ws, in_off), at((void*)c.wcache, cv.wk), at(c.ws, y_off), &e, c.stream));
     }
     if (finalize_now || !train_bn) {
         const int64_t count = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
@@ -557,7 +563,7 @@ bool alg_env() {
 }
 bool alg_block(const vince_trunk* t, size_t bi) {
     const Blk& b = t->blocks[bi];
-    return t->cfg.dtype == VINCE_BF16 && b.nconv == 3 && b.gram != NONE && b.alg != NONE && bi + 1 < t->blocks.size() &&
+    return t->sdtype == VINCE_BF16 && b.nconv == 3 && b.gram != NONE && b.alg != NONE && bi + 1 < t->blocks.size() &&
            (b.c[2].Ci == 64 || b.c[2].Ci == 128) && b.c[2].Co % 256 == 0 && b.c[2].k == 1 && b.c[2].stride == 1 &&
            (unsigned long long)t->cfg.N * b.c[2].Hi * b.c[2].Wi * b.c[2].Ci * 2 < 0x7ff00000ull;
 }
@@ -601,7 +607,7 @@ int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, co
     e.replicas = replicas;
     e.out_mask = out_mask;
     e.stats = gsums;
-    for (int i = 0; i < n; ++i) RC(vince_conv_igemm(&ds[i], c.dtype, dy, at((void*)c.wcache, cv.wt), dx, &e, c.stream));
+    for (int i = 0; i < n; ++i) RC(vince_conv_igemm(&ds[i], c.t->cb, dy, at((void*)c.wcache, cv.wt), dx, &e, c.stream));
     return VINCE_OK;
 }
 
@@ -620,7 +626,7 @@ int wgrad_launch(vince_trunk* t, void* ws, int dtype, const vince_conv_desc& d, 
 
 int wgrad(Ctx& c, const ConvL& cv, const void* in, const void* dy, float* dw) {
     vince_conv_desc d = fwd_desc(c.t, cv);
-    return wgrad_launch(c.t, c.ws, c.dtype, d, in, dy, dw, cv.Ci, 0, c.stream);
+    return wgrad_launch(c.t, c.ws, c.t->cb, d, in, dy, dw, cv.Ci, 0, c.stream);
 }
 
 // BN backward for y (conv output) given the gradient dz wrt the activation that followed this BatchNorm.
@@ -697,7 +703,7 @@ int prepare_common(vince_trunk* t, const float* const* params, void* wcache, con
         last = tab;
         t->prep_table_dev[which] = dev_table;
     }
-    return vince_prepare_weights_batched(t->cfg.dtype, (const vince_prep_entry*)dev_table, (int32_t)tab.size(), stream);
+    return vince_prepare_weights_batched(t->sdtype, (const vince_prep_entry*)dev_table, (int32_t)tab.size(), stream);
 }
 
 // fold constants inside a folded weight cache: scale[c] and bias[c] per BN channel (BN order, offset b.consts / 4), then
@@ -738,7 +744,7 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
     VINCE_CHECK_ARG(t && wcache && workspace && pooled, VINCE_E_ARG, "vince_trunk_forward_folded: null pointer");
     VINCE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, VINCE_E_ALIGN,
                     "vince_trunk_forward_folded: workspace / weight cache must be 256-byte aligned");
-    const int N = t->cfg.N, dtype = t->cfg.dtype;
+    const int N = t->cfg.N, dtype = t->sdtype;
     const float* bias = fold_bias(t, (void*)wcache);
     const float* ones = fold_ones(t, (void*)wcache);
     if (!input) {   // staged input, see vince_trunk_forward
@@ -763,7 +769,7 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
         memset(&e, 0, sizeof(e));
         e.flags = flags;
         e.bias = bias + b.consts / 4;
-        return vince_conv_igemm(&d, dtype, in, at((void*)wcache, cv.wk), out, &e, stream);
+        return vince_conv_igemm(&d, t->cf, in, at((void*)wcache, cv.wk), out, &e, stream);
     };
     RC(conv(stem_desc(t), t->stem, t->stem_bn, at(workspace, t->off_x0), at(workspace, t->off_ystem), 0));
     RC(vince_stem_pool_fwd(dtype, at(workspace, t->off_ystem), ones, ones + 64, at(workspace, t->off_p0),
@@ -801,7 +807,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
                     "vince_trunk_forward: null pointer");
     VINCE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, VINCE_E_ALIGN,
                     "vince_trunk_forward: workspace / weight cache must be 256-byte aligned");
-    Ctx c{t, params, wcache, workspace, stream, t->cfg.dtype};
+    Ctx c{t, params, wcache, workspace, stream, t->sdtype};
     const int N = t->cfg.N;
     if (train_bn)
         RC(vince_zero_async(at(workspace, t->off_stats), t->n_stats_doubles * sizeof(double), stream));
@@ -940,7 +946,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
                                           save ? zmask : nullptr, 1, stream));
             } else {
                 const vince_conv_desc d3 = fwd_desc(t, cv);
-                RC(vince_conv_igemm(&d3, c.dtype, at(workspace, in), at((void*)wcache, cv.wk), at(workspace, out), &e, stream));
+                RC(vince_conv_igemm(&d3, t->cf, at(workspace, in), at((void*)wcache, cv.wk), at(workspace, out), &e, stream));
             }
             cur = out;
             continue;
@@ -964,7 +970,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                                     const float* dpooled, float* const* grads, const int32_t* event_blocks,
                                     void* const* events, int32_t n_events, void* stream) {
     VINCE_CHECK_ARG(t && params && wcache && workspace && dpooled && grads, VINCE_E_ARG, "vince_trunk_backward: null pointer");
-    Ctx c{t, params, wcache, workspace, stream, t->cfg.dtype};
+    Ctx c{t, params, wcache, workspace, stream, t->sdtype};
     const int N = t->cfg.N;
     RC(vince_zero_async(at(workspace, t->off_sums), t->n_stats_doubles * sizeof(double), stream));
     // Weight gradients run on a side stream: wgrad(layer) only needs dY(layer) and the saved activation, and nothing but
@@ -1018,10 +1024,10 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         return VINCE_OK;
     };
     auto wgrad_async = [&](const vince_conv_desc& d, const void* in, float* dw, int ci_dw) -> int {
-        if (!overlap) return wgrad_launch(t, workspace, c.dtype, d, in, DY, dw, ci_dw, 0, stream);
+        if (!overlap) return wgrad_launch(t, workspace, t->cb, d, in, DY, dw, ci_dw, 0, stream);
         VINCE_CHECK_HIP(hipEventRecord(t->ev_dy[slot], main_s));
         VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_dy[slot], 0));
-        RC(wgrad_launch(t, workspace, c.dtype, d, in, DY, dw, ci_dw, 1, (void*)t->side));
+        RC(wgrad_launch(t, workspace, t->cb, d, in, DY, dw, ci_dw, 1, (void*)t->side));
         VINCE_CHECK_HIP(hipEventRecord(t->ev_wg[slot], t->side));
         t->wg_pending[slot] = true;
         return VINCE_OK;
@@ -1067,7 +1073,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                     VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_ds_dy, 0));
                     {
                         const vince_conv_desc dd = fwd_desc(t, b.cd);
-                        RC(wgrad_launch(t, workspace, c.dtype, dd, x_in, DYD, grads[b.cd.param], b.cd.Ci, 1, (void*)t->side));
+                        RC(wgrad_launch(t, workspace, t->cb, dd, x_in, DYD, grads[b.cd.param], b.cd.Ci, 1, (void*)t->side));
                     }
                     VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_wg, t->side));
                     ds_wg_pending = true;
@@ -1089,7 +1095,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             // R = g^T a straight into the weight-gradient buffer (on this stream: the algebra below needs it before the dgrad)
             {
                 const vince_conv_desc dw = fwd_desc(t, cv);
-                RC(wgrad_launch(t, workspace, c.dtype, dw, a_in, Z, grads[cv.param], cv.Ci, 0, stream));
+                RC(wgrad_launch(t, workspace, t->cb, dw, a_in, Z, grads[cv.param], cv.Ci, 0, stream));
             }
             RC(vince_bn3_bwd_prepare(grads[cv.param], wk, c.sums(bn), bn.R, c.consts(bn, 2), c.consts(bn, 3), params[bn.gamma], rows_out,
                                      cv.Co, cv.Ci, ap.coef, ap.w2, 2 * cv.Co, (unsigned char*)ap.w2 + (size_t)cv.Co * 2, 2 * cv.Co, ap.nr,
@@ -1150,7 +1156,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                 VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_ds_dy, 0));
                 {
                     const vince_conv_desc dd = fwd_desc(t, b.cd);
-                    RC(wgrad_launch(t, workspace, c.dtype, dd, x_in, DYD, grads[b.cd.param], b.cd.Ci, 1, (void*)t->side));
+                    RC(wgrad_launch(t, workspace, t->cb, dd, x_in, DYD, grads[b.cd.param], b.cd.Ci, 1, (void*)t->side));
                 }
                 VINCE_CHECK_HIP(hipEventRecord(t->ev_ds_wg, t->side));
                 ds_wg_pending = true;

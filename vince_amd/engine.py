@@ -4,7 +4,7 @@ import ctypes
 import torch
 
 from . import ops
-from ._lib import TrunkCfg, VINCE_BF16, VINCE_F32, check, lib
+from ._lib import TrunkCfg, VINCE_BF16, VINCE_F32, VINCE_F32X3, check, lib
 
 ARCH_CODE = {"ResNet18": 18, "ResNet50": 50}
 
@@ -49,13 +49,16 @@ class TrunkPlan:
 
 
 class Trunk:
-    """One engine instance for a fixed (arch, N, H, W, dtype)."""
+    """One engine instance for a fixed (arch, N, H, W, dtype).  x3: float32 tensors with every convolution as split-half products
+    (VINCE_F32X3: three half-precision MFMAs of hi / lo halves instead of fp32 MFMAs)."""
 
-    def __init__(self, arch, N, H, W, dtype):
+    def __init__(self, arch, N, H, W, dtype, x3=False):
         L = lib()
-        self.arch, self.N, self.H, self.W, self.dtype = arch, N, H, W, dtype
+        self.arch, self.N, self.H, self.W, self.dtype, self.x3 = arch, N, H, W, dtype, bool(x3)
+        if self.x3 and dtype != torch.float32:
+            raise ValueError("Trunk: split-half products (x3) keep float32 tensors")
         self._h = ctypes.c_void_p()
-        code = VINCE_F32 if dtype == torch.float32 else VINCE_BF16
+        code = (VINCE_F32X3 if self.x3 else VINCE_F32) if dtype == torch.float32 else VINCE_BF16
         check(L.vince_trunk_create(ctypes.byref(TrunkCfg(arch=ARCH_CODE[arch], N=N, H=H, W=W, dtype=code)),
                                    ctypes.byref(self._h)))
         self.ws_bytes = L.vince_trunk_workspace_bytes(self._h)

@@ -109,13 +109,19 @@ FOLD_BN = os.environ.get("VINCE_FOLD_BN", "1") != "0"
 _ALIGN = 64  # floats; every tensor in the flat buffers starts on a 256-byte boundary
 
 
+X3_NAMES = ("x3", "fp32x3", "f32x3")
+
+
 def _compute_dtype(args):
+    """args.compute_dtype -> the trunk's tensor dtype.  "x3" (= "fp32x3"): float32 tensors whose convolutions run as split-half
+    products on the half-precision matrix pipe (csrc/common.h x3_split): the mode that meets the reference's fp32 results to 1e-3
+    (vince/train_moco_v2.sh:40 runs fp32) at a multiple of the fp32 MFMA rate."""
     name = str(getattr(args, "compute_dtype", "fp32")).lower()
     if name in ("bf16", "bfloat16"):
         return torch.bfloat16
-    if name in ("fp32", "float32", "f32"):
+    if name in ("fp32", "float32", "f32") + X3_NAMES:
         return torch.float32
-    raise ValueError("compute_dtype must be bf16 or fp32, got %r" % name)
+    raise ValueError("compute_dtype must be bf16, fp32 or x3, got %r" % name)
 
 
 class _TransposedHeads(dict):
@@ -215,6 +221,7 @@ class VinceModel(BaseModel):
         super().__init__(args)
         self.args, self.num_frames = args, args.num_frames
         self.compute_dtype = _compute_dtype(args)
+        self.conv_x3 = str(getattr(args, "compute_dtype", "fp32")).lower() in X3_NAMES
 
         # Modules (vince_model.py:25-49).  Attribute names and nesting ARE the state-dict layout of the reference's checkpoints:
         # feature_extractor.*, embedding.{0,2}.*, jigsaw_linear.*, jigsaw_embedding.{0,2}.*, imagenet_decoders.{0,1.0,1.2}.*
@@ -370,7 +377,7 @@ class VinceModel(BaseModel):
         key = (n, h, w)
         t = self._trunks.get(key)
         if t is None:
-            t = Trunk(self.feature_extractor.arch, n, h, w, self.compute_dtype)
+            t = Trunk(self.feature_extractor.arch, n, h, w, self.compute_dtype, x3=self.conv_x3)
             self._trunks[key] = t
         return t
 

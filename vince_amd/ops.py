@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BnReduce, BnTrain, ConvDesc, ConvEpi, InfoNCEDesc, VINCE_BF16, VINCE_F32, check, lib
+from ._lib import BnReduce, BnTrain, ConvDesc, ConvEpi, InfoNCEDesc, VINCE_BF16, VINCE_F32, VINCE_F32X3B, VINCE_F32X3H, check, lib
 
 EPI_ACCUMULATE, EPI_RELU = _lib.EPI_ACCUMULATE, _lib.EPI_RELU
 STATS_REPLICAS = 16   # VINCE_STATS_REPLICAS in include/vince_hip.h
@@ -115,8 +115,20 @@ def bn_reduce_arg(y, mean, invstd, sums, mask_bits=None, mask_scale=None, mask_s
     return r
 
 
+X3_CODE = {None: None, "h": VINCE_F32X3H, "b": VINCE_F32X3B}
+
+
+def _conv_dtype(x, x3):
+    """x3: None = the tensors' own dtype; "h" / "b" = float32 tensors multiplied as split-half products (VINCE_F32X3H / VINCE_F32X3B)."""
+    if x3 is None:
+        return dtype_code(x)
+    if x.dtype != torch.float32:
+        raise TypeError("vince_amd: split-half products take float32 tensors")
+    return X3_CODE[x3]
+
+
 def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None, replicas=0, out_scale=None,
-               id_scale=None, id_shift=None, out_mask=None, in2=None):
+               id_scale=None, id_shift=None, out_mask=None, in2=None, x3=None):
     """vince_conv_igemm with the epilogue options of vince_conv_epi."""
     require_gpu(x, w, out, bias, stats, acc_mask, out_scale, id_scale, id_shift, out_mask, in2)
     e = ConvEpi()
@@ -133,7 +145,7 @@ def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, b
     e.out_mask = None if out_mask is None else out_mask.data_ptr()
     if in2 is not None:     # the last tap reads this tensor (vince_conv_epi.in2)
         e.in2, e.in2_channels = in2.data_ptr(), in2.shape[-1]
-    check(lib().vince_conv_igemm(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(w), _ptr(out), ctypes.byref(e),
+    check(lib().vince_conv_igemm(ctypes.byref(desc), _conv_dtype(x, x3), _ptr(x), _ptr(w), _ptr(out), ctypes.byref(e),
                                  stream_ptr()))
     return out
 
@@ -220,23 +232,24 @@ def bn3_bwd_finish_dw(RdW, w, gram, colsum, coef, mean, invstd):
     return RdW
 
 
-def conv_wgrad(desc, x, dy, dw, ci_dw=None, variant=0):
+def conv_wgrad(desc, x, dy, dw, ci_dw=None, variant=0, x3=None):
     require_gpu(x, dy, dw)
     if dw.dtype != torch.float32:
         raise TypeError("vince_amd: weight gradients are float32")
-    check(lib().vince_conv_wgrad(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(dy), _ptr(dw),
+    check(lib().vince_conv_wgrad(ctypes.byref(desc), _conv_dtype(x, x3), _ptr(x), _ptr(dy), _ptr(dw),
                                  desc.Ci if ci_dw is None else ci_dw, variant, stream_ptr()))
     return dw
 
 
-def conv_wgrad_det(desc, x, dy, dw, ci_dw=None, scratch=None):
+def conv_wgrad_det(desc, x, dy, dw, ci_dw=None, scratch=None, x3=None):
     """vince_conv_wgrad_det: the reproducible weight gradient (per-split slabs + a fixed-order reduction instead of fp32 atomics)."""
     require_gpu(x, dy, dw, scratch)
     ci = desc.Ci if ci_dw is None else ci_dw
+    code = _conv_dtype(x, x3)
     if scratch is None:
-        need = lib().vince_conv_wgrad_scratch_bytes(ctypes.byref(desc), dtype_code(x), ci)
+        need = lib().vince_conv_wgrad_scratch_bytes(ctypes.byref(desc), code, ci)
         scratch = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
-    check(lib().vince_conv_wgrad_det(ctypes.byref(desc), dtype_code(x), _ptr(x), _ptr(dy), _ptr(dw), ci, _ptr(scratch), scratch.numel(),
+    check(lib().vince_conv_wgrad_det(ctypes.byref(desc), code, _ptr(x), _ptr(dy), _ptr(dw), ci, _ptr(scratch), scratch.numel(),
                                      stream_ptr()))
     return dw
 
