@@ -13,9 +13,16 @@ ResNet-50, 224x224, B=256 per GPU, K=65536, D=128, T=0.2, bf16 trunk / fp32 head
 synthetic N(0,1) frames.  Weak scaling: per-GPU batch fixed.
 
 Extra legs (rank 0, N=1 only unless --no-extras):
-  roofline      per-kernel hipEvent timing of the dominant kernel (bf16 implicit-GEMM conv, 128-channel tile) over
-                instrumented steps: algorithmic FLOPs of its launches / their summed duration vs the 2.5 PFLOP/s dense
-                bf16 MFMA peak; plus the whole-step MFMA fraction.
+  roofline      every kernel family's launches bracketed by hipEvent pairs over instrumented (stream-serialised) steps;
+                `roofline.kernel` = the family with the most time per step whatever it is, held against the roof that binds
+                it (dense bf16 MFMA 2.5 PFLOP/s, or HBM 8 TB/s for the streaming families), `kernels` lists them all;
+                `traffic` / `step_hbm` from the committed PMC passes (profiles/pmc_conv_igemm.json, stamped with the
+                kernel-source hash).
+  fwd_infonce   forward + InfoNCE on B frames (the north-star quantity), no-grad and grad-enabled.
+  x3_step / fp32_step   the same step with fp32 tensors: convolutions as split-half products (compute_dtype "x3": the mode
+                that meets the reference's 1e-3 bar, priced against 2.5 PF / 3 -- three half-precision MFMAs per product)
+                and as exact fp32 MFMAs (157 TF/s); each with its own forward + InfoNCE time (dtype-matched roofs).
+  c2_step / c5_step     BASELINE config 2 and config 5's per-GPU work.
   cpu_baseline  the CPU oracle (oracle/vince_oracle.py, a torch-CPU restatement pinned to the reference) timed on the
                 host cores at B=16 for a few steps.
 """
@@ -37,7 +44,9 @@ import torch  # noqa: E402
 STEP_GFLOP_PER_SAMPLE = {"ResNet50": 32.766, "ResNet18": 14.512}     # key fwd + query fwd + query bwd + similarity
 FWD_GFLOP_PER_FRAME = {"ResNet50": 8.2000, "ResNet18": 3.6282}
 TRUNK_GFLOP_PER_FRAME = {"ResNet50": 8.1743, "ResNet18": 3.6271}      # conv MACs x 2 per image
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}                          # MI355X_MICROARCH.md dense MFMA peaks
+# MI355X_MICROARCH.md dense MFMA peaks; "x3" = fp32 tensors multiplied as hi*hi + hi*lo + lo*hi on the half-precision pipe:
+# three MFMAs per algorithmic product, so the roof for ALGORITHMIC FLOPs is a third of the 16-bit peak
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "x3": 2500.0 / 3.0}
 # One tag per kernel family, in the library's order (csrc/common.h VINCE_TAG_*).  bound "mfma": the profiler's `work` is algorithmic
 # FLOPs and the roof is the dense MFMA peak of the dtype; bound "hbm": `work` is algorithmic BYTES and the roof is 8 TB/s.
 KERNEL_TAGS = [("conv_igemm<%s,%s,%s>" % (t, shape, e), "mfma", t) for t in ("f32", "bf16")
@@ -161,7 +170,7 @@ def main():
     ap.add_argument("--queue", type=int, default=65536)
     ap.add_argument("--embed", type=int, default=128)
     ap.add_argument("--temperature", type=float, default=0.2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "x3"])
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline and cpu_baseline legs")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -469,7 +478,7 @@ def main():
         #              (vince/train_moco_v2.sh:40 has --use-apex commented out) and the mode that meets the 1e-3 embedding bar
         #   c2_step:   BASELINE config 2 (ResNet-18, fp32, B=256, K=4096, D=64, T=0.07)
         #   c5_step:   BASELINE config 5's per-GPU work (4 frames per clip, inter-batch + self-batch comparison, jigsaw side)
-        def step_leg(steps, frames=1, gflop_backbone=None, **over):
+        def step_leg(steps, frames=1, gflop_backbone=None, fwd_too=False, **over):
             nonlocal solver
             solver = None
             torch.cuda.empty_cache()
@@ -496,14 +505,46 @@ def main():
             if gf:
                 tfl = gf * bsz / 1000.0 / t2
                 leg.update({"tflops": round(tfl, 1), "mfma_frac": round(tfl / PEAK_TFLOPS[dt_name], 4)})
+            if fwd_too:   # the north-star quantity in THIS leg's dtype: no-grad forward + InfoNCE on B frames against its own roof
+                fb = base["batch_source"](0) if callable(base["batch_source"]) else None
+                fb = fb if fb is not None else pool(0)
+                fb = {"data": fb["data"][:bsz], "batch_types": ["images"], "batch_sizes": [bsz]}
+                kq2 = s2.vince_queue.dequeue()["queue_vectors"]
+                keys2 = torch.nn.functional.normalize(torch.randn(bsz, a2.vince_embedding_size, device=device), dim=1)
+
+                def f_once():
+                    with torch.no_grad():
+                        o = s2.model.get_embeddings(fb)[0]
+                        o.update(dict(queue_embeddings=keys2, queue_vectors=kq2, data_source="SYN", num_frames=1))
+                        return s2.model.loss(s2.model(o))["nce_loss"][1]
+
+                for _ in range(2):
+                    f_once()
+                barrier()
+                t3 = time.perf_counter()
+                for _ in range(max(3, steps)):
+                    f_once()
+                barrier()
+                t3 = (time.perf_counter() - t3) / max(3, steps)
+                ftf = FWD_GFLOP_PER_FRAME.get(gflop_backbone, 0.0) * bsz / 1000.0 / t3
+                leg["fwd_infonce"] = {"ms": round(t3 * 1000, 3), "tflops": round(ftf, 1), "mfma_frac": round(ftf / PEAK_TFLOPS[dt_name], 4),
+                                      "roof_tflops": round(PEAK_TFLOPS[dt_name], 1)}
             del s2
             torch.cuda.empty_cache()
             return leg
 
         is_c3 = opt.mode == "moco" and opt.input == "float"
+        if opt.fp32_steps > 0 and opt.dtype != "x3" and is_c3:
+            try:
+                out["x3_step"] = dict(step_leg(opt.fp32_steps, gflop_backbone=opt.backbone, fwd_too=True, compute_dtype="x3"),
+                                      what="fp32 tensors, convolutions as split-half products (f16 hi/lo forward, bf16 hi/lo gradients): the "
+                                           "parity mode -- embeddings and loss within 1e-3 of the fp32 reference (tests at the bar: G3, G9, "
+                                           "G11c, G12); mfma_frac against 2.5 PF / 3")
+            except Exception as e:
+                out["x3_step"] = {"error": repr(e)}
         if opt.fp32_steps > 0 and opt.dtype != "fp32":
             try:
-                out["fp32_step"] = step_leg(opt.fp32_steps, gflop_backbone=opt.backbone, compute_dtype="fp32")
+                out["fp32_step"] = step_leg(opt.fp32_steps, gflop_backbone=opt.backbone, fwd_too=is_c3, compute_dtype="fp32")
             except Exception as e:
                 out["fp32_step"] = {"error": repr(e)}
         if opt.config_steps > 0 and is_c3:
@@ -518,9 +559,9 @@ def main():
                 random.seed(1234 + rank)
                 out["c5_step"] = dict(step_leg(opt.config_steps, frames=4, num_frames=4, inter_batch_comparison=True,
                                                self_batch_comparison=True, jigsaw=True, vince_self_temperature=0.03),
-                                      workload="BASELINE config 5 per-GPU work: %s %dx%d, B=%d clips x 4 frames, K=%d, inter-batch + "
+                                      workload="BASELINE config 5 per-GPU work: %s %dx%d, B=%d frames = %d clips x 4 frames, K=%d, inter-batch + "
                                                "self-batch comparison, jigsaw side by a seeded coin, %s trunk"
-                                               % (opt.backbone, opt.size, opt.size, opt.batch, opt.queue, opt.dtype))
+                                               % (opt.backbone, opt.size, opt.size, opt.batch, opt.batch // 4, opt.queue, opt.dtype))
             except Exception as e:
                 out["c5_step"] = {"error": repr(e)}
         # ---- cpu_baseline leg ----------------------------------------------------------------------------------------

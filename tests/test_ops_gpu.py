@@ -73,12 +73,12 @@ CONVS = [
 ]
 
 
-def weights_krsc(w, dtype, cip=None):
-    """OIHW fp32 CPU -> GPU [Co][T][Ci] master (fp32) -> compute copies."""
+def weights_krsc(w, dtype, cip=None, x3=False):
+    """OIHW fp32 CPU -> GPU [Co][T][Ci] master (fp32) -> compute copies (x3: the split-half layout of VINCE_F32X3)."""
     ops = _ops()
     Co, Ci, kh, kw = w.shape
     master = w.permute(0, 2, 3, 1).reshape(Co, kh * kw, Ci).contiguous().to(DEV)
-    return ops.prepare_weight(master, dtype, cip=cip, want_transposed=True)
+    return ops.prepare_weight(master, dtype, cip=cip, want_transposed=True, x3=x3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -37,11 +37,12 @@ def test_x3h_forward_conv_is_as_good_as_fp32(cfg, xscale):
     w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k)) ** 0.5)
     ref = F.conv2d(x.double(), w.double(), None, s, p)
     wk, _ = weights_krsc(w, torch.float32)
+    wk3, _ = weights_krsc(w, torch.float32, x3=True)     # the split-half weight layout (IEEE half pairs)
     d = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
     xg = to_nhwc(x, torch.float32)
     out = torch.empty(N, d.Ho, d.Wo, Co, device=DEV)
     stats = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
-    ops.conv_igemm(d, xg, wk, out, stats=stats, x3="h")
+    ops.conv_igemm(d, xg, wk3, out, stats=stats, x3="h")
     e3 = _err(from_nhwc(out), ref)
     out32 = torch.empty_like(out)
     ops.conv_igemm(d, xg, wk, out32)
@@ -63,7 +64,7 @@ def test_x3b_gradients_vs_fp64(cfg):
     y = F.conv2d(x, w, None, s, p)
     dy = rnd(*y.shape, seed=8) * 1e-6
     y.backward(dy.double())
-    wk, wt = weights_krsc(w.detach().float(), torch.float32)
+    wk, wt = weights_krsc(w.detach().float(), torch.float32, x3=True)     # wt: the split-half layout, bfloat16 pairs
     dyg = to_nhwc(dy, torch.float32)
     dx = torch.full((N, H, W, Ci), float("nan"), device=DEV)
     descs = ops.dgrad_descs(N, H, W, Ci, Co, k, s, p)
@@ -104,7 +105,7 @@ def test_x3_stem_packed_rows(hw):
     xin = ops.input_nchw_to_rows(x.float().to(DEV), torch.float32)
     wp = torch.zeros(64, 7, 8, 4)
     wp[:, :, :7, :3] = w.detach().float().permute(0, 2, 3, 1)
-    wk = wp.reshape(64, 7, 32).to(DEV).contiguous()
+    wk, _ = ops.prepare_weight(wp.reshape(64, 7, 32).to(DEV).contiguous(), torch.float32, want_transposed=False, x3=True)
     d = ops.stem_desc(N, H, W)
     out = torch.empty(N, d.Ho, d.Wo, 64, device=DEV)
     ops.conv_igemm(d, xin, wk, out, x3="h")

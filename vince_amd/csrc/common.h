@@ -147,8 +147,9 @@ template <> struct Chunk<bf16_t> {
 // Split-half products (VINCE_F32X3H / VINCE_F32X3B): tensors stay fp32 in HBM and LDS; inside the MFMA loops every operand
 // element x is split into hi = half(x) and lo = half(x - hi) and the product runs as hi*hi + hi*lo + lo*hi on the half-precision
 // matrix pipe (3 x v_mfma_f32_32x32x16 = 96 cycles per 32x32x16 block against 512 for 8 x v_mfma_f32_32x32x2_f32), fp32 accumulate.
-//   x3h_t: IEEE half halves (11 + 11 significand bits: products to ~2^-22, the forward's precision; the WEIGHT operand is scaled by
-//          2^X3_WSHIFT before the split so that its lo half stays a normal half number, the accumulators are scaled back once);
+//   x3h_t: IEEE half halves (11 + 11 significand bits: products to ~2^-22, the forward's precision; both operands are scaled by a
+//          power of two before the split -- weights by 2^X3_WSHIFT, activations by 2^X3_XSHIFT -- so that their lo halves stay
+//          normal half numbers over the ranges a BatchNorm network produces; the accumulators are scaled back once);
 //   x3b_t: bfloat16 halves (8 + 8 bits, fp32's exponent range: the gradient launches, whose operands span many decades).
 // Both are tags over float: same chunk / element traits, same layouts, same epilogues.
 // ---------------------------------------------------------------------------------------------
@@ -161,7 +162,8 @@ template <> struct Chunk<x3b_t> : Chunk<float> {};
 template <typename T> struct X3 { static constexpr bool on = false, half = false; };
 template <> struct X3<x3h_t> { static constexpr bool on = true, half = true; };
 template <> struct X3<x3b_t> { static constexpr bool on = true, half = false; };
-constexpr int X3_WSHIFT = 8;   // |w| < 2^(16 - 8) keeps hi finite; lo is a normal half number down to |w| ~ 5e-4
+constexpr int X3_WSHIFT = 8;   // weights:     |w| < 2^(16 - 8) keeps hi finite; lo is a normal half number down to |w| ~ 5e-4
+constexpr int X3_XSHIFT = 4;   // activations: |x| < 2^(16 - 4); lo normal down to |x| ~ 8e-3, below that absolute steps of 4e-9
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(2))) __fp16 fp16x2_t;
@@ -177,7 +179,7 @@ template <typename T, bool WEIGHT> __device__ __forceinline__ void x3_split(cons
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         if constexpr (X3<T>::half) {
-            constexpr float K = WEIGHT ? (float)(1 << X3_WSHIFT) : 1.f;
+            constexpr float K = (float)(1 << (WEIGHT ? X3_WSHIFT : X3_XSHIFT));
             const float a = x[2 * p] * K, b = x[2 * p + 1] * K;
             const fp16x2_t hp = __builtin_amdgcn_cvt_pkrtz(a, b);          // hi by truncation: a - hi is exact in fp32
             const fp16x2_t lp = __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]);

@@ -62,7 +62,7 @@ template <> struct Mma<float> {
     }
 };
 
-// x3h_t scales the weight operand by 2^X3_WSHIFT before splitting it (common.h): the accumulators go back by the same power of two
+// x3h_t scales its operands by 2^X3_WSHIFT and 2^X3_XSHIFT before splitting them (common.h): the accumulators go back by the product
 template <typename T, int A, int B> __device__ __forceinline__ void x3_unscale(f32x16_t (&acc)[A][B]) {
     if constexpr (X3<T>::on && X3<T>::half) {
 #pragma unroll
@@ -70,7 +70,7 @@ template <typename T, int A, int B> __device__ __forceinline__ void x3_unscale(f
 #pragma unroll
             for (int i = 0; i < B; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[j][i][e] *= 1.f / (float)(1 << X3_WSHIFT);
+                for (int e = 0; e < 16; ++e) acc[j][i][e] *= 1.f / (float)(1 << (X3_WSHIFT + X3_XSHIFT));
     }
 }
 

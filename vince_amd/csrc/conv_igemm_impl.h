@@ -134,8 +134,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             for (int s = 0; s < KC / 2; s += 2) {
                 uint4 wh[CJ], wl[CJ], xh[2], xl[2];
 #pragma unroll
-                for (int j = 0; j < CJ; ++j)
-                    x3_split<T, true>(*(const uint4*)(ws + j * 32 * RS + s * 32), *(const uint4*)(ws + j * 32 * RS + s * 32 + 32), wh[j], wl[j]);
+                for (int j = 0; j < CJ; ++j) {   // weights arrive split (vince_prepare_weight, VINCE_F32X3): chunk h = hi, chunk 2 + h = lo
+                    wh[j] = *(const uint4*)(ws + j * 32 * RS + s * 32);
+                    wl[j] = *(const uint4*)(ws + j * 32 * RS + s * 32 + 32);
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     x3_split<T, false>(*(const uint4*)(xs + i * 32 * RS + s * 32), *(const uint4*)(xs + i * 32 * RS + s * 32 + 32), xh[i], xl[i]);
@@ -191,10 +193,14 @@ struct SmemD {
 // PTL = pixels per workgroup tile (128 or 256).  The L2 -> LDS fill rate of a CU (measured ~19 B/clk with every CU
 // streaming) caps a 128x128 tile at ~700 TFLOP/s chip-wide: 256 B of operands per K element feed 32768 FLOP.  The
 // 256-pixel tile moves 25 % fewer bytes per FLOP (each wave owns 128 pixels x CT/2 channels).
-template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, int MODE, bool ROT = false>
+// WN = wavefronts along the channel axis (the other 4 / WN split the pixels): 2 = the 2 x 2 arrangement, 1 = every wavefront holds all CT
+// channels of PTL / 4 pixels.
+template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, int MODE, bool ROT = false, int WN = 2>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
-    constexpr int CJ = CT / 64, PI = PTL / 64;
+    constexpr int WP = 4 / WN;
+    constexpr int CJ = CT / (32 * WN), PI = PTL / (32 * WP);
+    static_assert(!ROT || WN == 2, "the rotated loop is written for the 2 x 2 arrangement");
     using S = SmemD<T, CT, KC, STAGES, PTL>;
     constexpr int KB = S::KB;
     constexpr int RPW = 1024 / KB;                 // rows per wave DMA instruction (8 or 16)
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     if (IG_ABL(64)) return;   // launch + workgroup dispatch only
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave & 1, wp = wave >> 1;
+    const int wc = wave % WN, wp = wave / WN;
     const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
     const int ptile = tile / p.ctiles, ctile = tile - ptile * p.ctiles;
     const int p0 = ptile * PTL, c0 = ctile * CT;
@@ -409,18 +415,22 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     }
     for (int kt = kt0; kt < kt1; ++kt) {
         if (!IG_ABL(1)) issue_tile(kt + STAGES - 1, nbuf);
-        const unsigned char* xs = smem + buf * S::STAGE + (wp * (PTL / 2)) * KB + row_off;
-        const unsigned char* ws = smem + buf * S::STAGE + S::XB + (wc * (CT / 2)) * KB + row_off;
+        const unsigned char* xs = smem + buf * S::STAGE + (wp * (PTL / WP)) * KB + row_off;
+        const unsigned char* ws = smem + buf * S::STAGE + S::XB + (wc * (CT / WN)) * KB + row_off;
         if constexpr (X3<T>::on) {
-            // split-half products (x3h_t / x3b_t): the fragments of two MFMA phases (8 floats per lane and row) are split into
-            // hi / lo halves in registers and feed three half-precision 32x32x16 MFMAs per output block
+            // split-half products (x3h_t / x3b_t): the activation fragments of two MFMA phases (8 floats per lane and row) are split
+            // into hi / lo halves in registers, the weight fragments come split from the weight cache; three half-precision
+            // 32x32x16 MFMAs per output block.  The split is VALU work per ACTIVATION fragment, so these types run with WN = 1: a
+            // wavefront owns 32 pixels x all CT channels (one activation fragment per CT / 32 blocks)
 #pragma unroll
             for (int s = 0; s < KC / 2; s += 2) {
                 const int slot0 = ((s * 2 + khalf) ^ sw) * 16, slot1 = ((s * 2 + 2 + khalf) ^ sw) * 16;
                 uint4 wh[CJ], wl[CJ], xh[PI], xl[PI];
 #pragma unroll
-                for (int j = 0; j < CJ; ++j)
-                    x3_split<T, true>(*(const uint4*)(ws + j * 32 * KB + slot0), *(const uint4*)(ws + j * 32 * KB + slot1), wh[j], wl[j]);
+                for (int j = 0; j < CJ; ++j) {   // weights arrive split (vince_prepare_weight, VINCE_F32X3): chunk h = hi, chunk 2 + h = lo
+                    wh[j] = *(const uint4*)(ws + j * 32 * KB + slot0);
+                    wl[j] = *(const uint4*)(ws + j * 32 * KB + slot1);
+                }
 #pragma unroll
                 for (int i = 0; i < PI; ++i)
                     x3_split<T, false>(*(const uint4*)(xs + i * 32 * KB + slot0), *(const uint4*)(xs + i * 32 * KB + slot1), xh[i], xl[i]);
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     }
     x3_unscale<T>(acc);
     // rows in flight per thread in the epilogue: the 128-VGPR (4 workgroups/CU) configuration has no room for more than 2
-    conv_epilogue<T, CT, S::CRS, MODE, PTL, (MINW >= 4 ? 2 : 4)>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
+    conv_epilogue<T, CT, S::CRS, MODE, PTL, (MINW >= 4 ? 2 : 4), 256, WN>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
 __global__ void relu_inplace_kernel(float* x, size_t n4) {
@@ -509,10 +519,7 @@ __global__ void relu_inplace_kernel(float* x, size_t n4) {
 template <typename T, int CT, int MODE>
 int launch(ConvParams& p, hipStream_t stream) {
     constexpr bool BWD = MODE != 0;   // (anything but the lean forward epilogue)
-    // the split-half element types (x3h_t / x3b_t) keep raw and split fragments in registers: three workgroups per CU where the plain
-    // types fit four, and the plain (not rotated) main loop everywhere
-    constexpr int MW4 = X3<T>::on ? 3 : 4;
-    constexpr bool ROTV = !X3<T>::on;
+    static_assert(!X3<T>::on, "the split-half element types have their own tile selection: launch_x3");
     static int dlds_min_k = vince_knob("dlds_min_k", 0);
     const int k_elems = p.total_chunks * (16 / (int)sizeof(T));
     // VINCE_DLDS_CFG=4 forces the 128-pixel tile everywhere (measurement aid); the default (5) adds the 256-pixel tile
@@ -553,10 +560,8 @@ int launch(ConvParams& p, hipStream_t stream) {
             if constexpr (CT == 128) {
                 p.ptiles = (p.M + 255) / 256;
                 p.variant = 1;
-                if constexpr (X3<T>::on) {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
-                } else if (rot & 1) {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE, ROTV>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                if (rot & 1) {
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
                                        stream, p);
                 } else {
                     hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
@@ -569,10 +574,8 @@ int launch(ConvParams& p, hipStream_t stream) {
             if constexpr (CT == 64) {
                 p.ptiles = (p.M + 255) / 256;
                 p.variant = 1;
-                if constexpr (X3<T>::on) {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
-                } else if (rot & 2) {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, MODE, ROTV>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
+                if (rot & 2) {
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, MODE, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
                                        stream, p);
                 } else {
                     hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 64, 4, 2, 3, 256, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0,
@@ -598,7 +601,7 @@ int launch(ConvParams& p, hipStream_t stream) {
                 splits = (p.nkt + p.kt_per_split - 1) / p.kt_per_split;
                 const size_t n = (size_t)p.M * p.d.Co;
                 if (int zrc = vince_zero_async(p.out, n * sizeof(float), stream)) return zrc;
-                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, MW4, PT, MODE>), dim3(p.ptiles * p.ctiles, splits), dim3(256), 0,
+                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE>), dim3(p.ptiles * p.ctiles, splits), dim3(256), 0,
                                    stream, p);
                 if (relu) hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)min((size_t)1024, (n / 4 + 255) / 256)), dim3(256), 0,
                                              stream, (float*)p.out, n / 4);
@@ -608,14 +611,14 @@ int launch(ConvParams& p, hipStream_t stream) {
                 // default 2048: layer4's 3x3 (K = 4608) 92.6 -> 85 us, 2048 -> 512 50 -> 44 us; shorter reductions lose
                 static const int s3_min_k = vince_knob("s3_min_k", 2048);
                 if (s3_min_k > 0 && k_elems >= s3_min_k) {
-                    if (!X3<T>::on && (rot & 8))
-                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE, ROTV>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                    if (rot & 8)
+                        hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
                     else
                         hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
-                } else if (!X3<T>::on && (rot & 4) && k_elems >= rot_min_k) {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, MW4, PT, MODE, ROTV>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                } else if ((rot & 4) && k_elems >= rot_min_k) {
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
                 } else {
-                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, MW4, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                    hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 4, PT, MODE>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
                 }
             }
         }
@@ -635,6 +638,43 @@ int launch(ConvParams& p, hipStream_t stream) {
     } else {
         p.nkt = (p.total_chunks + 3) / 4;
         hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 4, (MODE == 2 ? 2 : 1)>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+    }
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
+// Tile selection of the split-half element types (x3h_t / x3b_t).  128-pixel tiles, every wavefront over all CT channels of 32 pixels
+// (WN = 1: the in-register split is paid per ACTIVATION fragment while the weights arrive split, so one activation fragment should
+// feed as many MFMA blocks as the tile has channels), plain main loop.  x3_cfg (cross-check / measurement switch): 1 (default) =
+// 128-byte K rows (whole cache lines, half the barriers per reduction element), 2 stages; 0 = 64-byte K rows, 2 or 3 stages by
+// reduction length (measured on the 12 layer shapes of ResNet-50 at N = 256: forward 2.26 -> 2.07 ms, input gradients 2.23 -> 2.02).
+template <typename T, int CT, int MODE>
+int launch_x3(ConvParams& p, hipStream_t stream) {
+    static_assert(X3<T>::on, "launch_x3 is for x3h_t / x3b_t");
+    const int k_elems = p.total_chunks * 4;
+    const int cpt = p.cpt_mask == 0x7fffffff ? p.total_chunks : p.cpt_mask + 1;
+    p.uniform_taps = (cpt % 4 == 0) && (p.total_chunks % 4 == 0);
+    if (!p.uniform_taps || p.in2) {
+        vince_set_error("vince_conv_igemm: the split-half types need Ci to be a multiple of 16 (the split weight layout) and take no in2");
+        return VINCE_E_SHAPE;
+    }
+    const dim3 grid(p.ptiles * p.ctiles);
+    if (p.in_bytes && p.w_bytes) {
+        static const int x3_cfg = vince_knob("x3_cfg", 1);
+        static const int x3_s3_min_k = vince_knob("x3_s3_min_k", 2048);
+        p.nkt = p.total_chunks / 4;     // 64-byte K rows
+        if (x3_cfg == 1 && cpt % 8 == 0 && p.total_chunks % 8 == 0) {
+            p.nkt = p.total_chunks / 8;
+            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 2, 2, PT, MODE, false, 1>), grid, dim3(256), 0, stream, p);
+        } else if (k_elems >= x3_s3_min_k) {
+            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE, false, 1>), grid, dim3(256), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 2, 3, PT, MODE, false, 1>), grid, dim3(256), 0, stream, p);
+        }
+    } else {   // tensors beyond the 31-bit buffer offsets of the direct-to-LDS path: the register-staged kernel (2 x 2 wavefronts)
+        p.variant = 2;
+        p.nkt = p.total_chunks / 4;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, CT, 4, (MODE == 2 ? 2 : 1)>), grid, dim3(256), 0, stream, p);
     }
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;

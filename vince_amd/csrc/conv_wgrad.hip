@@ -571,6 +571,13 @@ int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t
     const int use_tr = (int)vince_knob_live("wgrad_tr", 1);
     int tr_ct = 0, tr_nt = 0;
     if (use_tr && std::is_same<T, bf16_t>::value) vince_wgrad::wgrad_tr_tile(p, &tr_ct, &tr_nt);
+    // split-half products: the kernel of conv_wgrad_x3.hip (the addressing of conv_wgrad_tr on fp32 tiles) whenever the layer qualifies
+    // (`wgrad_x3=0`: the LDS-DMA kernel of this file instantiated for x3b_t, cross-check switch)
+    bool x3k = false;
+    if (std::is_same<T, x3b_t>::value && vince_knob_live("wgrad_x3", 1)) {
+        vince_wgrad::wgrad_x3_tile(p, &tr_ct, &tr_nt);
+        x3k = tr_ct > 0;
+    }
     const bool tr = tr_ct > 0;
     if (tr) { CT = tr_ct; NT = tr_nt; }
     // (Measured and not kept, round 3: the LDS-DMA kernel as 8 wavefronts on a 256 x 256 tile for layer3 / layer4's 3x3 -- half the operand
@@ -624,7 +631,8 @@ int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t
         }
     }
     int rc;
-    if (tr) rc = vince_wgrad::wgrad_tr_launch(p, CT, NT, splits, stream);
+    if (x3k) rc = vince_wgrad::wgrad_x3_launch(p, CT, NT, splits, stream);
+    else if (tr) rc = vince_wgrad::wgrad_tr_launch(p, CT, NT, splits, stream);
     else     if (CT == 64 && NT == 64) rc = launch<T, 64, 64>(p, splits, stream);
     else if (CT == 64) rc = launch<T, 64, 128>(p, splits, stream);
     else if (NT == 64) rc = launch<T, 128, 64>(p, splits, stream);

@@ -214,6 +214,117 @@ __global__ __launch_bounds__(256) void prepare_weights_batched_kernel(const vinc
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-half weight layout (dtype VINCE_F32X3; csrc/common.h x3_split).  The convolution kernels split every ACTIVATION fragment into
+// hi / lo halves in registers; the weights are split HERE, once per parameter update, so that a weight fragment is two plain 16-byte
+// LDS reads.  A K-contiguous row (K = Cip for the forward copy, Co for the transposed one; multiples of 16) is stored in groups of
+// 16 elements = 64 bytes -- the footprint of 16 floats -- as four 16-byte chunks
+//      [hi of e0-3, e8-11] [hi of e4-7, e12-15] [lo of e0-3, e8-11] [lo of e4-7, e12-15]
+// which is the order in which MFMA lane half `h` finds the 8 activations of its K slots (16-byte chunks h and 2 + h of the fp32 row).
+// wk: IEEE half pairs scaled by 2^X3_WSHIFT (forward launches, VINCE_F32X3H); wt: bfloat16 pairs (gradient launches, VINCE_F32X3B).
+template <typename T> __device__ __forceinline__ void x3_store_group(void* dst, const float* v) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint4 hi, lo;
+        x3_split<T, true>(make_uint4(__float_as_uint(v[4 * h]), __float_as_uint(v[4 * h + 1]), __float_as_uint(v[4 * h + 2]), __float_as_uint(v[4 * h + 3])),
+                          make_uint4(__float_as_uint(v[8 + 4 * h]), __float_as_uint(v[9 + 4 * h]), __float_as_uint(v[10 + 4 * h]), __float_as_uint(v[11 + 4 * h])),
+                          hi, lo);
+        *(uint4*)((unsigned char*)dst + 16 * h) = hi;
+        *(uint4*)((unsigned char*)dst + 32 + 16 * h) = lo;
+    }
+}
+
+__device__ void prep_x3_entry(const vince_prep_entry& e, unsigned char* tile_raw) {
+    const float* __restrict__ w = (const float*)e.w;
+    const float* __restrict__ sc = e.scale;
+    unsigned char* __restrict__ wk = (unsigned char*)e.wk;
+    unsigned char* __restrict__ wt = (unsigned char*)e.wt;
+    if (e.Cs > 0) {   // packed row taps (the stem): element k of tap t is (kw = k / Cs, c = k % Cs); forward copy only
+        const int64_t groups = (int64_t)e.Co * e.T * (e.Cip / 16);
+        for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+            const int k0 = (int)(g % (e.Cip / 16)) * 16;
+            const int64_t r = g / (e.Cip / 16);   // co * T + t
+            const float m = sc ? sc[r / e.T] : 1.f;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = k0 + i, kw = k / e.Cs, c = k - kw * e.Cs;
+                v[i] = (kw < e.Kw && c < e.Ci) ? w[((size_t)r * e.Kw + kw) * e.Ci + c] * m : 0.f;
+            }
+            x3_store_group<x3h_t>(wk + ((size_t)r * e.Cip + k0) * 4, v);
+        }
+        return;
+    }
+    if (wt && e.Ci % 64 == 0 && e.Co % 64 == 0 && e.Cip == e.Ci) {
+        // 64 x 64 (co x ci) tiles through LDS, both copies written as whole 64-byte groups
+        float (*tile)[65] = (float (*)[65])tile_raw;
+        const int tci = e.Ci / 64, tco = e.Co / 64;
+        const int ntiles = tco * e.T * tci;
+        const int row = threadIdx.x >> 2, grp = threadIdx.x & 3;
+        for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+            const int ci0 = (tl % tci) * 64;
+            const int t = (tl / tci) % e.T;
+            const int co0 = (tl / (tci * e.T)) * 64;
+            {
+                const size_t off = ((size_t)(co0 + row) * e.T + t) * e.Ci + ci0 + grp * 16;
+                const float m = sc ? sc[co0 + row] : 1.f;
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    const float4 q = *(const float4*)(w + off + i);
+                    v[i] = q.x * m; v[i + 1] = q.y * m; v[i + 2] = q.z * m; v[i + 3] = q.w * m;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tile[row][grp * 16 + i] = v[i];
+                x3_store_group<x3h_t>(wk + off * 4, v);
+            }
+            __syncthreads();
+            {
+                float v[16];   // row = ci within the tile, the group runs along co
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = tile[grp * 16 + i][row];
+                x3_store_group<x3b_t>(wt + (((size_t)(ci0 + row) * e.T + t) * e.Co + co0 + grp * 16) * 4, v);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    {   // any other shape (Cip and, for the transposed copy, Co multiples of 16): one group per thread, gathered element-wise
+        const int64_t groups = (int64_t)e.Co * e.T * (e.Cip / 16);
+        for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+            const int k0 = (int)(g % (e.Cip / 16)) * 16;
+            const int64_t r = g / (e.Cip / 16);
+            const int t = (int)(r % e.T), co = (int)(r / e.T);
+            const float m = sc ? sc[co] : 1.f;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = (k0 + i) < e.Ci ? w[((size_t)co * e.T + t) * e.Ci + k0 + i] * m : 0.f;
+            x3_store_group<x3h_t>(wk + ((size_t)r * e.Cip + k0) * 4, v);
+        }
+        if (wt) {
+            const int64_t tg = (int64_t)e.Ci * e.T * (e.Co / 16);
+            for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < tg; g += (int64_t)gridDim.x * 256) {
+                const int co0 = (int)(g % (e.Co / 16)) * 16;
+                const int64_t r = g / (e.Co / 16);   // ci * T + t
+                const int t = (int)(r % e.T), ci = (int)(r / e.T);
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = w[((size_t)(co0 + i) * e.T + t) * e.Ci + ci] * (sc ? sc[co0 + i] : 1.f);
+                x3_store_group<x3b_t>(wt + ((size_t)r * e.Co + co0) * 4, v);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void prepare_weights_batched_x3_kernel(const vince_prep_entry* __restrict__ table) {
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 65 * 4];
+    prep_x3_entry(table[blockIdx.y], tile);
+}
+__global__ __launch_bounds__(256) void prepare_weight_x3_kernel(const vince_prep_entry e) {
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 65 * 4];
+    prep_x3_entry(e, tile);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int N,
                                                            int C, int H, int W) {
@@ -370,9 +481,19 @@ extern "C" int vince_jigsaw_nchw_to_nhwc(int dtype, const float* in, void* out, 
 
 extern "C" int vince_prepare_weight(int dtype, const float* w, void* wk, void* wt, int32_t Co, int32_t T, int32_t Ci,
                                     int32_t Cip, void* stream) {
-    DTYPE_OK("vince_prepare_weight");
     VINCE_CHECK_ARG(w && wk && Co > 0 && T > 0 && Ci > 0 && Cip >= Ci, VINCE_E_ARG, "vince_prepare_weight: bad arguments");
     const int64_t total = (int64_t)Co * T * Cip;
+    if (dtype == VINCE_F32X3) {   // split-half layout: wk = IEEE half pairs (forward), wt = bfloat16 pairs (gradients)
+        VINCE_CHECK_ARG(Cip % 16 == 0 && (!wt || Co % 16 == 0), VINCE_E_SHAPE,
+                        "vince_prepare_weight: the split-half layout needs Cip (and Co for the transposed copy) to be multiples of 16");
+        vince_prep_entry e;
+        e.w = w; e.wk = wk; e.wt = wt; e.scale = nullptr;
+        e.Co = Co; e.T = T; e.Ci = Ci; e.Cip = Cip; e.Cs = e.Kw = 0;
+        hipLaunchKernelGGL(prepare_weight_x3_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, e);
+        VINCE_CHECK_LAUNCH();
+        return VINCE_OK;
+    }
+    DTYPE_OK("vince_prepare_weight");
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(prepare_weight_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w,
                            (float*)wk, (float*)wt, Co, T, Ci, Cip);
@@ -412,10 +533,15 @@ extern "C" int vince_transpose_f32(const float* in, float* out, int32_t rows, in
 }
 
 extern "C" int vince_prepare_weights_batched(int dtype, const vince_prep_entry* table_dev, int32_t n, void* stream) {
-    DTYPE_OK("vince_prepare_weights_batched");
     VINCE_CHECK_ARG(table_dev && n > 0, VINCE_E_ARG, "vince_prepare_weights_batched: bad arguments");
     static const int tiled = (VINCE_MEASURE_KNOB("prep_tiled", 1) != 0);   // measurement aid
     const dim3 grid(512, n);   // blocks beyond a small layer's element count fall through the grid-stride loop at once
+    if (dtype == VINCE_F32X3) {   // (every entry: Cip and, with a transposed copy, Co multiples of 16 -- the caller's contract)
+        hipLaunchKernelGGL(prepare_weights_batched_x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, table_dev);
+        VINCE_CHECK_LAUNCH();
+        return VINCE_OK;
+    }
+    DTYPE_OK("vince_prepare_weights_batched");
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(prepare_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, table_dev, tiled);
     else

@@ -703,7 +703,8 @@ int prepare_common(vince_trunk* t, const float* const* params, void* wcache, con
         last = tab;
         t->prep_table_dev[which] = dev_table;
     }
-    return vince_prepare_weights_batched(t->sdtype, (const vince_prep_entry*)dev_table, (int32_t)tab.size(), stream);
+    // (VINCE_F32X3: the split-half weight layout -- IEEE half pairs in the forward copies, bfloat16 pairs in the transposed ones)
+    return vince_prepare_weights_batched(t->cf == VINCE_F32X3H ? VINCE_F32X3 : t->sdtype, (const vince_prep_entry*)dev_table, (int32_t)tab.size(), stream);
 }
 
 // fold constants inside a folded weight cache: scale[c] and bias[c] per BN channel (BN order, offset b.consts / 4), then
@@ -920,8 +921,11 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             dg.Co = cv.Ci;
             if (!gram_done)
                 RC(wgrad_launch(t, workspace, c.dtype, dg, at(workspace, in), at(workspace, in), (float*)at(workspace, b.gram), cv.Ci, 0, stream));
+            // (split-half mode: the cache holds hi / lo half pairs, the finalize reads conv3's fp32 master weights -- [Co][1][1][Ci], the
+            // same [Co][K] rows -- instead)
+            const void* w3 = t->cf == VINCE_F32X3H ? (const void*)params[cv.param] : (const void*)at((void*)wcache, cv.wk);
             RC(vince_bn_gram_finalize(c.dtype, (const float*)at(workspace, b.gram), (const double*)at(workspace, b.colsum), GRAM_R,
-                                      rows, at((void*)wcache, cv.wk), cv.Ci, cv.Co, params[bn.gamma], params[bn.beta],
+                                      rows, w3, cv.Ci, cv.Co, params[bn.gamma], params[bn.beta],
                                       bn_running[2 * bn.index], bn_running[2 * bn.index + 1], bn_nbt ? bn_nbt[bn.index] : nullptr,
                                       0.1f, 1e-5f, c.consts(bn, 0), c.consts(bn, 1), c.consts(bn, 2), c.consts(bn, 3), stream));
             vince_conv_epi e;

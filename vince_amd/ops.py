@@ -511,14 +511,18 @@ def jigsaw_nchw_to_rows(x, dtype):
     return out
 
 
-def prepare_weight(w_master, dtype, cip=None, want_transposed=True):
-    """w_master: float32 [Co][T][Ci] contiguous.  Returns (wk [Co][T][Cip], wt [Ci][T][Co] or None)."""
+def prepare_weight(w_master, dtype, cip=None, want_transposed=True, x3=False):
+    """w_master: float32 [Co][T][Ci] contiguous.  Returns (wk [Co][T][Cip], wt [Ci][T][Co] or None).
+    x3: the split-half weight layout of VINCE_F32X3 (float32-sized tensors holding hi / lo half pairs: wk IEEE half pairs for forward
+    launches, wt bfloat16 pairs for gradient launches) -- what conv_igemm(..., x3="h" / "b") takes as its weight operand."""
     require_gpu(w_master)
     Co, T, Ci = w_master.shape
     cip = Ci if cip is None else cip
+    if x3 and dtype != torch.float32:
+        raise TypeError("vince_amd: the split-half weight layout lives in float32-sized tensors")
     wk = torch.empty(Co, T, cip, device=w_master.device, dtype=dtype)
     wt = torch.empty(Ci, T, Co, device=w_master.device, dtype=dtype) if want_transposed else None
-    check(lib().vince_prepare_weight(dtype_code(wk), _ptr(w_master), _ptr(wk), _ptr(wt), Co, T, Ci, cip, stream_ptr()))
+    check(lib().vince_prepare_weight(VINCE_F32X3H if x3 else dtype_code(wk), _ptr(w_master), _ptr(wk), _ptr(wt), Co, T, Ci, cip, stream_ptr()))
     return wk, wt
 
 
