@@ -299,8 +299,11 @@ int vince_bn3_bwd_prepare(const float* R, const void* w_bf16, const double* gsum
                           int32_t wd_ld, void* nq, int32_t nq_ld, float* nr, float* dgamma, float* dbeta, void* stream);
 /* ... and the weight gradient, in place of R:  dW = diag(s) (R - c1 A^T - diag(c2 invstd) (W G - mean A^T)),  G = a^T a (float[K][K], the
  * Gram matrix the forward's statistics came from, vince_bn_gram_finalize), A = column sums of a (double[colsum_replicas][K]). */
-int vince_bn3_bwd_finish_dw(float* RdW, const void* w_bf16, const float* gram, const double* colsum, int32_t colsum_replicas,
+int vince_bn3_bwd_finish_dw(float* RdW, float* dw_accum, const void* w_bf16, const float* gram, const double* colsum, int32_t colsum_replicas,
                             const float* coef, const float* mean, const float* invstd, int32_t Co, int32_t K, void* stream);
+/* dw_accum NULL: in place (R becomes dW).  dw_accum non-NULL: R is left untouched and the finished gradient is ADDED into dw_accum -- R then
+ * lives in scratch and the gradient buffer keeps the accumulate-into contract of vince_conv_wgrad (gradient accumulation over several
+ * backward passes without zero_grad). */
 
 /* out = [relu]( y*scale + shift + (identity ? (id_scale ? identity*id_scale + id_shift : identity) : 0) ).
  * mask_out (optional): one byte per 16-byte chunk of `out` (8 bf16 / 4 f32 channels), bit e = pre-ReLU value e > 0 --

@@ -187,7 +187,7 @@ def _save_case(rank, world):
     d = os.path.join(tempfile.gettempdir(), "vince_save_case_%s" % os.environ["MASTER_PORT"])
     calls = []
     model = types.SimpleNamespace(save=lambda it, keep: calls.append((it, keep)))
-    stub = types.SimpleNamespace(model=model, iteration=512)
+    stub = types.SimpleNamespace(model=model, iteration=512, check_loss_latch=lambda: None)
     VinceSolver.save(stub, 5)
     return calls
 
@@ -201,7 +201,7 @@ def _final_save_case(rank, world):
     from vince_amd.solvers.vince_solver import VinceSolver
     calls = []
     model = types.SimpleNamespace(save=lambda it, keep: calls.append((it, keep)))
-    stub = types.SimpleNamespace(model=model, iteration=7)
+    stub = types.SimpleNamespace(model=model, iteration=7, check_loss_latch=lambda: None)
     t = torch.ones(4)
     if rank == 1:
         VinceSolver.save(stub)          # the failing rank's `finally`
@@ -220,3 +220,43 @@ def test_final_save_holds_no_collective():
 def test_only_rank_zero_writes_checkpoints():
     out = run2(_save_case)
     assert out[0] == [(512, 5)] and out[1] == []
+
+
+def _latched_save_case(rank, world):
+    """the periodic (sync) save reads the finite-loss latch BEFORE writing, and shares the verdict: a NaN seen on ONE rank must
+    raise on every rank -- none left waiting in the save's barrier -- and nothing is written."""
+    import torch
+    from vince_amd.solvers.vince_solver import VinceSolver
+    calls = []
+    model = types.SimpleNamespace(save=lambda it, keep: calls.append((it, keep)), device=torch.device("cpu"))
+
+    def latch():
+        if rank == 1:
+            raise AssertionError("non-finite loss in 1 iteration(s), first at iteration 3")
+    stub = types.SimpleNamespace(model=model, iteration=64, check_loss_latch=latch)
+    try:
+        VinceSolver.save(stub, 5, sync=True)
+        raised = None
+    except AssertionError as e:
+        raised = str(e)
+    return calls, raised
+
+
+def test_periodic_save_refuses_a_model_that_took_nan_steps_on_every_rank():
+    out = run2(_latched_save_case)
+    assert out[0][0] == [] and out[1][0] == []
+    assert out[0][1] is not None and "another rank" in out[0][1]
+    assert out[1][1] is not None and "first at iteration 3" in out[1][1]
+
+
+def _samples_case(rank, world):
+    from vince_amd.solvers.vince_solver import VinceSolver
+    stub = types.SimpleNamespace(args=types.SimpleNamespace(batch_size=16))
+    return VinceSolver.samples_per_step.fget(stub)
+
+
+def test_iteration_counts_the_samples_of_all_ranks():
+    """`iteration` counts SAMPLES (vince_solver.py:514, where batch_size is the batch of ALL GPUs behind
+    nn.DataParallel); with a per-rank batch of 16 on two ranks a step consumes 32 -- so a data-parallel run and a single process at the
+    same global batch agree on the sample counter, the epoch a checkpoint resumes into and the schedule position."""
+    assert run2(_samples_case) == {0: 32, 1: 32}

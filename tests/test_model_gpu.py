@@ -999,6 +999,35 @@ def test_bn3_backward_algebra_in_the_model_vs_separate_passes(monkeypatch):
             assert c_new > c_old - 0.05, (n, c_new, c_old)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32", "x3"])
+def test_two_backward_passes_without_zero_grad_accumulate(dtype):
+    """Gradient accumulation: a second forward + backward WITHOUT zero_grad must ADD its gradient to the buffer -- for the
+    bf16 trunk that includes the layer1 / layer2 bottlenecks whose conv3 / bn3 gradients come out of the BatchNorm-backward algebra
+    (the raw weight gradient R lives in scratch; csrc/bn_algebra.hip finish_dw adds the finished one).  Same batch twice: every
+    gradient doubles."""
+    _, model = build("ResNet50", 128, dtype, 11)
+    model.train()
+    x = vo.structured_frames(8, 96, 96, seed=79).to(DEV)
+    w = torch.randn(8, 128, generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def fwd_bwd():
+        for m in model.modules():            # same BatchNorm state for both passes is irrelevant in train mode (batch statistics)
+            pass
+        o = model.get_embeddings({"data": x})
+        (o["embeddings"] * w).sum().backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad()
+    g1 = fwd_bwd()
+    g2 = fwd_bwd()                           # no zero_grad in between
+    worst = max(float((g2[n] - 2 * g1[n]).norm()) / (float(g1[n].norm()) * 2 + 1e-30) for n in g1)
+    names = [n for n in g1 if ("layer1" in n or "layer2" in n) and ("conv3" in n or "bn3" in n)]
+    assert names
+    print("accumulated twice vs 2 x once (%s): worst relative L2 difference %.2e" % (dtype, worst))
+    # (not bit-exact: fp32 atomics of the split weight gradients and, in bf16, the rounding of re-summed activations' gradients)
+    assert worst < (2e-2 if dtype == "bf16" else 2e-4), worst
+
+
 def test_backward_with_a_deeper_dy_ring_and_the_old_wgrad_kernel_gives_the_same_gradients(monkeypatch):
     """Two engine switches that must not change results: `dy_slots` (how many layer gradients the backward pass keeps alive for the
     weight-gradient stream; 3 by default, up to 8) and `wgrad_tr=0` (bf16 weight gradients through the LDS-DMA kernel that

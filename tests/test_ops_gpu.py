@@ -985,7 +985,13 @@ def test_bn3_backward_algebra_vs_autograd(w, rows):
     dgam, dbet = torch.zeros(Co, device=DEV), torch.zeros(Co, device=DEV)
     mean32, invstd32 = mu.detach().float().to(DEV), invstd.detach().float().to(DEV)
     coef, w2, nr = ops.bn3_bwd_prepare(R.view(Co, w), Wb, gs, mean32, invstd32, gamma.to(DEV), rows, dgam, dbet)
-    ops.bn3_bwd_finish_dw(R.view(Co, w), Wb, gram.view(w, w), colsum, coef, mean32, invstd32)
+    # the accumulate-into form (what the engine uses: R stays scratch, the finished gradient is ADDED to a buffer that already holds one)
+    R0 = R.clone()
+    acc = torch.full((Co, w), 0.5, device=DEV)
+    ops.bn3_bwd_finish_dw(R.view(Co, w), Wb, gram.view(w, w), colsum, coef, mean32, invstd32, dw_accum=acc)
+    assert torch.equal(R, R0)
+    ops.bn3_bwd_finish_dw(R.view(Co, w), Wb, gram.view(w, w), colsum, coef, mean32, invstd32)       # in place
+    assert float((acc - 0.5 - R.view(Co, w)).abs().max()) <= 1e-6 * float(R.abs().max()) + 1e-7
 
     def relerr(x, ref):
         return float((x.double().cpu() - ref).abs().max() / ref.abs().max())

@@ -33,6 +33,8 @@ for name, t in (("params", solver.model._flat), ("queue", solver.vince_queue.vec
     print("rank %d %s max |replica - rank0| = %.3e (max |x| %.3e)" % (rank, name, diff, float(t.abs().max())), flush=True)
     bad = bad or diff != 0.0
 assert not bad
+# the sample counter counts every rank's samples (a single process at the global batch of world * 16 would show the same number)
+assert solver.samples_per_step == world * 16 and solver.iteration == 4 * world * 16, (solver.samples_per_step, solver.iteration)
 # 4 steps x world*16 keys: 128 rows written into K = 128 -> the tail sits at the end (it wraps on the next enqueue)
 assert solver.vince_queue.current_tail in (0, 128), solver.vince_queue.current_tail
 print("rank %d ok: losses %s, tail %d" % (rank, ["%.4f" % l for l in losses], solver.vince_queue.current_tail))

@@ -66,7 +66,7 @@ PROTOTYPES = {
                                                c_void_p, c_int32, c_void_p]),
     "vince_bn3_bwd_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                       c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "vince_bn3_bwd_finish_dw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+    "vince_bn3_bwd_finish_dw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                         c_void_p]),
     "vince_conv_expand_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_void_p, P(BnReduce),
                                         c_int32, c_void_p]),

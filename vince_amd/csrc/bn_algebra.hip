@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void bn3_derive_kernel(const bf16_t* __restric
 }
 
 // dW[c][k] = s (R - c1 A[k] - c2 invstd (sum_j W[c][j] G[j][k] - mean A[k])), one workgroup per channel c, thread k
-__global__ __launch_bounds__(128) void bn3_finish_dw_kernel(float* __restrict__ RdW, const bf16_t* __restrict__ W, const float* __restrict__ gram,
+// dw_accum != nullptr: R is read-only scratch and the finished gradient is ADDED into dw_accum (the accumulate-into contract of every other
+// weight gradient); nullptr: in place, R becomes dW
+__global__ __launch_bounds__(128) void bn3_finish_dw_kernel(float* __restrict__ RdW, float* __restrict__ dw_accum, const bf16_t* __restrict__ W, const float* __restrict__ gram,
                                                             const double* __restrict__ colsum, int colsum_replicas, const float* __restrict__ coef,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int Co, int K) {
     __shared__ float wrow[128];
@@ -113,7 +115,8 @@ __global__ __launch_bounds__(128) void bn3_finish_dw_kernel(float* __restrict__ 
     for (int j = 0; j < K; ++j) wg += (double)wrow[j] * (double)gram[(size_t)j * K + k];
     const double s = coef[c], c1 = coef[Co + c], c2 = coef[2 * Co + c];
     const double v = s * ((double)RdW[(size_t)c * K + k] - c1 * A - c2 * (double)invstd[c] * (wg - (double)mean[c] * A));
-    RdW[(size_t)c * K + k] = (float)v;
+    if (dw_accum) dw_accum[(size_t)c * K + k] += (float)v;
+    else RdW[(size_t)c * K + k] = (float)v;
 }
 
 }  // namespace
@@ -133,11 +136,11 @@ extern "C" int vince_bn3_bwd_prepare(const float* R, const void* w_bf16, const d
     return VINCE_OK;
 }
 
-extern "C" int vince_bn3_bwd_finish_dw(float* RdW, const void* w_bf16, const float* gram, const double* colsum, int32_t colsum_replicas,
+extern "C" int vince_bn3_bwd_finish_dw(float* RdW, float* dw_accum, const void* w_bf16, const float* gram, const double* colsum, int32_t colsum_replicas,
                                        const float* coef, const float* mean, const float* invstd, int32_t Co, int32_t K, void* stream) {
     VINCE_CHECK_ARG(RdW && w_bf16 && gram && colsum && coef && mean && invstd, VINCE_E_ARG, "vince_bn3_bwd_finish_dw: null pointer");
     VINCE_CHECK_ARG(Co > 0 && K > 0 && K <= 128 && colsum_replicas > 0, VINCE_E_SHAPE, "vince_bn3_bwd_finish_dw: K=%d (at most 128)", K);
-    hipLaunchKernelGGL(bn3_finish_dw_kernel, dim3(Co), dim3(128), 0, (hipStream_t)stream, RdW, (const bf16_t*)w_bf16, gram, colsum,
+    hipLaunchKernelGGL(bn3_finish_dw_kernel, dim3(Co), dim3(128), 0, (hipStream_t)stream, RdW, dw_accum, (const bf16_t*)w_bf16, gram, colsum,
                        colsum_replicas, coef, mean, invstd, Co, K);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;

@@ -28,7 +28,9 @@ struct ConvParams {
 
 }  // namespace vince_conv
 
-// conv_m8.hip: the 8-wavefront 256 x 256 core (bf16).  -1 = shape does not qualify, the caller keeps its own tiles.
+// conv_m8.hip: the 8-wavefront 256 x 256 core (bf16).  VINCE_M8_NOT_ELIGIBLE (positive: outside the ABI's error codes, which are <= 0)
+// = the shape does not qualify, the caller keeps its own tiles.
+#define VINCE_M8_NOT_ELIGIBLE 1
 int vince_conv_m8_launch(vince_conv::ConvParams& p, int mode, hipStream_t stream);
 // conv_igemm_x3.hip: the conv_igemm kernels instantiated for the split-half element types (dtype VINCE_F32X3H / VINCE_F32X3B)
 int vince_conv_igemm_x3_launch(vince_conv::ConvParams& p, int dtype, int mode, bool narrow, hipStream_t stream);

@@ -135,11 +135,11 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     static const int m8_on = vince_knob("m8", 1);
     static const int m8_min_k = vince_knob("m8_min_k", 1024);
     static const int m8_min_tiles = vince_knob("m8_min_tiles", 128);
-    rc = -1;
+    rc = VINCE_M8_NOT_ELIGIBLE;
     if (m8_on && !e.in2 && dtype == VINCE_BF16 && d.Co % 256 == 0 && T * d.Ci >= m8_min_k &&
         (long)((p.M + 255) / 256) * (d.Co / 256) >= m8_min_tiles)
         rc = vince_conv_m8_launch(p, join ? 2 : (bwd ? 1 : 0), s);
-    if (rc != -1) {
+    if (rc != VINCE_M8_NOT_ELIGIBLE) {
         if (tok) {
             vince_profile_set_tag(tok, VINCE_TAG_M8_FWD + (bwd ? 1 : 0));
             vince_profile_end_launch(tok, stream);

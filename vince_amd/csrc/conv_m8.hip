@@ -286,10 +286,10 @@ __global__ __launch_bounds__(512) void conv_m8_kernel(const ConvParams p) {
 // own tiles).  mode: 0 forward, 1 gradient epilogues, 2 forward residual join.
 int vince_conv_m8_launch(vince_conv::ConvParams& p, int mode, hipStream_t stream) {
     const vince_conv_desc& d = p.d;
-    if (!(p.in_bytes && p.w_bytes) || d.Cs != 0 || d.Ci % 64 != 0 || p.kt_per_split != 0) return -1;
+    if (!(p.in_bytes && p.w_bytes) || d.Cs != 0 || d.Ci % 64 != 0 || p.kt_per_split != 0) return VINCE_M8_NOT_ELIGIBLE;
     const int taps = d.TA * d.TB;
     p.kt_per_tap = d.Ci / 64;
-    if (p.kt_per_tap & (p.kt_per_tap - 1)) return -1;      // the per-tap walk wants a power of two (every ResNet layer)
+    if (p.kt_per_tap & (p.kt_per_tap - 1)) return VINCE_M8_NOT_ELIGIBLE;      // the per-tap walk wants a power of two (every ResNet layer)
     p.ktpt_mask = p.kt_per_tap - 1;
     p.log2_ktpt = 0;
     while ((1 << p.log2_ktpt) < p.kt_per_tap) ++p.log2_ktpt;

@@ -44,6 +44,7 @@ struct Blk {
     size_t x_in, y[3], a[2], yd, z, zmask;   // byte offsets in workspace (zmask: 1 byte per 16-B chunk of z)
     size_t gram, colsum;                      // Gram-statistics scratch of conv3's input (byte offsets; NONE: not eligible)
     size_t alg;                               // BatchNorm-backward algebra scratch (coef, wd, nq, nr: see alg_ptrs), beside gram
+    size_t algR;                              // ... and its raw weight gradient R (float[Co][K]), inside the off_algR region
 };
 
 constexpr size_t NONE = (size_t)-1;
@@ -71,6 +72,7 @@ struct vince_trunk {
     std::vector<int> bnC;
     size_t off_x0, off_ystem, off_amax, off_p0, off_stats, off_sums, off_consts, off_g[3], off_dy[NDY_MAX];
     size_t n_stats_doubles, n_consts_floats, max_act, ws_bytes, wc_bytes, off_prep_table;
+    size_t off_algR = 0, algR_bytes = 0;      // raw weight gradients of the BatchNorm-backward algebra (scratch, zeroed per backward)
     size_t off_gram = 0, gram_bytes = 0;      // Gram matrices + column sums of the eligible blocks (zeroed per forward)
     std::vector<vince_prep_entry> prep_table[2];   // last uploaded batched weight-prep descriptors (training / folded)
     void* prep_table_dev[2] = {nullptr, nullptr};
@@ -341,6 +343,14 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
             P.ws = align_up(P.ws + align_up(4 * co * sizeof(float)) + align_up(w * 2 * co * 2) + align_up(w * sizeof(float)));
         }
     }
+    // the raw weight gradients R = g^T a of the algebra blocks (float[Co][K] each, one contiguous region zeroed once per backward):
+    // scratch, so that the gradient buffer itself is only ever ADDED to (gradient accumulation without zero_grad stays correct)
+    t->off_algR = P.ws;
+    for (Blk& b : t->blocks) {
+        b.algR = NONE;
+        if (b.alg != NONE) { b.algR = P.ws; P.ws = align_up(P.ws + (size_t)b.c[2].Co * b.c[2].Ci * sizeof(float)); }
+    }
+    t->algR_bytes = P.ws - t->off_algR;
     for (int i = 0; i < 3; ++i) { t->off_g[i] = P.ws; P.ws = align_up(P.ws + t->max_act); }
     t->ndy = (int)vince_knob("dy_slots", 3);
     if (t->ndy < 3) t->ndy = 3;
@@ -977,6 +987,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     Ctx c{t, params, wcache, workspace, stream, t->sdtype};
     const int N = t->cfg.N;
     RC(vince_zero_async(at(workspace, t->off_sums), t->n_stats_doubles * sizeof(double), stream));
+    if (t->fwd_alg && t->algR_bytes) RC(vince_zero_async(at(workspace, t->off_algR), t->algR_bytes, stream));
     // Weight gradients run on a side stream: wgrad(layer) only needs dY(layer) and the saved activation, and nothing but
     // the optimiser needs its result, so it overlaps the BatchNorm-backward / dgrad chain of the layers below (compute-
     // bound MFMA work next to HBM-bound streams).  dY lives in a 3-slot ring; a slot is rewritten only after the wgrad
@@ -1096,15 +1107,17 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             const void* a_in = at(workspace, b.a[L - 1]);
             const void* wk = at((void*)wcache, cv.wk);
             const AlgPtrs ap = alg_ptrs(workspace, b);
-            // R = g^T a straight into the weight-gradient buffer (on this stream: the algebra below needs it before the dgrad)
+            // R = g^T a into this block's scratch (on this stream: the algebra below needs it before the dgrad); the finished weight
+            // gradient is then ADDED into the gradient buffer like every other one
+            float* const R = (float*)at(workspace, b.algR);
             {
                 const vince_conv_desc dw = fwd_desc(t, cv);
-                RC(wgrad_launch(t, workspace, t->cb, dw, a_in, Z, grads[cv.param], cv.Ci, 0, stream));
+                RC(wgrad_launch(t, workspace, t->cb, dw, a_in, Z, R, cv.Ci, 0, stream));
             }
-            RC(vince_bn3_bwd_prepare(grads[cv.param], wk, c.sums(bn), bn.R, c.consts(bn, 2), c.consts(bn, 3), params[bn.gamma], rows_out,
+            RC(vince_bn3_bwd_prepare(R, wk, c.sums(bn), bn.R, c.consts(bn, 2), c.consts(bn, 3), params[bn.gamma], rows_out,
                                      cv.Co, cv.Ci, ap.coef, ap.w2, 2 * cv.Co, (unsigned char*)ap.w2 + (size_t)cv.Co * 2, 2 * cv.Co, ap.nr,
                                      grads[bn.gamma], grads[bn.beta], stream));
-            RC(vince_bn3_bwd_finish_dw(grads[cv.param], wk, (const float*)at(workspace, b.gram), (const double*)at(workspace, b.colsum),
+            RC(vince_bn3_bwd_finish_dw(R, grads[cv.param], wk, (const float*)at(workspace, b.gram), (const double*)at(workspace, b.colsum),
                                        GRAM_R, ap.coef, c.consts(bn, 2), c.consts(bn, 3), cv.Co, cv.Ci, stream));
             // da = (W^T diag(s)) g + nq a + nr in ONE launch: the reduction runs over g's 4w channels (tap 0) and then over a's w
             // channels (tap 1 = vince_conv_epi.in2), with the fused reduction of the BatchNorm below as the plain dgrad has it

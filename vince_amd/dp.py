@@ -116,10 +116,23 @@ class GradientReducer:
         w = world()[0]
         if w == 1:
             return
-        for p in getattr(self, "extra", ()):
-            if p.grad is not None:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-                p.grad.div_(w)
+        extra = getattr(self, "extra", ())
+        if not extra:
+            return
+        # ONE collective per step over every extra parameter, whether or not this rank's batch gave it a gradient (a rank whose batch
+        # carried no labelled data contributes zeros): the collective sequence can then never differ between ranks
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in extra])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(w)
+        off = 0
+        for p in extra:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
 
     def reduce_after_backward(self):
         """Call right after loss.backward(): launches whatever the engine hook has not (the stem + layer1 bucket, final only when
@@ -131,19 +144,28 @@ class GradientReducer:
             return
         if self._hook_error is not None:
             err, self._hook_error = self._hook_error, None
+            self._launched.clear()      # (a failed step must not leave buckets marked as reduced for the next one)
             raise err
         cur = torch.cuda.current_stream()
         tail_event = torch.cuda.Event()
         tail_event.record(cur)
-        with torch.cuda.stream(self.comm_stream):
-            for e, (blk, a, b) in enumerate(self.plan):
-                if e in self._launched:
-                    continue
-                self.comm_stream.wait_event(tail_event)
-                self._reduce_bucket(a, b)
-            self.done.record(self.comm_stream)
-        self._launched.clear()
+        try:
+            with torch.cuda.stream(self.comm_stream):
+                for e, (blk, a, b) in enumerate(self.plan):
+                    if e in self._launched:
+                        continue
+                    self.comm_stream.wait_event(tail_event)
+                    self._reduce_bucket(a, b)
+                self.done.record(self.comm_stream)
+        finally:
+            self._launched.clear()
         cur.wait_event(self.done)
+
+    def begin_step(self):
+        """Call before loss.backward(): forgets bucket launches of a step whose backward raised before reduce_after_backward ran."""
+        if self.on_gpu:
+            self._launched.clear()
+            self._hook_error = None
 
 
 # ------------------------------------------------------------------------------------------------ keys

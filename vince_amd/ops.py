@@ -223,13 +223,14 @@ def bn3_bwd_prepare(R, w, gsums, mean, invstd, gamma, count, dgamma, dbeta):
     return coef, w2, nr
 
 
-def bn3_bwd_finish_dw(RdW, w, gram, colsum, coef, mean, invstd):
-    """vince_bn3_bwd_finish_dw: the raw weight gradient R becomes the weight gradient, in place."""
-    require_gpu(RdW, w, gram, colsum, coef, mean, invstd)
+def bn3_bwd_finish_dw(RdW, w, gram, colsum, coef, mean, invstd, dw_accum=None):
+    """vince_bn3_bwd_finish_dw: the raw weight gradient R becomes the weight gradient -- in place, or (dw_accum given) ADDED into
+    dw_accum with R left untouched."""
+    require_gpu(RdW, w, gram, colsum, coef, mean, invstd, dw_accum)
     Co, K = w.shape[0], w.shape[-1]
-    check(lib().vince_bn3_bwd_finish_dw(_ptr(RdW), _ptr(w), _ptr(gram), _ptr(colsum), colsum.shape[0], _ptr(coef), _ptr(mean),
+    check(lib().vince_bn3_bwd_finish_dw(_ptr(RdW), _ptr(dw_accum), _ptr(w), _ptr(gram), _ptr(colsum), colsum.shape[0], _ptr(coef), _ptr(mean),
                                         _ptr(invstd), Co, K, stream_ptr()))
-    return RdW
+    return RdW if dw_accum is None else dw_accum
 
 
 def conv_wgrad(desc, x, dy, dw, ci_dw=None, variant=0, x3=None):

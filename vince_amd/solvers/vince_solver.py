@@ -78,6 +78,13 @@ class VinceSolver(BaseSolver):
     def iterations_per_epoch(self):
         return self.args.iterations_per_epoch
 
+    @property
+    def samples_per_step(self):
+        """Samples one training step consumes over the whole job: args.batch_size is the PER-RANK batch here, the reference's is the
+        batch nn.DataParallel splits over its GPUs (models/vince_model.py:35) -- so a data-parallel run and a single process at the same
+        global batch agree on `iteration`, on the epoch a checkpoint resumes into and on the schedule position."""
+        return int(self.args.batch_size) * dp.world()[0]
+
     def setup_other(self):
         pass   # CIFAR kNN data (vince_solver.py:236-250) is an eval-only extra
 
@@ -135,7 +142,9 @@ class VinceSolver(BaseSolver):
                                         keep_images=getattr(args, "keep_queue_images", False))
         if w > 1:
             torch.distributed.broadcast(self.vince_queue.vector_queue, src=0)
-        samples_per_epoch = self.args.iterations_per_epoch * self.args.batch_size
+        # `iteration` counts SAMPLES of the whole job (vince_solver.py:514 with the reference's batch_size = the batch of all GPUs
+        # behind nn.DataParallel): under data parallelism every step consumes world x the per-rank batch
+        samples_per_epoch = self.args.iterations_per_epoch * self.samples_per_step
         self.epoch = self.iteration // samples_per_epoch
         if self.iteration:
             print("Resuming epoch", self.epoch)
@@ -207,6 +216,7 @@ class VinceSolver(BaseSolver):
                 "num_frames": num_frames, "batch_type": "images", "batch_size": data.shape[0]}
 
     def reset_epoch(self):
+        self.check_loss_latch()    # (once per epoch: the loaders' epoch boundary synchronises anyway)
         super().reset_epoch()
         self.queue_model.train()   # the key encoder never leaves train mode (vince_solver.py:337)
         self.drawn_this_epoch = False
@@ -282,6 +292,21 @@ class VinceSolver(BaseSolver):
         that only SOME ranks took -- is no collective at all: a rank that failed must not enter a barrier its peers answer with a
         gradient all-reduce."""
         w, r = dp.world()
+        # The reference asserts a finite loss BEFORE every backward (vince_solver.py:446), so what it saves is always finite; here the
+        # check is a device-side latch, read now: a model that has taken NaN steps is not written (and old checkpoints are not pruned).
+        # Under sync every rank reaches this point, so the verdict is shared first -- one rank raising alone would strand its peers.
+        bad = None
+        try:
+            self.check_loss_latch()
+        except AssertionError as e:
+            bad = e
+        if w > 1 and sync:
+            flag = torch.tensor([1.0 if bad is not None else 0.0], device=self.model.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if bad is None and float(flag) > 0:
+                bad = AssertionError("non-finite loss on another rank")
+        if bad is not None:
+            raise bad
         if r == 0:
             self.model.save(self.iteration, num_to_keep)
         if w > 1 and sync:
@@ -380,11 +405,14 @@ class VinceSolver(BaseSolver):
         terms = list(loss_dict.values())
         loss = terms[0] if len(terms) == 1 else torch.stack([t.reshape(()) for t in terms]).sum()
         # every iteration, without a host sync: a NaN / inf loss latches the step index on the device (ops.nonfinite_latch); the
-        # latch is read wherever the host synchronises anyway (log iterations, save, end of epoch) and raises there
+        # latch is read wherever the host synchronises anyway -- log iterations, every save() before it writes, the start of each
+        # epoch -- and raises there
         self._watch_loss(loss)
 
         lap("metrics_time")
         self.optimizer.zero_grad()
+        if self.reducer is not None:
+            self.reducer.begin_step()
         loss.backward()
         if self.reducer is not None:
             self.reducer.reduce_after_backward()
@@ -399,9 +427,6 @@ class VinceSolver(BaseSolver):
         self.queue_model.vince_update(self.model)
 
         step_no = self.logger_iteration
-        if step_no % self.args.save_frequency == 0:
-            self.save(5, sync=True)
-
         if step_no % self.args.log_frequency == 0:
             # the only host synchronisation of the step: scalar read-back for the meters (the reference's
             # assert torch.isfinite(loss), vince_solver.py:446, synchronises every step)
@@ -421,7 +446,10 @@ class VinceSolver(BaseSolver):
                 record.update({"metrics/%s/%s" % (tag, k): self.metric_meters[k].val for k in metrics})
                 self.train_logger.dict_log(record, self.iteration)
 
-        self.iteration += int(self.args.batch_size)       # the reference counts SAMPLES (vince_solver.py:514)
+        if step_no % self.args.save_frequency == 0:
+            self.save(5, sync=True)     # (checks the finite-loss latch first: a NaN model is never checkpointed)
+
+        self.iteration += self.samples_per_step       # the reference counts SAMPLES (vince_solver.py:514); all ranks' samples under DP
         self.time_meters["total_time"].update(time.time() - began)
         self.logger_iteration += 1
         return loss_dict, metrics
