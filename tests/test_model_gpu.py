@@ -371,6 +371,68 @@ def test_g11_centred_head_vs_reference_golden(dtype):
         assert e_loss < b["loss"] and e_emb < b["emb"] and cos > b["cos"]
 
 
+# ------------------------------------------------------------------------------------------ G13: config 5 at its own size
+@pytest.mark.parametrize("coin", ["k", "q"])
+@pytest.mark.parametrize("dtype", ["fp32", "x3", "bf16"])
+def test_g13_config5_multiframe_jigsaw_vs_reference_golden(dtype, coin):
+    """G13 (oracle/make_golden_g13.py): BASELINE config 5's per-GPU work at ITS OWN size against the imported
+    reference -- ResNet-50, 224 x 224, 4 frames per clip (8 clips), inter-batch + self-batch comparison, D=128, T=0.2 / self-T 0.03,
+    K=65536, jigsaw head (the jigsawed side padded to 225 -> 9 tiles of 75 x 75 per frame, models/vince_model.py:144-171), ONE full
+    iteration per coin outcome (solvers/vince_solver.py:397-403: "k" = key side jigsawed, "q" = query side, whose backward then runs
+    through the jigsaw head and the 9x batch); the reference's per-sample tile orders are inputs.  fp32 / x3: loss terms, both sides'
+    embeddings and pre-norm features, metrics at the north-star bar; every gradient's sum |g| and sampled head rows.  bf16: reported."""
+    from vince_amd.models.vince_model import VinceQueueModel
+    g = load("g13_config5.npz")
+    c = vo.G13
+    args, model = build(c["arch"], c["embed"], dtype, c["seed"], jigsaw=True, batch_size=c["B"], num_frames=c["F"], vince_queue_size=c["K"],
+                        vince_temperature=c["T"], vince_self_temperature=c["self_T"], base_lr=c["lr"], inter_batch_comparison=True,
+                        self_batch_comparison=True, input_size=(c["hw"], c["hw"]))
+    model.train()
+    qm = VinceQueueModel(args, model)
+    qm.to(DEV)
+    qm.train()
+    queue = vo.g13_queue().to(DEV)
+    data, qdata = vo.g13_inputs()
+    p = coin + "_"
+    orders = torch.from_numpy(g[p + "orders"]).to(DEV)
+    batch = {"data": data.to(DEV), "queue_data": qdata.to(DEV), "batch_types": ["images"], "batch_sizes": [c["B"]], "data_source": ["XX"],
+             "num_frames": [c["F"]], ("queue_jigsaw_orders" if coin == "k" else "jigsaw_orders"): orders}
+    qb = qm(batch, jigsaw=(coin == "k"), shuffle=True)
+    o = model.get_embeddings(batch, jigsaw=(coin == "q"), shuffle=True)[0]
+    o.update({"queue_vectors": queue, "queue_images": None, "queue_data_sources": None})
+    o.update(model.split_dict_by_type(batch["batch_types"], batch["batch_sizes"], batch)[0])
+    o.update(qb[0])
+    o.update(model(o))
+    ld = model.loss(o)
+    met = model.get_metrics(o)
+    model.zero_grad()
+    sum(w * v for w, v in ld.values()).backward()
+    torch.cuda.synchronize()
+    assert sorted(ld) == list(g[p + "loss_names"]) and sorted(met) == list(g[p + "metric_names"])
+    terms = np.array([float(ld[k][0] * ld[k][1]) for k in sorted(ld)])
+    e_terms = float(np.abs(terms / g[p + "loss_terms"] - 1).max())
+    errs = {k: rel(o[k].detach().float().cpu(), g[p + k]) for k in ("embeddings", "prenorm_features", "extracted_features")}
+    errs.update({"queue_" + k: rel(qb[0]["queue_" + k].float().cpu(), g[p + "queue_" + k]) for k in ("embeddings", "prenorm_features")})
+    named = dict(model.named_parameters())
+    names = list(g[p + "grad_names"])
+    ratios = {n: abs(vo.tensor_checksum(named[n].grad.detach().float().cpu())[2] / g[p + "grad_checksums"][names.index(n)][2] - 1.0)
+              for n in names if named[n].grad is not None}
+    assert set(n for n in names) == set(n for n, q in named.items() if q.grad is not None)
+    print("G13 coin %s, %s trunk: loss terms rel %.3e  %s  sum|g| rel err median %.2e worst %.2e (%s)"
+          % (coin, dtype, e_terms, "  ".join("%s %.2e" % kv for kv in errs.items()), float(np.median(list(ratios.values()))),
+             max(ratios.values()), max(ratios, key=ratios.get)))
+    if dtype == "bf16":
+        assert np.isfinite(e_terms) and e_terms < 0.2     # reported (DESIGN.md section 3)
+        return
+    assert e_terms < 1e-3 and max(errs.values()) < 1e-3, (e_terms, errs)
+    np.testing.assert_allclose([float(met[k]) for k in sorted(met)], g[p + "metrics"], rtol=2e-3, atol=2e-4)
+    head = "jigsaw_embedding.2.weight" if coin == "q" else "embedding.2.weight"
+    assert rel(named[head].grad[:8].cpu(), g[p + "grad_" + head]) < 5e-3
+    early = ("feature_extractor.model.conv1", "feature_extractor.model.bn1", "feature_extractor.model.layer1")
+    bad = [(n, v) for n, v in ratios.items() if not v < (5e-2 if n.startswith(early) else 2e-2)]
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_g11_after_twenty_sgd_steps_vs_oracle(dtype):
     """The state after 20 SGD iterations of G11's recipe, reached by replaying them with the CPU oracle (pinned to the reference's

@@ -245,3 +245,44 @@ def test_g11_twenty_sgd_steps_trajectory():
     e, ge = r["embeddings"].numpy(), g["embeddings"]
     assert float((e * ge).sum(1).min()) > 0.99
     np.testing.assert_allclose(r["cosine_sim"], traj[20, 2], atol=3e-2)
+
+
+@pytest.mark.parametrize("coin", ["k", "q"])
+def test_g13_config5_multiframe_jigsaw_iteration(coin):
+    """G13 (oracle/make_golden_g13.py): ONE iteration of the imported reference at BASELINE config 5's own size -- ResNet-50, 224 x 224,
+    8 clips x 4 frames, inter-batch + self-batch comparison, jigsaw head (the jigsawed side padded to 225 -> 9 tiles of 75 x 75) -- per
+    coin outcome; the oracle replays it with the recorded per-sample tile orders: both loss terms, embeddings of both sides, head gradient."""
+    g = load("g13_config5.npz")
+    c = vo.G13
+    tr = vo.OracleTrainer(c["arch"], c["embed"], c["K"], c["B"], c["T"], c["lr"], inter_batch=True, num_frames=c["F"], self_batch=True,
+                          self_temperature=c["self_T"], seed=c["seed"], jigsaw=True, queue_init=vo.g13_queue().numpy())
+    data, qdata = vo.g13_inputs()
+    p = coin + "_"
+    orders = torch.from_numpy(g[p + "orders"])
+    r = tr.step(data, qdata, jig_key=(coin == "k"), jig_query=(coin == "q"), orders_key=orders if coin == "k" else None,
+                orders_query=orders if coin == "q" else None)
+    terms = dict(zip(g[p + "loss_names"], g[p + "loss_terms"]))
+    np.testing.assert_allclose(r["nce_loss"], terms["nce_loss"], rtol=1e-4)
+    np.testing.assert_allclose(r["nce_loss_self"], terms["nce_loss_self"], rtol=1e-4)
+    np.testing.assert_allclose(r["embeddings"].numpy(), g[p + "embeddings"], atol=2e-4)
+    np.testing.assert_allclose(r["queue_embeddings"].numpy(), g[p + "queue_embeddings"], atol=2e-4)
+    head = "jigsaw_embedding.2.weight" if coin == "q" else "embedding.2.weight"
+    np.testing.assert_allclose(r["grads"][head][:8].numpy(), g[p + "grad_" + head], rtol=5e-2, atol=1e-5)
+    names = list(g[p + "grad_names"])
+    for n in (head, "feature_extractor.model.layer4.2.conv3.weight"):
+        want = g[p + "grad_checksums"][names.index(n)]
+        assert abs(vo.tensor_checksum(r["grads"][n])[2] - want[2]) <= 2e-2 * abs(want[2]), n
+
+
+def test_g12_fixture_is_the_centred_head_state_at_config3_size():
+    """G12 (oracle/make_golden_g12.py: config 3 at its real size from the centred-head state; 2.5 minutes and 40 GB of host memory for the
+    reference, so the CPU suite only checks the fixture's shape and that it IS a spread-out state -- the GPU tests hold the HIP path
+    against it): 256 unit embeddings of width 128, mean pairwise cosine far from the collapsed 0.98, every gradient tensor recorded."""
+    g = load("g12_full_centred.npz")
+    assert g["embeddings"].shape == (256, 128) and g["queue_embeddings"].shape == (256, 128) and g["shift"].shape == (128,)
+    np.testing.assert_allclose(np.linalg.norm(g["embeddings"], axis=1), 1.0, atol=1e-5)
+    e = g["embeddings"].astype(np.float64)
+    pair = ((e @ e.T).sum() - 256) / (256 * 255)
+    np.testing.assert_allclose(pair, float(g["pairwise_cosine"]), atol=1e-5)
+    assert pair < 0.3 and 0.5 < float(g["m_nce_accuracy_mean"]) <= 1.0
+    assert len(g["grad_names"]) == 163 == len(g["grad_checksums"])
