@@ -136,14 +136,16 @@ def workload_label(opt, world):
 
 
 def measure_copy_ceiling(L, device, nbytes=1 << 30):
-    """TB/s (read + write) of the library's own 16-byte-per-lane copy kernel on this box: the rate an element-wise pass can be
-    held against (`roofline.hbm_achievable`).  Best of a few grid sizes, nt and plain."""
+    """TB/s (read + write) of the library's own copy kernel on this box: the rate an element-wise pass can be held against
+    (`roofline.hbm_achievable`).  Best of the copy's shapes (grid-stride 16 B per lane / 32 B per lane / block-contiguous segments:
+    the last one with nt loads and stores is the one that reaches the guide's 6.3 TB/s on a 256 MiB buffer, tools/ceilings.py), nt and
+    plain, two grid sizes."""
     src = torch.empty(nbytes, dtype=torch.uint8, device=device).random_(0, 255)
     dst = torch.empty_like(src)
     st = torch.cuda.current_stream().cuda_stream
     best = (0.0, None)
-    for nt in (1, 0):
-        for blocks in (4096, 16384):
+    for nt in (5, 4, 1, 0, 2):          # bit 0 = nt; bits 1-2 = shape (vince_stream_copy)
+        for blocks in (8192, 16384):
             for _ in range(2):
                 L.vince_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, blocks, nt, st)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -154,7 +156,8 @@ def measure_copy_ceiling(L, device, nbytes=1 << 30):
             torch.cuda.synchronize()
             r = 2.0 * nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e12
             if r > best[0]:
-                best = (r, "vince_stream_copy, 1 GiB, %d blocks, %s" % (blocks, "nt" if nt else "plain"))
+                best = (r, "vince_stream_copy, 1 GiB, %d blocks, %s, %s" % (blocks, ("grid-stride", "32 B per lane", "block-contiguous")[nt >> 1],
+                                                                            "nt" if nt & 1 else "plain"))
     del src, dst
     return best
 

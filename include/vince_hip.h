@@ -64,7 +64,9 @@ int vince_set_side_streams(int32_t n);
 int vince_profile_collect(int32_t ntags, double* ms, double* flops, int64_t* count);
 /* Calibration aid (bench.py `roofline.hbm_achievable`, tools/ceilings.py): copies `bytes` (multiple of 16) with a plain
  * 16-byte-per-lane grid-stride kernel of `blocks` workgroups (<= 0: 2048) -- the HBM streaming rate this box gives an
- * element-wise pass, measured with the library's own code instead of a framework copy.  nontemporal != 0: `nt` loads and stores. */
+ * element-wise pass, measured with the library's own code instead of a framework copy.  nontemporal: bit 0 = `nt` loads and stores;
+ * bits 1-2 = the copy's shape (0: grid-stride, 16 bytes per lane; 1: 32 bytes per lane; 2: block-contiguous segments) -- the shapes
+ * tried against the guide's 6.29 TB/s, tools/ceilings.py. */
 int vince_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks, int32_t nontemporal, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

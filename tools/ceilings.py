@@ -43,7 +43,7 @@ L = _lib.lib()
 for nbytes in (256 << 20, 1 << 30, 2 << 30):
     s = src[:nbytes]
     d = dst[:nbytes]
-    for nt in (0, 1):
+    for nt in (0, 1, 2, 3, 4, 5):     # bit 0: nt loads / stores; bits 1-2: 0 grid-stride 16 B per lane, 1 = 32 B per lane, 2 = block-contiguous
         best = None
         for blocks in (1024, 2048, 4096, 8192, 16384):
             st = torch.cuda.current_stream().cuda_stream
@@ -51,5 +51,5 @@ for nbytes in (256 << 20, 1 << 30, 2 << 30):
             r = 2.0 * nbytes / t / 1e12
             if best is None or r > best[0]:
                 best = (r, blocks)
-            print("vince_stream_copy %4d MiB nt=%d blocks=%5d: %.2f TB/s read+write" % (nbytes >> 20, nt, blocks, r))
-        print("  best %d MiB nt=%d: %.2f TB/s at %d blocks" % (nbytes >> 20, nt, best[0], best[1]))
+            print("vince_stream_copy %4d MiB shape=%d nt=%d blocks=%5d: %.2f TB/s read+write" % (nbytes >> 20, nt >> 1, nt & 1, blocks, r))
+        print("  best %d MiB shape=%d nt=%d: %.2f TB/s at %d blocks" % (nbytes >> 20, nt >> 1, nt & 1, best[0], best[1]))

@@ -683,6 +683,35 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4_t* __restr
     }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
+// Two other shapes of the same copy, tried once against the guide's 6.29 TB/s (MI355X_MICROARCH.md:35):
+// SHAPE 1: 32 bytes per lane -- a lane moves two ADJACENT 16-byte pieces, a wavefront instruction pair covers 2 KB contiguous;
+// SHAPE 2: block-contiguous -- a workgroup owns one contiguous segment of the buffer and walks it in 4 KB steps (no grid stride).
+template <int SHAPE, bool NT>
+__global__ __launch_bounds__(256) void stream_copy_shape_kernel(const f32x4_t* __restrict__ src, f32x4_t* __restrict__ dst, size_t n16) {
+    auto ld = [&](size_t k) { return NT ? __builtin_nontemporal_load(src + k) : src[k]; };
+    auto st = [&](size_t k, f32x4_t v) { if (NT) __builtin_nontemporal_store(v, dst + k); else dst[k] = v; };
+    if constexpr (SHAPE == 1) {
+        const size_t stride = (size_t)gridDim.x * 512;     // 16-byte pieces per grid pass
+        for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2; i + 1 < n16; i += 2 * stride) {
+            const bool two = i + stride + 1 < n16;
+            const f32x4_t a0 = ld(i), a1 = ld(i + 1);
+            f32x4_t b0, b1;
+            if (two) { b0 = ld(i + stride); b1 = ld(i + stride + 1); }
+            st(i, a0); st(i + 1, a1);
+            if (two) { st(i + stride, b0); st(i + stride + 1, b1); }
+        }
+    } else {
+        const size_t per = ((n16 + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+        const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n16 ? b0 + per : n16;
+        for (size_t i = b0 + threadIdx.x; i < b1; i += 1024) {
+            f32x4_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i + u * 256 < b1) v[u] = ld(i + u * 256);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i + u * 256 < b1) st(i + u * 256, v[u]);
+        }
+    }
+}
 }  // namespace
 
 extern "C" int vince_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks, int32_t nontemporal, void* stream) {
@@ -691,6 +720,19 @@ extern "C" int vince_stream_copy(void* dst, const void* src, size_t bytes, int32
     if (bytes == 0) return VINCE_OK;
     const size_t n16 = bytes / 16;
     if (blocks <= 0) blocks = 2048;
+    // nontemporal: bit 0 = nt loads / stores; bits 1-2 = copy shape (0 the grid-stride copy above, 1 = 32 bytes per lane, 2 = block-contiguous)
+    const int shape = (nontemporal >> 1) & 3;
+    nontemporal &= 1;
+    if (shape == 1 || shape == 2) {
+        const dim3 g((unsigned)blocks), b(256);
+        hipStream_t s = (hipStream_t)stream;
+        if (shape == 1 && nontemporal) hipLaunchKernelGGL((stream_copy_shape_kernel<1, true>), g, b, 0, s, (const f32x4_t*)src, (f32x4_t*)dst, n16);
+        else if (shape == 1) hipLaunchKernelGGL((stream_copy_shape_kernel<1, false>), g, b, 0, s, (const f32x4_t*)src, (f32x4_t*)dst, n16);
+        else if (nontemporal) hipLaunchKernelGGL((stream_copy_shape_kernel<2, true>), g, b, 0, s, (const f32x4_t*)src, (f32x4_t*)dst, n16);
+        else hipLaunchKernelGGL((stream_copy_shape_kernel<2, false>), g, b, 0, s, (const f32x4_t*)src, (f32x4_t*)dst, n16);
+        VINCE_CHECK_LAUNCH();
+        return VINCE_OK;
+    }
     if (nontemporal)
         hipLaunchKernelGGL((stream_copy_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            (const f32x4_t*)src, (f32x4_t*)dst, n16);
