@@ -183,8 +183,11 @@ struct SmemD {
     static constexpr int KB = KC * 16;                       // bytes of K per row per stage
     static constexpr int XB = PTL * KB, WB = CT * KB, STAGE = XB + WB;
     static constexpr int MAIN = STAGES * STAGE;
-    static constexpr int CRS = CT * (int)sizeof(T) + 16;
-    static constexpr int EPI = PTL * CRS + 4 * CT * 2 * 4;
+    // the split-half types leave through the epilogue in two 64-channel passes (ECT): an fp32 tile of 128 x 128 outputs would hold the
+    // kernel to two workgroups per CU by its LDS alone
+    static constexpr int ECT = (X3<T>::on && CT == 128) ? 64 : CT;
+    static constexpr int CRS = ECT * (int)sizeof(T) + 16;
+    static constexpr int EPI = PTL * CRS + 4 * ECT * 2 * 4;
     static constexpr int BYTES0 = MAIN > EPI ? MAIN : EPI;
 };
 
@@ -505,6 +508,15 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
         return;
     }
     x3_unscale<T>(acc);
+    if constexpr (S::ECT != CT) {
+        // two passes of CT / 2 channels each through the (half-size) epilogue tile; WN = 1: a wavefront's accumulators split by index
+        static_assert(WN == 1 && CT == 2 * S::ECT, "the two-pass epilogue is written for WN = 1");
+        constexpr int HJ = CJ / 2;
+        conv_epilogue<T, S::ECT, S::CRS, MODE, PTL, 4, 256, WN>(p, smem, *(f32x16_t (*)[HJ][PI])&acc[0], tile, p0, c0, tid, lane, wave, wp, wc);
+        __syncthreads();
+        conv_epilogue<T, S::ECT, S::CRS, MODE, PTL, 4, 256, WN>(p, smem, *(f32x16_t (*)[HJ][PI])&acc[HJ], tile, p0, c0 + S::ECT, tid, lane, wave, wp, wc);
+        return;
+    }
     // rows in flight per thread in the epilogue: the 128-VGPR (4 workgroups/CU) configuration has no room for more than 2
     conv_epilogue<T, CT, S::CRS, MODE, PTL, (MINW >= 4 ? 2 : 4), 256, WN>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
@@ -663,7 +675,9 @@ int launch_x3(ConvParams& p, hipStream_t stream) {
         static const int x3_cfg = vince_knob("x3_cfg", 1);
         static const int x3_s3_min_k = vince_knob("x3_s3_min_k", 2048);
         p.nkt = p.total_chunks / 4;     // 64-byte K rows
-        if (x3_cfg == 1 && cpt % 8 == 0 && p.total_chunks % 8 == 0) {
+        // (reductions of at most 128 elements -- the 1x1 expand convolutions of layer1 / layer2, pure HBM streams -- do better with the
+        // 64-byte rows' three to four workgroups per CU: 255 -> 213 us and 161 -> 144 us at N = 256)
+        if (x3_cfg == 1 && cpt % 8 == 0 && p.total_chunks % 8 == 0 && k_elems > 128) {
             p.nkt = p.total_chunks / 8;
             hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 2, 2, PT, MODE, false, 1>), grid, dim3(256), 0, stream, p);
         } else if (k_elems >= x3_s3_min_k) {

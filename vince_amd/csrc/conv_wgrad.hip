@@ -599,6 +599,14 @@ int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t
     // the workgroups hide twice the latency (192 -> 134 us timed alone; every other shape is best at 512)
     int target = target_blocks;
     if (d.TA * d.TB > 1 && (long)d.Co * ntot <= 65536) target *= 2;
+    if (x3k) {
+        // the split-half kernel is bound by its in-register splits, not by atomics: multi-tap layers take twice the workgroups
+        // (measured alone at N = 256: 3x3 layers 431 / 306 / 292 / 267 us at 512 -> 398 / 248 / 267 / 237 at 1024; the 1x1 layers are
+        // best at 512: 105-122 against 115-134)
+        static const int x3_blocks = (int)vince_knob("x3_wgrad_blocks", 0);
+        const int base = x3_blocks > 0 ? x3_blocks : (d.TA * d.TB > 1 ? 1024 : 512);
+        target = base * ((d.TA * d.TB > 1 && (long)d.Co * ntot <= 65536) ? 2 : 1);
+    }
     int splits = (target + tiles - 1) / tiles;
     const int max_splits = (p.nkt_total * kp / 64 + 7) / 8;   // at least 512 pixels per split
     if (splits > max_splits) splits = max_splits;

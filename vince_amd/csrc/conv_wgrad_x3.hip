@@ -234,6 +234,12 @@ void wgrad_x3_tile(const WgradParams& p, int* ct, int* nt) {
     if (!(p.in_bytes && p.dy_bytes) || p.variant != 0 || d.Cs != 0 || d.Co % 64 || d.Ci % 64 || p.Ci_dw != d.Ci) return;
     if (d.Ho * d.Wo < 2 || d.Wo < 2) return;                       // fdiv wants divisors >= 2
     if ((unsigned long long)p.M * d.Co * 4 + (1u << 20) >= 0x7ff00000ull) return;
+    static const long forced = vince_knob("x3_wgrad_tile", 0);   // cross-check / measurement switch: ct * 1000 + nt (64 / 128 each)
+    if (forced) {
+        *ct = (int)(forced / 1000);
+        *nt = (int)(forced % 1000);
+        if ((*ct == 64 || *ct == 128) && (*nt == 64 || *nt == 128) && d.Co % *ct == 0 && ntot % *nt == 0) return;
+    }
     *ct = d.Co % 128 ? 64 : 128;
     *nt = ntot % 128 ? 64 : 128;
 }
