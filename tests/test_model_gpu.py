@@ -417,7 +417,11 @@ def test_g13_config5_multiframe_jigsaw_vs_reference_golden(dtype, coin):
     names = list(g[p + "grad_names"])
     ratios = {n: abs(vo.tensor_checksum(named[n].grad.detach().float().cpu())[2] / g[p + "grad_checksums"][names.index(n)][2] - 1.0)
               for n in names if named[n].grad is not None}
-    assert set(n for n in names) == set(n for n, q in named.items() if q.grad is not None)
+    # the head the step did not touch: no gradient in the reference's fresh model; here its (flat-buffer) gradient exists and is zero
+    for n, q in named.items():
+        if q.grad is not None and n not in names:
+            assert float(q.grad.abs().max()) == 0.0, n
+    assert all(named[n].grad is not None for n in names)
     print("G13 coin %s, %s trunk: loss terms rel %.3e  %s  sum|g| rel err median %.2e worst %.2e (%s)"
           % (coin, dtype, e_terms, "  ".join("%s %.2e" % kv for kv in errs.items()), float(np.median(list(ratios.values()))),
              max(ratios.values()), max(ratios, key=ratios.get)))
