@@ -194,6 +194,12 @@ int vince_conv_expand_stats(int dtype, const void* x, const void* w, int64_t row
  * (dh + 1) * 3 + (dw + 1) (null: identity = the forward convolution).  H must be a multiple of 4. */
 int vince_conv3x3_strip(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                         const int32_t* tap_map, void* out, double* stats, int32_t replicas, void* stream);
+/* The INPUT GRADIENT of that layer through the same kernel (autograd of resnet.py:119-121 under loss.backward()): dx [N][H][56][64] =
+ * conv3x3(dy, wt with the taps flipped), wt = the prepared [Ci][tap][Co] copy, with vince_conv_igemm's fused BatchNorm-backward reduction
+ * of the BatchNorm + ReLU below (bnred with mask_scale / mask_shift, no mask bits; may be NULL): bnred->sums += (sum g, sum g * xhat) of
+ * the STORED gradient, g gated by the sign of y * mask_scale + mask_shift. */
+int vince_conv3x3_strip_dgrad(int dtype, const void* dy, const void* wt, int32_t N, int32_t H, int32_t W, int32_t C, void* dx,
+                              const vince_bn_reduce* bnred, int32_t replicas, void* stream);
 
 /* And for the block-input gradient of a bottleneck (the input gradient of its conv1 = an expand-shaped 1x1 again: dx [rows][Co]
  * from dy [rows][K] and W^T [Co][K], bf16, K = 64 / 128, Co multiple of 256) with vince_conv_igemm's gradient epilogues:

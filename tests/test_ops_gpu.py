@@ -833,6 +833,45 @@ def test_conv3x3_image_strip_kernel(N, H):
     assert_close(out.permute(0, 3, 1, 2), wantf, torch.bfloat16, bf16=1e-2, what="strip conv, flipped taps")
 
 
+@pytest.mark.parametrize("N,H", [(3, 56), (5, 8)])
+def test_conv3x3_image_strip_kernel_input_gradient_with_fused_bn_reduction(N, H):
+    """vince_conv3x3_strip_dgrad (layer1's 3x3 input gradient through the image-strip kernel, taps flipped over the [Ci][tap][Co] weight
+    copy): dx equal to vince_conv_igemm's input-gradient launch up to summation order, the fused BatchNorm-backward sums (sum g, sum g * xhat of the
+    stored gradient, gated by the sign of y * scale + shift) equal to that launch's epilogue and to the stand-alone reduction, and dx
+    against torch autograd on the CPU."""
+    ops = _ops()
+    x = rnd(N, 64, H, 56, seed=51).requires_grad_(True)
+    w = (rnd(64, 64, 3, 3, seed=52) * (2.0 / 576) ** 0.5).bfloat16().float().requires_grad_(True)
+    dy = (rnd(N, 64, H, 56, seed=53) * 0.1).bfloat16().float()
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    _, wt = weights_krsc(w.detach(), torch.bfloat16)
+    dyg = to_nhwc(dy, torch.bfloat16)
+    yb = to_nhwc(rnd(N, 64, H, 56, seed=54), torch.bfloat16)
+    mean, invstd = rnd(64, seed=55).to(DEV), (rnd(64, seed=56).abs() + 0.5).to(DEV)
+    msc, msh = rnd(64, seed=57).to(DEV), rnd(64, seed=58, scale=0.3).to(DEV)
+    res = {}
+    for which in ("strip", "igemm"):
+        sums = torch.zeros(ops.STATS_REPLICAS, 64, 2, device=DEV, dtype=torch.float64)
+        dx = torch.full((N, H, 56, 64), float("nan"), device=DEV, dtype=torch.bfloat16)
+        br = ops.bn_reduce_arg(yb, mean, invstd, sums, mask_scale=msc, mask_shift=msh)
+        if which == "strip":
+            ops.conv3x3_strip_dgrad(dyg, wt, dx, bnred=br, replicas=4)
+        else:
+            ops.conv_igemm(ops.dgrad_descs(N, H, 56, 64, 64, 3, 1, 1)[0], dyg, wt, dx, bnred=br, replicas=4)
+        res[which] = (dx, sums.sum(0))
+    # (not bit-identical: the strip kernel walks the kernel positions in raster order, the implicit GEMM its own tap enumeration -- the
+    # fp32 sums differ in their last bits and a few stored values by one bf16 rounding)
+    assert_close(res["strip"][0], res["igemm"][0].float(), torch.bfloat16, bf16=4e-3, what="strip vs implicit-GEMM input gradient")
+    want = ops.bn_bwd_reduce(res["strip"][0], yb, mean, invstd, mask_scale=msc, mask_shift=msh)
+    scale = float(want.abs().max()) + 1e-6
+    assert float((res["strip"][1] - want).abs().max()) / scale < 1e-5          # the sums of what THIS launch stored
+    assert float((res["strip"][1] - res["igemm"][1]).abs().max()) / scale < 2e-3
+    assert_close(from_nhwc(res["strip"][0]), x.grad, torch.bfloat16, bf16=1e-2, what="strip input gradient vs autograd")
+    plain = torch.empty_like(res["strip"][0])
+    ops.conv3x3_strip_dgrad(dyg, wt, plain)                 # without the reduction
+    assert torch.equal(plain, res["strip"][0])
+
+
 def test_conv3x3_image_strip_kernel_several_images_per_workgroup():
     """The ring restarts per image: with fewer workgroups than images (VINCE_KNOBS strip_grid, read once per process) every workgroup
     walks several images -- re-run the parity test above in a child process with 2 workgroups."""

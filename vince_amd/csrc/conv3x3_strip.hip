@@ -52,10 +52,19 @@ struct XsParams {
     uint32_t x_bytes, w_bytes;
     int N, H, strips_per_image, replicas;
     int tap_w[9];                          // weight tap index of kernel position (dh + 1) * 3 + (dw + 1)
+    // BNRED (the input-gradient launch, vince_bn_reduce with mask_scale / mask_shift): the tensor being written is the gradient dz that a
+    // BatchNorm + ReLU backward consumes next; `stats` then receives (sum g, sum g * xhat) of the STORED values, g = dz where
+    // y * msc + msh > 0, xhat = (y - mean) * invstd -- what the implicit-GEMM gradient epilogue fuses for every other layer
+    const void* br_y;
+    const float* br_mean;
+    const float* br_invstd;
+    const float* br_msc;
+    const float* br_msh;
 };
 
+template <bool BNRED>
 __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[XS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XS_BYTES + (BNRED ? 512 : 0)];
     unsigned char* const wsm = smem;
     unsigned char* const xsm = smem + XS_WB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -77,6 +86,9 @@ __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParam
             const uint32_t co = (uint32_t)(rb + dr);
             const uint32_t off = ((co * 9u + (uint32_t)p.tap_w[tap]) * (uint32_t)XS_C + (uint32_t)(kt * 32 + dchunk * 8)) * 2u;
             lds_dma16(__builtin_amdgcn_readfirstlane(smem_base + tk * (XS_C * 64) + rb * 64), off, rsrc_w);
+        }
+        if constexpr (BNRED) {
+            if (tid < 128) ((float*)(smem + XS_BYTES))[tid] = tid < 64 ? p.br_msc[tid] : p.br_msh[tid - 64];
         }
         // the zero pixels of every ring row
         for (int i = tid; i < XS_RING * 2 * 8; i += XS_THREADS) {
@@ -141,6 +153,11 @@ __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParam
     for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int e = 0; e < 8; ++e) ssum[q][e] = ssq[q][e] = 0.f;
+    // BNRED: the constants of this lane's 2 x 8 channels (a lane stores the same channels for the whole launch)
+    // (in the loop only the ReLU test needs constants -- sum g * xhat = invstd * (sum g * y - mean * sum g) is finished per lane at the
+    // end -- and they sit in the last 512 bytes of LDS: the register file is full)
+    const bf16_t* __restrict__ br_y = (const bf16_t*)p.br_y;
+    const float* const ctab = (const float*)(smem + XS_BYTES);      // [2][64]: mask_scale, mask_shift
 
     auto consume = [&](auto nbc) {
         constexpr int NB = decltype(nbc)::value;
@@ -163,6 +180,7 @@ __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParam
         f32x16_t pacc[NB][2];                               // accumulators of the previous strip
         uint32_t ppix0 = 0;                                 // its first output pixel (this wavefront's first block)
         uint4 opk[2][2], tval;
+        uint4 yq[2];                                        // BNRED: the BatchNorm input at this lane's two output chunks of a pass
         auto epi_pack = [&](int u, int j, int gp) {
             float v[8];
 #pragma unroll
@@ -188,14 +206,38 @@ __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParam
             const int prow = lane / 4 + 16 * sidx, c = lane % 4;
             tval = *(const uint4*)(tbuf + prow * 64 + ((c ^ ((prow >> 1) & 3)) * 16));
         };
+        auto epi_yload = [&](int u, int pass) {             // BNRED: requested 6 pieces (MFMA steps) before the stores that use it
+            if constexpr (BNRED) {
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    const int prow = lane / 4 + 16 * sidx, c = lane % 4;
+                    yq[sidx] = *(const uint4*)(br_y + (size_t)(ppix0 + (uint32_t)(32 * u + prow)) * XS_C + (size_t)(pass * 32 + c * 8));
+                }
+            }
+        };
         auto epi_store = [&](int u, int pass, int sidx) {
             const int prow = lane / 4 + 16 * sidx, c = lane % 4;
             const size_t off = (size_t)(ppix0 + (uint32_t)(32 * u + prow)) * XS_C + (size_t)(pass * 32 + c * 8);
             if constexpr (!(XS_ABLATE & 2)) *(uint4*)(out + off) = tval;
             float f[8];
             Chunk<bf16_t>::unpack(tval, f);
+            if constexpr (BNRED) {
+                float yy[8], csc[8], csh[8];
+                Chunk<bf16_t>::unpack(yq[sidx], yy);
+                *(float4*)&csc[0] = *(const float4*)(ctab + pass * 32 + c * 8);
+                *(float4*)&csc[4] = *(const float4*)(ctab + pass * 32 + c * 8 + 4);
+                *(float4*)&csh[0] = *(const float4*)(ctab + 64 + pass * 32 + c * 8);
+                *(float4*)&csh[4] = *(const float4*)(ctab + 64 + pass * 32 + c * 8 + 4);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { ssum[pass][e] += f[e]; ssq[pass][e] += f[e] * f[e]; }
+                for (int e = 0; e < 8; ++e) {
+                    const float ge = (yy[e] * csc[e] + csh[e]) > 0.f ? f[e] : 0.f;
+                    ssum[pass][e] += ge;
+                    ssq[pass][e] += ge * yy[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ssum[pass][e] += f[e]; ssq[pass][e] += f[e] * f[e]; }
+            }
         };
         auto epi_fence = [&]() {
             __builtin_amdgcn_wave_barrier();
@@ -206,14 +248,14 @@ __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParam
             const int u = (at - 1) / 12, k = (at - 1) % 12;
             if (at < 1 || u >= NB) return;
             switch (k) {
-                case 0: epi_pack(u, 0, 0); break;
+                case 0: epi_yload(u, 0); epi_pack(u, 0, 0); break;
                 case 1: epi_pack(u, 0, 1); break;
                 case 2: epi_pack(u, 1, 0); break;
                 case 3: epi_pack(u, 1, 1); break;
                 case 4: epi_write(0); break;
                 case 5: epi_read(0); break;
                 case 6: epi_store(u, 0, 0); epi_read(1); break;
-                case 7: epi_store(u, 0, 1); epi_fence(); break;
+                case 7: epi_store(u, 0, 1); epi_fence(); epi_yload(u, 1); break;
                 case 8: epi_write(1); break;
                 case 9: epi_read(0); break;
                 case 10: epi_store(u, 1, 0); epi_read(1); break;
@@ -297,6 +339,15 @@ __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParam
     };
     consume(std::integral_constant<int, 1>{});
     if (p.stats) {
+        if constexpr (BNRED) {   // (sum g, sum g * y) -> (sum g, sum g * xhat), xhat = (y - mean) * invstd
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = q * 32 + (lane % 4) * 8 + e;
+                    ssq[q][e] = (ssq[q][e] - p.br_mean[ch] * ssum[q][e]) * p.br_invstd[ch];
+                }
+        }
         // lanes l, l + 4, l + 8, ... hold the same channels: fold them, then one fp64 atomic per channel and wavefront
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -334,11 +385,8 @@ static int xs_num_cu() {
     return n_cu;
 }
 
-// out[N][H][56][64] = conv3x3(x[N][H][56][64], w[64][9][64]) (stride 1, pad 1, bf16), per-channel (sum, sum of squares) of the stored
-// output into stats (double[replicas][64][2], zeroed by the caller; may be null).  tap_map: 9 weight-tap indices by kernel position
-// (dh + 1) * 3 + (dw + 1), or null for the identity (the forward convolution; the input gradient passes the flipped order).
-extern "C" int vince_conv3x3_strip(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
-                                   const int32_t* tap_map, void* out, double* stats, int32_t replicas, void* stream) {
+static int strip_common(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                        const int32_t* tap_map, void* out, double* stats, const vince_bn_reduce* bnred, int32_t replicas, void* stream) {
     VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv3x3_strip: bf16 only");
     VINCE_CHECK_ARG(x && w && out && N > 0, VINCE_E_ARG, "vince_conv3x3_strip: null pointer");
     VINCE_CHECK_ARG(Ci == XS_C && Co == XS_C && W == XS_W && H > 0 && H % XS_ROWS == 0, VINCE_E_UNSUPPORTED,
@@ -361,7 +409,32 @@ extern "C" int vince_conv3x3_strip(int dtype, const void* x, const void* w, int3
     if (grid_env > 0) grid = grid_env;
     if (grid > N) grid = N;
     VinceProfScope prof(VINCE_TAG_STRIP, 2.0 * N * H * W * Co * 9.0 * Ci, stream);
-    hipLaunchKernelGGL(conv3x3_strip_kernel, dim3((unsigned)grid), dim3(XS_THREADS), 0, (hipStream_t)stream, p);
+    if (bnred && bnred->y) {
+        VINCE_CHECK_ARG(bnred->mean && bnred->invstd && bnred->sums && bnred->mask_scale && bnred->mask_shift && !bnred->mask_bits && !stats, VINCE_E_ARG,
+                        "vince_conv3x3_strip_dgrad: bnred needs y, mean, invstd, sums and mask_scale / mask_shift (no mask bits), and excludes stats");
+        p.stats = bnred->sums;
+        p.br_y = bnred->y; p.br_mean = bnred->mean; p.br_invstd = bnred->invstd; p.br_msc = bnred->mask_scale; p.br_msh = bnred->mask_shift;
+        hipLaunchKernelGGL(conv3x3_strip_kernel<true>, dim3((unsigned)grid), dim3(XS_THREADS), 0, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL(conv3x3_strip_kernel<false>, dim3((unsigned)grid), dim3(XS_THREADS), 0, (hipStream_t)stream, p);
+    }
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
+}
+
+// out[N][H][56][64] = conv3x3(x[N][H][56][64], w[64][9][64]) (stride 1, pad 1, bf16), per-channel (sum, sum of squares) of the stored
+// output into stats (double[replicas][64][2], zeroed by the caller; may be null).  tap_map: 9 weight-tap indices by kernel position
+// (dh + 1) * 3 + (dw + 1), or null for the identity (the forward convolution; the input gradient passes the flipped order).
+extern "C" int vince_conv3x3_strip(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                                   const int32_t* tap_map, void* out, double* stats, int32_t replicas, void* stream) {
+    return strip_common(dtype, x, w, N, H, W, Ci, Co, tap_map, out, stats, nullptr, replicas, stream);
+}
+
+// The INPUT GRADIENT of the same layer (autograd of resnet.py:119-121): dx = conv3x3(dy, W^T with the taps flipped) -- wt is the prepared
+// [Ci][tap][Co] copy -- with vince_conv_igemm's fused BatchNorm-backward reduction (vince_bn_reduce with mask_scale / mask_shift: the
+// plain BatchNorm + ReLU below this convolution) accumulated from the stored values.  bnred may be NULL (plain input gradient).
+extern "C" int vince_conv3x3_strip_dgrad(int dtype, const void* dy, const void* wt, int32_t N, int32_t H, int32_t W, int32_t C, void* dx,
+                                         const vince_bn_reduce* bnred, int32_t replicas, void* stream) {
+    static const int32_t flipped[9] = {8, 7, 6, 5, 4, 3, 2, 1, 0};
+    return strip_common(dtype, dy, wt, N, H, W, C, C, flipped, dx, nullptr, bnred, replicas, stream);
 }

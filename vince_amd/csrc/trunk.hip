@@ -604,6 +604,15 @@ int dgrad(Ctx& c, const ConvL& cv, const void* dy, void* dx, bool accumulate, co
         return vince_conv_expand_dgrad(c.dtype, dy, at((void*)c.wcache, cv.wt), (int64_t)c.t->cfg.N * cv.Hi * cv.Wi, cv.Co, cv.Ci, dx, 1,
                                        acc_mask, bnred, replicas, c.stream);
     }
+    // layer1's 3x3 (64 -> 64 at 56 x 56, stride 1): the image-strip kernel with the taps flipped (csrc/conv3x3_strip.hip) -- every dy
+    // element crosses L2 -> LDS once instead of nine times, the BatchNorm-backward reduction of the BatchNorm below rides in its
+    // epilogue as in the implicit-GEMM gradient launch.  `strip3x3_dgrad=0`: off (cross-check switch).
+    static const bool strip_dgrad = (vince_knob("strip3x3", 1) != 0) && (vince_knob("strip3x3_dgrad", 1) != 0);
+    if (strip_dgrad && c.dtype == VINCE_BF16 && !accumulate && !acc_mask && !out_mask && !gsums && cv.k == 3 && cv.stride == 1 &&
+        cv.Ci == 64 && cv.Co == 64 && cv.Wi == 56 && cv.Hi % 4 == 0 && cv.Hi == cv.Ho && cv.Wi == cv.Wo &&
+        (!bnred || (bnred->mask_scale && !bnred->mask_bits)) &&
+        (unsigned long long)c.t->cfg.N * cv.Hi * cv.Wi * cv.Co * 2 < 0x7ff00000ull)
+        return vince_conv3x3_strip_dgrad(c.dtype, dy, at((void*)c.wcache, cv.wt), c.t->cfg.N, cv.Hi, cv.Wi, cv.Ci, dx, bnred, replicas, c.stream);
     vince_conv_desc ds[4];
     const int n = dgrad_descs(c.t, cv, ds);
     const int classes = cv.stride * cv.stride;

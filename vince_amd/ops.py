@@ -174,6 +174,17 @@ def conv_expand_stats(x, w, out, stats=None, replicas=0):
     return out
 
 
+def conv3x3_strip_dgrad(dy, wt, dx, bnred=None, replicas=0):
+    """dx = the input gradient of layer1's 3x3 (dy, dx [N, H, 56, 64] bf16, wt [64, 9, 64] = the prepared [Ci][tap][Co] copy) through the
+    image-strip kernel, with the fused BatchNorm-backward reduction of vince_conv_igemm's gradient epilogue (bnred: bn_reduce_arg(...,
+    mask_scale=, mask_shift=))."""
+    require_gpu(dy, wt, dx)
+    N, H, W, C = dy.shape
+    check(lib().vince_conv3x3_strip_dgrad(dtype_code(dy), _ptr(dy), _ptr(wt), N, H, W, C, _ptr(dx), None if bnred is None else ctypes.byref(bnred),
+                                          replicas, stream_ptr()))
+    return dx
+
+
 def conv3x3_strip(x, w, out, stats=None, replicas=0, tap_map=None):
     """out = conv3x3(x, w) for layer1's shape (x, out [N, H, 56, 64] bf16, w [64, 9, 64]) through the image-strip kernel, BatchNorm
     statistics of the stored values into stats (double[R][64][2], zeroed by the caller)."""
