@@ -116,6 +116,43 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def conv_layer_table(arch, batch, hw):
+    """(N, Hi, Ci, Co, k, stride, Ho) of every convolution of the trunk, in forward order: torchvision's ResNet-18 / -50 as the
+    reference vendors it (models/building_blocks/resnet.py:140-250; stride 2 on the 3x3 of a bottleneck)."""
+    rows = [(batch, hw, 3, 64, 7, 2, (hw + 1) // 2)]
+    h = ((hw + 1) // 2 + 1) // 2          # after the 3x3 / s2 max-pool
+    cin = 64
+    if arch == "ResNet50":
+        for li, (nb, w) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512))):
+            for bi in range(nb):
+                s = 2 if (li > 0 and bi == 0) else 1
+                ho = (h + 1) // 2 if s == 2 else h
+                rows += [(batch, h, cin, w, 1, 1, h), (batch, h, w, w, 3, s, ho), (batch, ho, w, 4 * w, 1, 1, ho)]
+                if bi == 0:
+                    rows.append((batch, h, cin, 4 * w, 1, s, ho))
+                cin, h = 4 * w, ho
+    else:
+        for li, w in enumerate((64, 128, 256, 512)):
+            for bi in range(2):
+                s = 2 if (li > 0 and bi == 0) else 1
+                ho = (h + 1) // 2 if s == 2 else h
+                rows += [(batch, h, cin, w, 3, s, ho), (batch, ho, w, w, 3, 1, ho)]
+                if bi == 0 and (s == 2 or cin != w):
+                    rows.append((batch, h, cin, w, 1, s, ho))
+                cin, h = w, ho
+    return rows
+
+
+def wgrad_algorithmic_bytes(arch, batch, hw, esize):
+    """Mean ALGORITHMIC bytes of a weight-gradient launch of the workload: x + dy once (esize bytes per element) + dw (fp32) --
+    what `traffic` (the PMC bytes of the same family) is held against."""
+    tab = conv_layer_table(arch, batch, hw)
+    tot = 0.0
+    for n, hi, ci, co, k, s, ho in tab:
+        tot += (n * hi * hi * (4 if ci == 3 else ci) + n * ho * ho * co) * esize + co * k * k * ci * 4
+    return tot / len(tab), len(tab)
+
+
 def workload_label(opt, world):
     """Names the BASELINE.json configuration the ARGUMENTS describe (never a fixed string: a ResNet-18 fp32 run is config 2)."""
     shape = "%s %dx%d, B=%d per GPU, K=%d, D=%d, T=%g, %s trunk" % (opt.backbone, opt.size, opt.size, opt.batch, opt.queue,
@@ -456,6 +493,13 @@ def main():
             if other:
                 o = max(other, key=lambda kk: kernels[kk]["ms_per_step"])
                 out["roofline"]["largest_%s_family" % kernels[o]["bound"]] = dict(kernel=o, **kernels[o])
+            if dom.startswith("conv_wgrad"):
+                ab, nl = wgrad_algorithmic_bytes(opt.backbone, opt.batch, opt.size, 4 if "f32" in dom else 2)
+                out["roofline"]["algorithmic_bytes_per_launch"] = round(ab)
+                out["roofline"]["algorithmic_bytes_note"] = ("mean over the %d weight-gradient launches of the layer table: x + dy once + dw in "
+                                                             "fp32 (the Gram / algebra launches of the family excluded)" % nl)
+                if traffic:
+                    out["roofline"]["traffic_over_algorithmic"] = round(traffic / ab, 3)
             if traffic_stamp is not None:
                 out["roofline"]["traffic_stale"] = bool(traffic_stamp["stale"])
                 out["roofline"]["traffic_taken_from"] = {k2: traffic_stamp[k2] for k2 in ("git_head", "kernel_source_hash")}
@@ -558,6 +602,14 @@ def main():
                                                % (opt.size, opt.size, opt.batch))
             except Exception as e:
                 out["c2_step"] = {"error": repr(e)}
+            try:
+                out["c2_x3_step"] = dict(step_leg(opt.config_steps, gflop_backbone="ResNet18", backbone="ResNet18", compute_dtype="x3",
+                                                  vince_queue_size=4096, vince_embedding_size=64, vince_temperature=0.07),
+                                         workload="BASELINE config 2 with the split-half convolutions: fp32 tensors and fp32-grade results "
+                                                  "(embeddings within 1e-4 of the fp32 reference on G3 / G9 / G11c / G12 / G13) at a multiple of "
+                                                  "the fp32 MFMA rate; mfma_frac against 2.5 PF / 3")
+            except Exception as e:
+                out["c2_x3_step"] = {"error": repr(e)}
             try:
                 random.seed(1234 + rank)
                 out["c5_step"] = dict(step_leg(opt.config_steps, frames=4, num_frames=4, inter_batch_comparison=True,

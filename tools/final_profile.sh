@@ -33,6 +33,12 @@ cat $O/pmc_summary.txt | head -12
 bash tools/aug_profile.sh > /dev/null 2>&1; cp gpurun_out/aug_kstats.txt $O/input_stage_kernel_stats.txt
 timeout 300 python bench.py --no-extras --input u8aug > $O/bench_u8aug.json 2>/dev/null
 timeout 20 python tools/bench_brief.py $O/bench_u8aug.json u8aug
+# ---- round 4: the split-half mode (x3), the forward-only PMC pass, the copy ceilings
+bash tools/x3_profile.sh final_x3 > /dev/null 2>&1; cp gpurun_out/final_x3/kernel_stats_serialised.txt $O/x3_kernel_stats_serialised.txt; cp gpurun_out/final_x3/bench.json $O/x3_bench.json
+timeout 300 python tools/x3_micro.py final > $O/x3_micro.txt 2>&1
+bash tools/fwd_pmc.sh $O/fwd_pmc > /dev/null 2>&1; cp $O/fwd_pmc/fwd_pmc_summary.txt $O/fwd_pmc_summary.txt
+timeout 300 python tools/ceilings.py > $O/ceilings.txt 2>&1
+timeout 120 python tools/strip_dgrad_micro.py > $O/strip_dgrad_micro.txt 2>&1
 export VINCE_GIT_HEAD=${VINCE_GIT_HEAD:-unknown}
 # the bench line once more, now that profiles/pmc_conv_igemm.json of THIS build exists (traffic_stale false)
 cp $O/pmc_conv_igemm.json profiles/pmc_conv_igemm.json
