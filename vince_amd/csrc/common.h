@@ -171,33 +171,32 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16v8_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16v2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
+// Two floats -> one dword of hi halves + one dword of lo halves.
+template <typename T, bool WEIGHT> __device__ __forceinline__ void x3_split_pair(float x0, float x1, uint32_t& h, uint32_t& l) {
+    if constexpr (X3<T>::half) {
+        constexpr float K = (float)(1 << (WEIGHT ? X3_WSHIFT : X3_XSHIFT));
+        const float a = x0 * K, b = x1 * K;
+        const fp16x2_t hp = __builtin_amdgcn_cvt_pkrtz(a, b);          // hi by truncation: a - hi is exact in fp32
+        const fp16x2_t lp = __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]);
+        __builtin_memcpy(&h, &hp, 4);
+        __builtin_memcpy(&l, &lp, 4);
+    } else {
+        const f32x2_t v = {x0, x1};
+        const bf16v2_t hp = __builtin_convertvector(v, bf16v2_t);       // v_cvt_pk_bf16_f32, round to nearest even
+        uint32_t hb;
+        __builtin_memcpy(&hb, &hp, 4);
+        const f32x2_t r = {x0 - __uint_as_float(hb << 16), x1 - __uint_as_float(hb & 0xffff0000u)};
+        const bf16v2_t lp = __builtin_convertvector(r, bf16v2_t);
+        h = hb;
+        __builtin_memcpy(&l, &lp, 4);
+    }
+}
 // 8 floats (two 16-byte fragments) -> 8 hi halves + 8 lo halves, each one MFMA operand register quad.
 template <typename T, bool WEIGHT> __device__ __forceinline__ void x3_split(const uint4& f0, const uint4& f1, uint4& hi, uint4& lo) {
-    const float x[8] = {__uint_as_float(f0.x), __uint_as_float(f0.y), __uint_as_float(f0.z), __uint_as_float(f0.w),
-                        __uint_as_float(f1.x), __uint_as_float(f1.y), __uint_as_float(f1.z), __uint_as_float(f1.w)};
-    uint32_t h[4], l[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if constexpr (X3<T>::half) {
-            constexpr float K = (float)(1 << (WEIGHT ? X3_WSHIFT : X3_XSHIFT));
-            const float a = x[2 * p] * K, b = x[2 * p + 1] * K;
-            const fp16x2_t hp = __builtin_amdgcn_cvt_pkrtz(a, b);          // hi by truncation: a - hi is exact in fp32
-            const fp16x2_t lp = __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]);
-            __builtin_memcpy(&h[p], &hp, 4);
-            __builtin_memcpy(&l[p], &lp, 4);
-        } else {
-            const f32x2_t v = {x[2 * p], x[2 * p + 1]};
-            const bf16v2_t hp = __builtin_convertvector(v, bf16v2_t);       // v_cvt_pk_bf16_f32, round to nearest even
-            uint32_t hb;
-            __builtin_memcpy(&hb, &hp, 4);
-            const f32x2_t r = {x[2 * p] - __uint_as_float(hb << 16), x[2 * p + 1] - __uint_as_float(hb & 0xffff0000u)};
-            const bf16v2_t lp = __builtin_convertvector(r, bf16v2_t);
-            h[p] = hb;
-            __builtin_memcpy(&l[p], &lp, 4);
-        }
-    }
-    hi = make_uint4(h[0], h[1], h[2], h[3]);
-    lo = make_uint4(l[0], l[1], l[2], l[3]);
+    x3_split_pair<T, WEIGHT>(__uint_as_float(f0.x), __uint_as_float(f0.y), hi.x, lo.x);
+    x3_split_pair<T, WEIGHT>(__uint_as_float(f0.z), __uint_as_float(f0.w), hi.y, lo.y);
+    x3_split_pair<T, WEIGHT>(__uint_as_float(f1.x), __uint_as_float(f1.y), hi.z, lo.z);
+    x3_split_pair<T, WEIGHT>(__uint_as_float(f1.z), __uint_as_float(f1.w), hi.w, lo.w);
 }
 // c += a*b with a = ah + al, b = bh + bl, the lo*lo term dropped; small terms first
 template <typename T> __device__ __forceinline__ void x3_mma(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16_t& c) {

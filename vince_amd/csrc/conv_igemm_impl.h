@@ -677,6 +677,21 @@ int launch_x3(ConvParams& p, hipStream_t stream) {
         p.nkt = p.total_chunks / 4;     // 64-byte K rows
         // (reductions of at most 128 elements -- the 1x1 expand convolutions of layer1 / layer2, pure HBM streams -- do better with the
         // 64-byte rows' three to four workgroups per CU: 255 -> 213 us and 161 -> 144 us at N = 256)
+        // 256-pixel tiles (a wavefront owns 64 pixels x 128 channels; 64-byte K rows in a 3-stage ring, two workgroups per CU): a quarter
+        // fewer operand bytes per MFMA through the L2 -> LDS path that bounds these kernels (~32 B/clk/CU for 128-byte row pieces against
+        // the ~84 the matrix pipe could take from two 128 x 128 workgroups).  Pays where several channel tiles share a pixel tile and the
+        // reduction is long: layer3's 3x3 220 -> 198 us, its input gradient 210 -> 181; layer2's 3x3 (one channel tile) loses 3 %.
+        // x3_big_min_k = 0: off.
+        static const int x3_big_min_k = vince_knob("x3_big_min_k", 512);
+        if constexpr (CT == 128) {
+            if (x3_big_min_k > 0 && k_elems >= x3_big_min_k && p.ctiles >= 2 && (long)((p.M + 255) / 256) * p.ctiles >= 256) {
+                p.ptiles = (p.M + 255) / 256;
+                p.variant = 1;
+                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, 128, 4, 3, 2, 256, MODE, false, 1>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
+                VINCE_CHECK_LAUNCH();
+                return VINCE_OK;
+            }
+        }
         if (x3_cfg == 1 && cpt % 8 == 0 && p.total_chunks % 8 == 0 && k_elems > 128) {
             p.nkt = p.total_chunks / 8;
             hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 2, 2, PT, MODE, false, 1>), grid, dim3(256), 0, stream, p);
