@@ -1169,6 +1169,25 @@ def test_two_ranks_on_one_gpu_stay_identical():
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
 
+def test_a_discarded_model_is_collected():
+    """The autograd node of a grad-enabled forward holds the model (ctx.model); the model must not hold that node's OUTPUT tensors in its
+    saved state, or the cycle runs through a C++ object Python's collector cannot see and every discarded model keeps its workspaces
+    (tens of GB per solver at the benchmark size; found through bench.py's extra legs)."""
+    import gc
+    import weakref
+    _, model = build("ResNet18", 64, "bf16", 11)
+    model.train()
+    x = vo.structured_frames(4, 64, 64, seed=80).to(DEV)
+    o = model.get_embeddings({"data": x})
+    (o["embeddings"] * 0.5).sum().backward()
+    o2 = model.get_embeddings({"data": x})         # a second grad-enabled forward whose graph is simply dropped
+    torch.cuda.synchronize()
+    ref = weakref.ref(model)
+    del model, o, o2
+    gc.collect()
+    assert ref() is None
+
+
 def test_cpu_model_forward_raises():
     from vince_amd.config import make_args
     from vince_amd.models.vince_model import VinceModel

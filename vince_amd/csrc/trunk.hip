@@ -382,18 +382,40 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     return VINCE_OK;
 }
 
+// The engine's own streams are PROCESS-WIDE, one pair per device, created on first use and never destroyed: this runtime deals streams
+// to its (four) hardware queues in creation order, so an engine instance built later in the process -- a second solver, a trunk for
+// another input size -- must land on the queues the first one had, not on whatever the creation counter has reached (measured: the
+// same x3 step 52.3 ms in a fresh process, 59.6-60.7 ms as the second solver of a process with per-instance streams).
+namespace {
+hipStream_t g_side_stream[64] = {}, g_ds_stream[64] = {};
+int shared_stream(hipStream_t* pool, bool low_priority, int prio_sign, hipStream_t* out) {
+    int dev = 0;
+    VINCE_CHECK_HIP(hipGetDevice(&dev));
+    VINCE_CHECK_ARG(dev >= 0 && dev < 64, VINCE_E_UNSUPPORTED, "vince_trunk: device index %d", dev);
+    if (!pool[dev]) {
+        if (low_priority) {
+            int least = 0, greatest = 0;
+            VINCE_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            VINCE_CHECK_HIP(hipStreamCreateWithPriority(&pool[dev], hipStreamNonBlocking, prio_sign > 0 ? least : greatest));
+        } else {
+            VINCE_CHECK_HIP(hipStreamCreateWithFlags(&pool[dev], hipStreamNonBlocking));
+        }
+    }
+    *out = pool[dev];
+    return VINCE_OK;
+}
+}  // namespace
+
 extern "C" void vince_trunk_destroy(vince_trunk_t t) {
     if (!t) return;
     if (t->side) {
-        hipStreamSynchronize(t->side);
+        hipStreamSynchronize(t->side);     // (the stream itself is shared by every engine instance of the process: it stays)
         for (int i = 0; i < t->ndy; ++i) { hipEventDestroy(t->ev_dy[i]); hipEventDestroy(t->ev_wg[i]); }
         hipEventDestroy(t->ev_join);
-        hipStreamDestroy(t->side);
     }
     if (t->ds_stream) {
         hipStreamSynchronize(t->ds_stream);
         hipEventDestroy(t->ev_ds_start); hipEventDestroy(t->ev_ds_dy); hipEventDestroy(t->ev_ds_wg); hipEventDestroy(t->ev_ds_done);
-        hipStreamDestroy(t->ds_stream);
     }
     delete t;
 }
@@ -864,7 +886,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     const bool ds_side = (ds_fwd_mode == 1 || (ds_fwd_mode == 2 && save && t->ds_stream)) && !vince_profile_enabled() &&
                          vince_side_stream_budget() >= 2;
     if (ds_side && !t->ds_stream) {
-        VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->ds_stream, hipStreamNonBlocking));
+        RC(shared_stream(g_ds_stream, false, 0, &t->ds_stream));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_start, hipEventDisableTiming));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_dy, hipEventDisableTiming));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_wg, hipEventDisableTiming));
@@ -1010,12 +1032,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         // their stream gets the LOWEST priority so that a 1000-workgroup wgrad never delays the next dgrad's start
         // (-0.1 ms/step, 4 of 4 paired runs).  VINCE_SIDE_PRIO: 1 lowest (default), 0 same as the caller's, -1 highest.
         static const int side_prio = VINCE_MEASURE_KNOB("side_prio", 1);
-        if (side_prio != 0) {
-            int least = 0, greatest = 0;
-            VINCE_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            VINCE_CHECK_HIP(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, side_prio > 0 ? least : greatest));
-        } else
-        VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+        RC(shared_stream(g_side_stream, side_prio != 0, side_prio, &t->side));
         for (int i = 0; i < t->ndy; ++i) {
             VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_dy[i], hipEventDisableTiming));
             VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_wg[i], hipEventDisableTiming));
@@ -1028,7 +1045,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                                (vince_knob("ds_stream_bwd", 1) != 0);
     const bool ds_overlap = overlap && ds_env && vince_side_stream_budget() >= 2;
     if (ds_overlap && !t->ds_stream) {
-        VINCE_CHECK_HIP(hipStreamCreateWithFlags(&t->ds_stream, hipStreamNonBlocking));
+        RC(shared_stream(g_ds_stream, false, 0, &t->ds_stream));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_start, hipEventDisableTiming));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_dy, hipEventDisableTiming));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_wg, hipEventDisableTiming));

@@ -452,7 +452,10 @@ class VinceModel(BaseModel):
         if getattr(self, "clone_spatial", True):
             spatial = spatial.clone()
         pre = emb = None
-        saved = dict(trunk=trunk, pooled=pooled, jigsaw=jigsaw)
+        # (detached aliases: `pooled` and `pre` are also RETURNED through _EncodeFn, whose autograd node holds the model -- saving the
+        # returned objects themselves would close a cycle model -> _saved -> tensor -> grad_fn -> ctx.model that Python's collector
+        # cannot see through, and every discarded model would keep its workspaces: tens of GB per solver at the benchmark size)
+        saved = dict(trunk=trunk, pooled=pooled.detach(), jigsaw=jigsaw)
         if with_head:
             if jigsaw:   # vince_model.py:161-171
                 f = ops.linear_fwd(pooled, self.jigsaw_linear.weight.data, self.jigsaw_linear.bias.data)
@@ -467,7 +470,7 @@ class VinceModel(BaseModel):
                 pre = ops.linear_fwd(hid, self.embedding[2].weight.data, self.embedding[2].bias.data)
                 saved.update(hid=hid)
             emb, norms = ops.l2norm_fwd(pre)   # F.normalize(dim=1), vince_model.py:180
-            saved.update(pre=pre, norms=norms)
+            saved.update(pre=pre.detach(), norms=norms)
         if save:
             self._saved = saved
         return spatial, pooled, pre, emb

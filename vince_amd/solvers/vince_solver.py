@@ -43,6 +43,20 @@ def stack_dicts_in_list(dicts, concat=False):
     return out
 
 
+_KEY_STREAMS = {}
+
+
+def _shared_key_stream(device):
+    """The key encoder's side stream, ONE per device for the whole process: streams are dealt to the runtime's hardware queues in creation
+    order, so a solver built later in the process must reuse the stream of the first instead of creating another (csrc/trunk.hip
+    shared_stream has the measurement)."""
+    key = (device.type, device.index)
+    if key not in _KEY_STREAMS:
+        with torch.cuda.device(device):
+            _KEY_STREAMS[key] = torch.cuda.Stream()
+    return _KEY_STREAMS[key]
+
+
 class VinceSolver(BaseSolver):
     def __init__(self, args, train_logger=None, val_logger=None):
         # (attribute names are the reference's: end-task code and drivers reach into them)
@@ -101,8 +115,7 @@ class VinceSolver(BaseSolver):
                 from .._lib import lib
                 lib().vince_set_side_streams(int(os.environ.get("VINCE_DP_SIDE_STREAMS", "1")))   # (2: measurement, keeps the downsample stream)
                 if self.overlap_key_encoder:
-                    with torch.cuda.device(self.model.device):
-                        self._key_stream = torch.cuda.Stream()
+                    self._key_stream = _shared_key_stream(self.model.device)
                     comm = self._key_stream
             self.reducer = dp.GradientReducer(self.model, ARCH_LAYERS[self.model.feature_extractor.arch], comm_stream=comm,
                                               payload=getattr(self.args, "dp_grad_payload", None))
@@ -363,7 +376,7 @@ class VinceSolver(BaseSolver):
         if on_gpu and self.overlap_key_encoder:
             main = torch.cuda.current_stream()
             if self._key_stream is None:
-                self._key_stream = torch.cuda.Stream()
+                self._key_stream = _shared_key_stream(self.model.device)
             self._key_stream.wait_stream(main)
             with torch.cuda.stream(self._key_stream):
                 queue_batches, gathered_keys = self._encode_keys(concat_batch, jig_key)
