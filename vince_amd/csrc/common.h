@@ -106,8 +106,17 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// two floats -> two bf16 in one dword: v_cvt_pk_bf16_f32 (round to nearest even, the same bits as f32_to_bf16 for every finite input
+// and infinity; a NaN stays a quiet NaN).  One instruction where the integer sequence takes ~10: the store side of every bf16
+// epilogue (64 values per lane and 128 x 128 tile) is VALU work that the matrix pipe does not hide.
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float pk_f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 pk_bf16x2_t;
+    const pk_f32x2_t v = {lo, hi};
+    const pk_bf16x2_t h = __builtin_convertvector(v, pk_bf16x2_t);
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
 }
 
 template <typename T> struct Elem;
@@ -322,8 +331,36 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     else static_assert(N == 0, "add the vmcnt literal");
+}
+
+// ---------------------------------------------------------------------------------------------
+// A train-mode BatchNorm + ReLU in the operand path of the convolution that consumes it (vince_conv_epi.bn_in, vince_conv_expand_stats_bn)
+// ---------------------------------------------------------------------------------------------
+constexpr int BNIN_MAX_K = 512;   // input channels of a bn_in convolution (the LDS table: 2 x 4 bytes each)
+
+// one activation fragment (8 consecutive reduction elements of a pixel, bf16) through relu(x * sc[e] + sh[e]), rounded to bf16 the way
+// vince_bn_train_apply stores it (round to nearest even; the ReLU on the rounded halves: a negative or -0 half becomes +0)
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+__device__ __forceinline__ void bn_in_apply(uint4& x, const float* __restrict__ sc, const float* __restrict__ sh) {
+    const float4 a0 = *(const float4*)sc, a1 = *(const float4*)(sc + 4), b0 = *(const float4*)sh, b1 = *(const float4*)(sh + 4);
+    const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float f[8];
+    Chunk<bf16_t>::unpack(x, f);
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2_t v = {f[2 * q] * a[2 * q] + b[2 * q], f[2 * q + 1] * a[2 * q + 1] + b[2 * q + 1]};
+        const bf16v2_t h = __builtin_convertvector(v, bf16v2_t);
+        s16x2_t sv;
+        __builtin_memcpy(&sv, &h, 4);
+        sv = __builtin_elementwise_max(sv, (s16x2_t)(short)0);
+        __builtin_memcpy(&o[q], &sv, 4);
+    }
+    x = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
