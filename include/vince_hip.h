@@ -126,7 +126,6 @@ typedef struct vince_bn_reduce {
     double* sums;             /* double[R][C][2], zeroed by the caller, R = VINCE_STATS_REPLICAS */
 } vince_bn_reduce;
 
-struct vince_bn_train;
 typedef struct vince_conv_epi {
     int32_t flags;            /* VINCE_EPI_* */
     const float* bias;        /* optional float[Co] */
@@ -160,15 +159,6 @@ typedef struct vince_conv_epi {
      * launch (the input gradient of the BatchNorm-backward algebra: da = wd g + nq a, csrc/bn_algebra.hip).  Direct-to-LDS kernels only. */
     const void* in2;
     int32_t in2_channels;
-    /* The INPUT read through a train-mode BatchNorm + ReLU:  x' = relu(bn(x))  with the batch statistics in bn_in->stats, i.e. the
-     * bn2 + ReLU of a bottleneck (resnet.py:119-121) folded into the operand path of its conv3 (:123) -- the separate pass
-     * (vince_bn_train_apply) and the tensor it writes disappear from no-grad forwards.  Every workgroup folds the statistic replicas
-     * into scale / shift in its prologue (workgroup 0 also publishes bn_in->scale / shift / save_* and updates the running
-     * statistics, exactly as vince_bn_train_apply does); the fragments are transformed after their LDS read and rounded to bf16
-     * as the stored tensor would have been, so the result is bit-identical to the two-launch route.  bf16, 1x1, stride 1, no
-     * padding, Ci a multiple of 32 and <= 512, Co a multiple of 128, N*Ho*Wo a multiple of 128, forward epilogues without in2
-     * (VINCE_E_UNSUPPORTED otherwise).  bn_in->out_sum is not supported here. */
-    const struct vince_bn_train* bn_in;
 } vince_conv_epi;
 
 /* in/w/out have element type `dtype`.  epi may be NULL (plain store). */
@@ -189,22 +179,12 @@ int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows
                            const float* out_scale, const float* out_shift, const void* identity, const float* id_scale,
                            const float* id_shift, void* out, void* y_raw, uint8_t* mask_out, int relu, void* stream);
 
-/* The same streaming structure for an expand convolution on its own: out[p][co] = sum_k w[co][k] x[p][k] (bf16, K = 64 / 128 with
- * Co a multiple of 256, K = 256 with Co a multiple of 128; stride 1) with the BatchNorm statistics of the STORED values accumulated into stats
+/* The same streaming structure for an expand convolution on its own: out[p][co] = sum_k w[co][k] x[p][k] (bf16, K = 64 / 128,
+ * Co multiple of 256, stride 1) with the BatchNorm statistics of the STORED values accumulated into stats
  * (double[replicas][Co][2], zeroed by the caller; optional) -- what vince_conv_igemm(stats) computes for the same layer, as a
  * persistent HBM stream whose statistics live in registers for the whole launch. */
 int vince_conv_expand_stats(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co, void* out,
                             double* stats, int32_t replicas, void* stream);
-/* The K = 256 member (layer3's conv3, 256 -> 1024; Co a multiple of 128; csrc/conv_xk.hip), optionally reading x through the
- * train-mode BatchNorm + ReLU that produces it -- x' = relu(bn(x)) with the batch statistics in bn_in->stats, the bn2 + ReLU of the
- * bottleneck (resnet.py:119-123) -- so that the separate pass (vince_bn_train_apply) and the tensor it writes disappear from
- * no-grad forwards.  Every workgroup folds the statistic replicas in its prologue, workgroup 0 publishes bn_in->scale / shift /
- * save_* and updates the running statistics exactly as vince_bn_train_apply does; the fragments are rounded to bf16 as the stored
- * tensor would have been, so out is bit-identical to vince_bn_train_apply + vince_conv_igemm.  bn_in NULL: the plain expand
- * convolution (vince_conv_expand_stats forwards K = 256 here).  bn_in->out_sum is not supported. */
-struct vince_bn_train;
-int vince_conv_expand_stats_bn(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co, void* out,
-                               double* stats, int32_t replicas, const struct vince_bn_train* bn_in, void* stream);
 
 /* Layer1's 3x3 convolution (reference models/building_blocks/resnet.py:119-121 conv2 of the 64-wide bottlenecks: 64 -> 64 channels,
  * 56 pixels wide, stride 1, pad 1, bf16) as an image-strip kernel: input rows resident in an LDS ring, every input element crosses

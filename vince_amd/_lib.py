@@ -29,8 +29,7 @@ class BnReduce(ctypes.Structure):
 class ConvEpi(ctypes.Structure):
     _fields_ = [("flags", c_int32), ("bias", c_void_p), ("stats", c_void_p), ("acc_mask", c_void_p),
                 ("bnred", BnReduce), ("replicas", c_int32),
-                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p), ("out_mask", c_void_p), ("in2", c_void_p), ("in2_channels", c_int32),
-                ("bn_in", c_void_p)]
+                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p), ("out_mask", c_void_p), ("in2", c_void_p), ("in2_channels", c_int32)]
 
 
 class BnTrain(ctypes.Structure):
@@ -64,7 +63,6 @@ PROTOTYPES = {
     "vince_conv3x3_strip": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_conv3x3_strip_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, P(BnReduce), c_int32, c_void_p]),
     "vince_conv_expand_stats": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
-    "vince_conv_expand_stats_bn": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "vince_conv_expand_dgrad_masked": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_void_p, c_void_p,
                                                c_void_p, c_int32, c_void_p]),
     "vince_bn3_bwd_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,

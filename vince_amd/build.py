@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libvince_hip.so")
-SOURCES = ["error.cpp", "conv_igemm.hip", "conv_igemm_x3.hip", "conv_m8.hip", "conv_xjoin.hip", "conv_xk.hip", "conv3x3_strip.hip", "conv_wgrad.hip", "conv_wgrad_tr.hip", "conv_wgrad_x3.hip", "bn_pool.hip", "bn_gram.hip", "bn_algebra.hip", "misc.hip", "infonce.hip", "trunk.hip", "augment.hip"]
+SOURCES = ["error.cpp", "conv_igemm.hip", "conv_igemm_x3.hip", "conv_m8.hip", "conv_xjoin.hip", "conv3x3_strip.hip", "conv_wgrad.hip", "conv_wgrad_tr.hip", "conv_wgrad_x3.hip", "bn_pool.hip", "bn_gram.hip", "bn_algebra.hip", "misc.hip", "infonce.hip", "trunk.hip", "augment.hip"]
 # augment.hip restates Pillow's double / float arithmetic: an fma where the C library rounds twice changes results
 EXTRA_FLAGS = {"augment.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]

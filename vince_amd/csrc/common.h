@@ -337,30 +337,3 @@ template <int N> static __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     else static_assert(N == 0, "add the vmcnt literal");
 }
-
-// ---------------------------------------------------------------------------------------------
-// A train-mode BatchNorm + ReLU in the operand path of the convolution that consumes it (vince_conv_epi.bn_in, vince_conv_expand_stats_bn)
-// ---------------------------------------------------------------------------------------------
-constexpr int BNIN_MAX_K = 512;   // input channels of a bn_in convolution (the LDS table: 2 x 4 bytes each)
-
-// one activation fragment (8 consecutive reduction elements of a pixel, bf16) through relu(x * sc[e] + sh[e]), rounded to bf16 the way
-// vince_bn_train_apply stores it (round to nearest even; the ReLU on the rounded halves: a negative or -0 half becomes +0)
-typedef __attribute__((ext_vector_type(2))) short s16x2_t;
-__device__ __forceinline__ void bn_in_apply(uint4& x, const float* __restrict__ sc, const float* __restrict__ sh) {
-    const float4 a0 = *(const float4*)sc, a1 = *(const float4*)(sc + 4), b0 = *(const float4*)sh, b1 = *(const float4*)(sh + 4);
-    const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    float f[8];
-    Chunk<bf16_t>::unpack(x, f);
-    uint32_t o[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x2_t v = {f[2 * q] * a[2 * q] + b[2 * q], f[2 * q + 1] * a[2 * q + 1] + b[2 * q + 1]};
-        const bf16v2_t h = __builtin_convertvector(v, bf16v2_t);
-        s16x2_t sv;
-        __builtin_memcpy(&sv, &h, 4);
-        sv = __builtin_elementwise_max(sv, (s16x2_t)(short)0);
-        __builtin_memcpy(&o[q], &sv, 4);
-    }
-    x = make_uint4(o[0], o[1], o[2], o[3]);
-}
-

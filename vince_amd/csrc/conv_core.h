@@ -24,7 +24,6 @@ struct ConvParams {
     uint32_t in2_bytes;
     int cs2;
     vince_conv_epi e;   // epilogue options (bias, statistics, residual join, fused BatchNorm forward / backward-reduce)
-    vince_bn_train bnin;   // e.bn_in by value (the kernel reads this copy; e.bn_in itself is only the "present" flag on the host)
 };
 
 }  // namespace vince_conv

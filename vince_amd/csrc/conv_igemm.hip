@@ -46,19 +46,6 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
                     "vince_conv_igemm: in2 is the input of the last of at least two taps, in2_channels <= Ci, 16-byte aligned");
     const vince_conv_desc& d = *dd;
     const int CH = f32_store ? 4 : 8;
-    if (e.bn_in) {
-        const vince_bn_train& b = *e.bn_in;
-        VINCE_CHECK_ARG(b.stats && b.count > 0 && b.gamma && b.beta && b.scale && b.shift && !b.out_sum, VINCE_E_ARG,
-                        "vince_conv_igemm: bn_in needs stats, count, gamma, beta, scale and shift (and takes no out_sum)");
-        VINCE_CHECK_ARG(!b.running_mean == !b.running_var, VINCE_E_ARG, "vince_conv_igemm: bn_in running_mean and running_var come together");
-        const bool ok = dtype == VINCE_BF16 && d.TA * d.TB == 1 && d.Cs == 0 && d.sh == 1 && d.sw == 1 && d.dh0 == 0 && d.dw0 == 0 &&
-                        d.Hi == d.Ho && d.Wi == d.Wo && d.Ci % 32 == 0 && d.Ci <= BNIN_MAX_K && d.Co % 128 == 0 &&
-                        ((long long)d.N * d.Ho * d.Wo) % 128 == 0 && !e.in2 && !(e.flags & VINCE_EPI_ACCUMULATE) && !e.bnred.y &&
-                        !e.out_mask && !e.out_scale && !e.id_scale;
-        VINCE_CHECK_ARG(ok, VINCE_E_UNSUPPORTED,
-                        "vince_conv_igemm: bn_in is for the bf16 1x1 stride-1 forward with Ci %% 32 == 0, Ci <= %d, Co %% 128 == 0, pixels %% 128 == 0",
-                        BNIN_MAX_K);
-    }
     VINCE_CHECK_ARG(d.N > 0 && d.Hi > 0 && d.Wi > 0 && d.Ho > 0 && d.Wo > 0 && d.Co > 0 && d.Ci > 0, VINCE_E_SHAPE,
                     "vince_conv_igemm: non-positive dimension");
     VINCE_CHECK_ARG(d.Ci % CH == 0, VINCE_E_SHAPE, "vince_conv_igemm: Ci=%d not a multiple of %d", d.Ci, CH);
@@ -99,11 +86,6 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.div_howo = make_fastdiv((uint32_t)(d.Ho * d.Wo));
     p.div_wo = make_fastdiv((uint32_t)d.Wo);
     p.in = in; p.w = w; p.out = out; p.e = e;
-    memset(&p.bnin, 0, sizeof(p.bnin));
-    if (e.bn_in) {
-        p.bnin = *e.bn_in;
-        if (p.bnin.replicas <= 0 || p.bnin.replicas > VINCE_STATS_REPLICAS) p.bnin.replicas = VINCE_STATS_REPLICAS;
-    }
     p.variant = 0;
     p.cs = d.Cs > 0 ? d.Cs : d.Ci;
     p.in2 = e.in2;
@@ -154,15 +136,6 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     static const int m8_min_k = vince_knob("m8_min_k", 1024);
     static const int m8_min_tiles = vince_knob("m8_min_tiles", 128);
     rc = VINCE_M8_NOT_ELIGIBLE;
-    if (e.bn_in) {
-        VINCE_CHECK_ARG(p.in_bytes && p.w_bytes, VINCE_E_UNSUPPORTED, "vince_conv_igemm: bn_in tensors beyond the 31-bit buffer offsets");
-        rc = launch_bnin(p, s);
-        if (tok) {
-            vince_profile_set_tag(tok, 8 + 2 * 2);   // counted with the bf16 128ch x 128px forward
-            vince_profile_end_launch(tok, stream);
-        }
-        return rc;
-    }
     if (m8_on && !e.in2 && dtype == VINCE_BF16 && d.Co % 256 == 0 && T * d.Ci >= m8_min_k &&
         (long)((p.M + 255) / 256) * (d.Co / 256) >= m8_min_tiles)
         rc = vince_conv_m8_launch(p, join ? 2 : (bwd ? 1 : 0), s);

@@ -198,18 +198,12 @@ struct SmemD {
 // 256-pixel tile moves 25 % fewer bytes per FLOP (each wave owns 128 pixels x CT/2 channels).
 // WN = wavefronts along the channel axis (the other 4 / WN split the pixels): 2 = the 2 x 2 arrangement, 1 = every wavefront holds all CT
 // channels of PTL / 4 pixels.
-// BNIN (bf16, 1x1, WN = 1): the activation fragments pass through relu(x * scale[k] + shift[k]) between their LDS read and the MFMA
-// (vince_conv_epi.bn_in: the bottleneck's bn2 + ReLU in the operand path of conv3).  scale / shift of all Ci input channels sit in an
-// LDS table that every workgroup derives from the statistic replicas in its prologue, under the latency of its first DMA tiles.  The
-// transform is ~24 VALU instructions per fragment, and a fragment feeds CT / 32 MFMAs: with WN = 1 that is one per four.
-template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, int MODE, bool ROT = false, int WN = 2, bool BNIN = false>
+template <typename T, int CT, int KC, int STAGES, int MINW, int PTL, int MODE, bool ROT = false, int WN = 2>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvParams p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int WP = 4 / WN;
     constexpr int CJ = CT / (32 * WN), PI = PTL / (32 * WP);
     static_assert(!ROT || WN == 2, "the rotated loop is written for the 2 x 2 arrangement");
-    static_assert(!BNIN || (WN == 1 && !ROT && !X3<T>::on && sizeof(T) == 2 && MODE == 0), "bn_in: the bf16 forward, one wavefront per pixel block");
-    __shared__ __attribute__((aligned(16))) float bntab[BNIN ? 2 * BNIN_MAX_K : 4];
     using S = SmemD<T, CT, KC, STAGES, PTL>;
     constexpr int KB = S::KB;
     constexpr int RPW = 1024 / KB;                 // rows per wave DMA instruction (8 or 16)
@@ -339,44 +333,6 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
             for (int pc = 0; pc < PER_STAGE; ++pc) issue_piece(pc, st);
         }
     }
-    if constexpr (BNIN) {
-        // train-mode finalize of the input's BatchNorm, as in bn_apply_kernel: fold the statistic replicas of every input channel;
-        // the workgroup of tile 0 publishes the constants and updates the running statistics
-        const vince_bn_train& fin = p.bnin;
-#ifdef BNIN_NO_FIN
-        for (int c = tid; c < d.Ci; c += 256) { bntab[c] = 1.f; bntab[BNIN_MAX_K + c] = 0.f; }
-        if (false)
-#endif
-        for (int c = tid; c < d.Ci; c += 256) {
-            double s1 = 0, s2 = 0;
-            for (int rr = 0; rr < fin.replicas; ++rr) {
-                s1 += fin.stats[((size_t)rr * d.Ci + c) * 2];
-                s2 += fin.stats[((size_t)rr * d.Ci + c) * 2 + 1];
-            }
-            const double cnt = (double)fin.count;
-            const double m = s1 / cnt;
-            double var = s2 / cnt - m * m;
-            if (var < 0) var = 0;
-            const float mean = (float)m;
-            const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
-            const float scv = fin.gamma[c] * invstd;
-            const float shv = fin.beta[c] - mean * scv;
-            bntab[c] = scv;
-            bntab[BNIN_MAX_K + c] = shv;
-            if (tile == 0) {
-                fin.scale[c] = scv;
-                fin.shift[c] = shv;
-                if (fin.save_mean) fin.save_mean[c] = mean;
-                if (fin.save_invstd) fin.save_invstd[c] = invstd;
-                if (fin.running_mean) {
-                    const double unbiased = cnt > 1 ? var * cnt / (cnt - 1) : var;
-                    fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * mean;
-                    fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
-                }
-                if (c == 0 && fin.num_batches_tracked) *fin.num_batches_tracked += 1;
-            }
-        }
-    }
     wait_vmcnt<(STAGES - 2) * PER_STAGE>();
     __syncthreads();
     const int sw = ((lane & 31) >> SWSH) & SWMASK, khalf = lane >> 5;
@@ -497,16 +453,6 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
             for (int j = 0; j < CJ; ++j) wf[j] = *(const uint4*)(ws + j * 32 * KB + slot);
 #pragma unroll
             for (int i = 0; i < PI; ++i) xf[i] = *(const uint4*)(xs + i * 32 * KB + slot);
-            if constexpr (BNIN) {
-                const int kb = (kt * KC + s * 2 + khalf) * 8;    // first input channel of this lane's fragment (1x1: k = channel)
-#pragma unroll
-                for (int i = 0; i < PI; ++i)
-#ifndef BNIN_NO_XFORM
-                    bn_in_apply(xf[i], bntab + kb, bntab + BNIN_MAX_K + kb);
-#else
-                    asm volatile("" ::"v"(kb));
-#endif
-            }
             if (IG_ABL(2)) {   // keep the LDS reads, drop the matrix work
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) asm volatile("" ::"v"(wf[j].x), "v"(wf[j].w));
@@ -580,18 +526,6 @@ __global__ void relu_inplace_kernel(float* x, size_t n4) {
         float4 v = ((float4*)x)[i];
         ((float4*)x)[i] = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     }
-}
-
-// vince_conv_epi.bn_in: the 1x1 bf16 forward whose input passes through a train-mode BatchNorm + ReLU in the operand path.  One
-// configuration: 128 x 128 tiles, 64-byte K rows, two stages, every wavefront over all 128 channels of 32 pixels.
-inline int launch_bnin(ConvParams& p, hipStream_t stream) {
-    p.uniform_taps = 1;
-    p.nkt = p.total_chunks / 4;
-    p.ptiles = (p.M + PT - 1) / PT;
-    p.ctiles = p.d.Co / 128;
-    hipLaunchKernelGGL((conv_igemm_dlds_kernel<bf16_t, 128, 4, 2, 3, PT, 0, false, 1, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
-    VINCE_CHECK_LAUNCH();
-    return VINCE_OK;
 }
 
 template <typename T, int CT, int MODE>

@@ -479,10 +479,9 @@ static int xj_num_cu() {
 
 extern "C" int vince_conv_expand_stats(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co, void* out,
                                        double* stats, int32_t replicas, void* stream) {
-    if (K == 256) return vince_conv_expand_stats_bn(dtype, x, w, rows, K, Co, out, stats, replicas, nullptr, stream);   // csrc/conv_xk.hip
     VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_expand_stats: bf16 only");
     VINCE_CHECK_ARG(x && w && out && rows > 0, VINCE_E_ARG, "vince_conv_expand_stats: null pointer");
-    VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_stats: K=%d (64, 128 or 256)", K);
+    VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_stats: K=%d (64 or 128)", K);
     VINCE_CHECK_ARG(Co > 0 && Co % XJ_CG == 0, VINCE_E_SHAPE, "vince_conv_expand_stats: Co=%d must be a multiple of %d", Co, XJ_CG);
     VINCE_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) == 0, VINCE_E_ALIGN, "vince_conv_expand_stats: pointers must be 16-byte aligned");
     const unsigned long long xb = (unsigned long long)rows * K * 2, wb = (unsigned long long)Co * K * 2;

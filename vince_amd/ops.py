@@ -128,9 +128,8 @@ def _conv_dtype(x, x3):
 
 
 def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None, replicas=0, out_scale=None,
-               id_scale=None, id_shift=None, out_mask=None, in2=None, x3=None, bn_in=None):
-    """vince_conv_igemm with the epilogue options of vince_conv_epi.  bn_in: a BnTrain (bn_train_arg) -- the input is read through
-    relu(bn(x)) with the batch statistics in it (vince_conv_epi.bn_in)."""
+               id_scale=None, id_shift=None, out_mask=None, in2=None, x3=None):
+    """vince_conv_igemm with the epilogue options of vince_conv_epi."""
     require_gpu(x, w, out, bias, stats, acc_mask, out_scale, id_scale, id_shift, out_mask, in2)
     e = ConvEpi()
     e.flags = flags
@@ -146,8 +145,6 @@ def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, b
     e.out_mask = None if out_mask is None else out_mask.data_ptr()
     if in2 is not None:     # the last tap reads this tensor (vince_conv_epi.in2)
         e.in2, e.in2_channels = in2.data_ptr(), in2.shape[-1]
-    if bn_in is not None:
-        e.bn_in = ctypes.addressof(bn_in)
     check(lib().vince_conv_igemm(ctypes.byref(desc), _conv_dtype(x, x3), _ptr(x), _ptr(w), _ptr(out), ctypes.byref(e),
                                  stream_ptr()))
     return out
@@ -167,15 +164,11 @@ def conv_expand_join(x, w, out_scale, out_shift, identity, out=None, id_scale=No
     return out
 
 
-def conv_expand_stats(x, w, out, stats=None, replicas=0, bn_in=None):
-    """out = x @ w.T (bf16, K = 64 / 128 / 256) through the streaming kernel, BatchNorm statistics of the stored values into stats
-    (double[R][Co][2], zeroed by the caller).  bn_in (K = 256): a BnTrain (bn_train_arg) -- x is read through relu(bn(x))."""
+def conv_expand_stats(x, w, out, stats=None, replicas=0):
+    """out = x @ w.T (bf16, K = 64 / 128, Co multiple of 256) through the streaming kernel, BatchNorm statistics of the stored
+    values into stats (double[R][Co][2], zeroed by the caller)."""
     require_gpu(x, w, out, stats)
     rows, K = x.numel() // x.shape[-1], x.shape[-1]
-    if bn_in is not None:
-        check(lib().vince_conv_expand_stats_bn(dtype_code(x), _ptr(x), _ptr(w), rows, K, w.shape[0], _ptr(out), _ptr(stats), replicas,
-                                               ctypes.addressof(bn_in), stream_ptr()))
-        return out
     check(lib().vince_conv_expand_stats(dtype_code(x), _ptr(x), _ptr(w), rows, K, w.shape[0], _ptr(out), _ptr(stats), replicas,
                                         stream_ptr()))
     return out
@@ -347,23 +340,6 @@ def bn_apply(y, scale, shift, identity=None, id_scale=None, id_shift=None, relu=
     check(lib().vince_bn_apply(dtype_code(y), _ptr(y), _ptr(scale), _ptr(shift), _ptr(identity), _ptr(id_scale),
                                _ptr(id_shift), _ptr(out), _ptr(mask), y.numel() // C, C, int(relu), stream_ptr()))
     return (out, mask) if want_mask else out
-
-
-def bn_train_arg(stats, count, gamma, beta, running_mean=None, running_var=None, nbt=None, replicas=0, momentum=0.1, eps=1e-5):
-    """A vince_bn_train for conv_igemm(bn_in=): returns (BnTrain, (scale, shift, mean, invstd)) -- the four output tensors the launch
-    publishes (keep both alive until the launch has been issued)."""
-    require_gpu(stats, gamma, beta, running_mean, running_var, nbt)
-    C = gamma.numel()
-    outs = tuple(torch.empty(C, device=gamma.device) for _ in range(4))
-    bt = BnTrain()
-    bt.stats, bt.replicas, bt.count = stats.data_ptr(), replicas, count
-    bt.gamma, bt.beta = gamma.data_ptr(), beta.data_ptr()
-    bt.running_mean = None if running_mean is None else running_mean.data_ptr()
-    bt.running_var = None if running_var is None else running_var.data_ptr()
-    bt.num_batches_tracked = None if nbt is None else nbt.data_ptr()
-    bt.momentum, bt.eps = momentum, eps
-    bt.scale, bt.shift, bt.save_mean, bt.save_invstd = (t.data_ptr() for t in outs)
-    return bt, outs
 
 
 def bn_train_apply(y, stats, count, gamma, beta, running_mean=None, running_var=None, nbt=None, identity=None, id_scale=None,
