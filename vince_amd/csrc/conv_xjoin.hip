@@ -405,35 +405,20 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         }
     };
 
-    if constexpr (DGRAD) {
-        // old gradient chunks one UNIT ahead (registers are shorter here: the reduction's operands live beside them)
+    {
+        // identity / old-gradient chunks one UNIT ahead of the unit being computed (four 16-byte chunks per lane in flight).  A whole tile
+        // ahead (round 2) held 64 registers for it and pushed every join instantiation over the 168 the nine-wavefront workgroup allows:
+        // 12-32 bytes of scratch per lane, and a scratch RELOAD waits for every older vector memory operation of the wavefront -- the
+        // output stores it has just issued -- once per unit.
         uint4 oA[2][2], oB[2][2];
         load_ids(oA, 0, 0);
         for (int t = 0; t < ntiles; ++t) {
             load_ids(oB, t, 1);
-            __builtin_amdgcn_s_barrier();                   // B(t)
+            __builtin_amdgcn_s_barrier();                   // B(t): the loader has seen tile t land
             run_unit(oA, t, 0);
             load_ids(oA, t + 1, 0);
             run_unit(oB, t, 1);
         }
-    } else {
-    // identity chunks one whole tile ahead (two units = 8 chunks per lane in flight beside the tile being computed)
-    uint4 idA[2][2][2], idB[2][2][2];
-    load_ids(idA[0], 0, 0);
-    load_ids(idA[1], 0, 1);
-    for (int t = 0; t < ntiles; t += 2) {
-        load_ids(idB[0], t + 1, 0);
-        load_ids(idB[1], t + 1, 1);
-        __builtin_amdgcn_s_barrier();                       // B(t): the loader has seen tile t land
-        run_unit(idA[0], t, 0);
-        run_unit(idA[1], t, 1);
-        if (t + 1 >= ntiles) break;                         // (uniform)
-        load_ids(idA[0], t + 2, 0);
-        load_ids(idA[1], t + 2, 1);
-        __builtin_amdgcn_s_barrier();                       // B(t + 1)
-        run_unit(idB[0], t + 1, 0);
-        run_unit(idB[1], t + 1, 1);
-    }
     }
     if constexpr (PLAIN || DGRAD) {
         if (DGRAD ? (p.br_sums != nullptr) : (p.stats != nullptr)) {
