@@ -39,6 +39,10 @@ timeout 300 python tools/x3_micro.py final > $O/x3_micro.txt 2>&1
 bash tools/fwd_pmc.sh $O/fwd_pmc > /dev/null 2>&1; cp $O/fwd_pmc/fwd_pmc_summary.txt $O/fwd_pmc_summary.txt
 timeout 300 python tools/ceilings.py > $O/ceilings.txt 2>&1
 timeout 120 python tools/strip_dgrad_micro.py > $O/strip_dgrad_micro.txt 2>&1
+timeout 300 python tools/xjoin_micro.py > $O/xjoin_micro.txt 2>&1
+timeout 200 python tools/dgrad_epi_micro.py > $O/dgrad_epi_micro.txt 2>&1
+# the full-size parity fixtures, with what each dtype measured against the reference printed (G9, G12: fp32 / x3 / bf16)
+timeout 1500 python -m pytest tests/test_full_size_gpu.py -q -s -k "g9 or g12" 2>&1 | grep -E "G9|G12|passed|failed" | cut -c1-600 > $O/full_size_parity.txt
 export VINCE_GIT_HEAD=${VINCE_GIT_HEAD:-unknown}
 # the bench line once more, now that profiles/pmc_conv_igemm.json of THIS build exists (traffic_stale false)
 cp $O/pmc_conv_igemm.json profiles/pmc_conv_igemm.json
