@@ -944,6 +944,32 @@ def test_conv_expand_dgrad_streaming_kernel(rows, K, Co, mode):
         np.testing.assert_allclose(a[1][:, 1].cpu().numpy(), (gg * xhat).sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3)
 
 
+def test_bf16_stores_round_to_nearest_even_like_the_reference():
+    """Every bf16 tensor the library stores goes through pack_bf16x2 = v_cvt_pk_bf16_f32 (csrc/common.h).  Its rounding against torch's
+    fp32 -> bfloat16 conversion (round to nearest even: what the reference's autocast-free bf16 tensors would hold), bit for bit, on random
+    bit patterns, every halfway case neighbourhood, denormals, the largest finite values (which round to infinity) and infinities --
+    through vince_bn_apply with y = 0, scale = 1, shift = the test values."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    bits = torch.randint(0, 2 ** 32, (1 << 16,), generator=g, dtype=torch.int64)
+    hi = torch.randint(0, 2 ** 16, (4096,), generator=g, dtype=torch.int64) << 16
+    edge = torch.cat([hi | lo for lo in (0x7fff, 0x8000, 0x8001, 0xffff, 0x0001, 0x0000)])
+    special = torch.tensor([0x00000001, 0x00008000, 0x00018000, 0x007fffff, 0x7f7fffff, 0x7f7f8000, 0x7f7f7fff, 0xff7fffff, 0x7f800000,
+                            0xff800000, 0x3f800000, 0x3f808000, 0x3f818000], dtype=torch.int64)
+    allbits = torch.cat([bits, edge, special])
+    vals = (allbits & 0xffffffff).to(torch.int64)
+    vals = torch.where(vals >= 2 ** 31, vals - 2 ** 32, vals).to(torch.int32).view(torch.float32)
+    vals = vals[~torch.isnan(vals)]
+    vals = vals[: vals.numel() // 8 * 8]
+    want = (torch.zeros_like(vals) + vals).bfloat16().view(torch.int16)                  # (0 + x: a negative zero enters as +0)
+    C = vals.numel()
+    y = torch.zeros(64, C, device=DEV, dtype=torch.bfloat16)
+    out = ops.bn_apply(y, torch.ones(C, device=DEV), vals.to(DEV), relu=False)
+    got = out.cpu().view(torch.int16)
+    assert torch.equal(got[0], want), int((got[0] != want).sum())
+    assert torch.equal(got[63], want)
+
+
 def test_nonfinite_loss_latch():
     """The per-iteration finite-loss assertion of the reference (solvers/vince_solver.py:446-452) as a device-side latch: finite
     values leave it alone, NaN / +-inf count and keep the FIRST offending step."""
