@@ -316,7 +316,13 @@ void wgrad_tr_tile(const WgradParams& p, int* ct, int* nt) {
 }
 
 int wgrad_tr_launch(const WgradParams& p, int ct, int nt, int splits, hipStream_t stream) {
-    static const int stages4 = (int)VINCE_MEASURE_KNOB("wgrad_stages", 3) == 4;
+    // Ring depth.  1x1 / stride 1 layers (one address step per slice, nothing else between the MFMAs): FOUR stages -- three slices in flight,
+    // two workgroups per CU instead of three -- 28x28 512<-128 66.1 -> 57.3 us, 128<-512 62.1 -> 56.3, the 14x14 and 7x7 pairs -4.5 / -5.5 %,
+    // layer1's HBM-bound pair -2 % (tools/wgrad_micro.py, round 4).  The multi-tap layers keep three: with four the 3x3 layers lose 13-16 %
+    // (85 -> 99 us on layer3's).  `wgrad_stages4_linear=0`: three everywhere (cross-check switch).
+    static const int stages_knob = (int)VINCE_MEASURE_KNOB("wgrad_stages", 0);
+    static const bool linear4 = vince_knob("wgrad_stages4_linear", 1) != 0;
+    const int stages4 = stages_knob ? stages_knob == 4 : (linear4 && p.linear_x);
 #define TR_CASE(C, N)                                                                                   \
     if (ct == C && nt == N) {                                                                           \
         if constexpr ((C + N) / 64 * SUB * 4 <= 163840) {                                               \
