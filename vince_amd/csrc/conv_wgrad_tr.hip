@@ -319,7 +319,9 @@ int wgrad_tr_launch(const WgradParams& p, int ct, int nt, int splits, hipStream_
     // Ring depth.  1x1 / stride 1 layers (one address step per slice, nothing else between the MFMAs): FOUR stages -- three slices in flight,
     // two workgroups per CU instead of three -- 28x28 512<-128 66.1 -> 57.3 us, 128<-512 62.1 -> 56.3, the 14x14 and 7x7 pairs -4.5 / -5.5 %,
     // layer1's HBM-bound pair -2 % (tools/wgrad_micro.py, round 4).  The multi-tap layers keep three: with four the 3x3 layers lose 13-16 %
-    // (85 -> 99 us on layer3's).  `wgrad_stages4_linear=0`: three everywhere (cross-check switch).
+    // (85 -> 99 us on layer3's).  `wgrad_stages4_linear=0`: three everywhere (cross-check switch).  (With four stages the 1x1 layers timed
+    // ALONE prefer 256 workgroups per launch to 512 -- 50 -> 42 us at 14x14, 58 -> 49 at 28x28 -- but inside the overlapped step that split
+    // is 0.05-0.09 ms SLOWER in two paired runs: one long-lived workgroup per CU holds its 64 KB of LDS against the chain's kernels.  512 stays.)
     static const int stages_knob = (int)VINCE_MEASURE_KNOB("wgrad_stages", 0);
     static const bool linear4 = vince_knob("wgrad_stages4_linear", 1) != 0;
     const int stages4 = stages_knob ? stages_knob == 4 : (linear4 && p.linear_x);
