@@ -332,6 +332,8 @@ def test_wgrad_suite_through_every_tile_of_the_transposing_kernel():
     for tile in (64064, 64128, 128064):
         _rerun_conv_tests({"VINCE_KNOBS": "wgrad_tile=%d" % tile}, sel)
     _rerun_conv_tests({"VINCE_KNOBS": "wgrad_tr=0"}, sel)
+    # the 1x1 layers run a four-stage ring by default (round 4); the three-stage instantiation they ran before stays selectable
+    _rerun_conv_tests({"VINCE_KNOBS": "wgrad_stages4_linear=0"}, sel + " or test_linear_fwd_bwd")
 
 
 def test_conv_suite_through_whole_line_k_rows():
