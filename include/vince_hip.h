@@ -48,6 +48,10 @@ extern "C" {
 #define VINCE_F32X3 VINCE_F32X3H
 
 const char* vince_last_error(void);
+/* Bumped whenever an exported signature, a struct layout or a dtype code changes.  vince_abi_version() returns the value the library
+ * was BUILT with; a binding compares it at load (vince_amd/_lib.py: a stale .so behind VINCE_HIP_LIB would otherwise be called with
+ * shifted arguments). */
+#define VINCE_ABI_VERSION 5
 int vince_abi_version(void);
 
 /* Measurement aid (bench.py): while enabled, every conv_igemm / conv_wgrad launch is bracketed by a hipEvent pair on

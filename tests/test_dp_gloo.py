@@ -187,7 +187,7 @@ def _save_case(rank, world):
     d = os.path.join(tempfile.gettempdir(), "vince_save_case_%s" % os.environ["MASTER_PORT"])
     calls = []
     model = types.SimpleNamespace(save=lambda it, keep: calls.append((it, keep)))
-    stub = types.SimpleNamespace(model=model, iteration=512, check_loss_latch=lambda: None)
+    stub = types.SimpleNamespace(model=model, iteration=512, check_loss_latch=lambda **kw: None)
     VinceSolver.save(stub, 5)
     return calls
 
@@ -201,7 +201,7 @@ def _final_save_case(rank, world):
     from vince_amd.solvers.vince_solver import VinceSolver
     calls = []
     model = types.SimpleNamespace(save=lambda it, keep: calls.append((it, keep)))
-    stub = types.SimpleNamespace(model=model, iteration=7, check_loss_latch=lambda: None)
+    stub = types.SimpleNamespace(model=model, iteration=7, check_loss_latch=lambda **kw: None)
     t = torch.ones(4)
     if rank == 1:
         VinceSolver.save(stub)          # the failing rank's `finally`
@@ -230,16 +230,21 @@ def _latched_save_case(rank, world):
     calls = []
     model = types.SimpleNamespace(save=lambda it, keep: calls.append((it, keep)), device=torch.device("cpu"))
 
-    def latch():
-        if rank == 1:
-            raise AssertionError("non-finite loss in 1 iteration(s), first at iteration 3")
-    stub = types.SimpleNamespace(model=model, iteration=64, check_loss_latch=latch)
+    # the solver's own latch check on a device-side latch only rank 1 has tripped (first offending iteration 3, stored + 1)
+    stub = types.SimpleNamespace(model=model, iteration=64, _loss_latch=torch.tensor([1 if rank == 1 else 0, 4 if rank == 1 else 0]))
+    stub.check_loss_latch = lambda *a, **kw: VinceSolver.check_loss_latch(stub, *a, **kw)
     try:
         VinceSolver.save(stub, 5, sync=True)
         raised = None
     except AssertionError as e:
         raised = str(e)
-    return calls, raised
+    # the same shared verdict at the other two points every rank reaches together (log iterations, the epoch boundary)
+    try:
+        stub.check_loss_latch({"nce_loss": 1.0}, shared=True)
+        raised_log = None
+    except AssertionError as e:
+        raised_log = str(e)
+    return calls, raised, raised_log
 
 
 def test_periodic_save_refuses_a_model_that_took_nan_steps_on_every_rank():
@@ -247,6 +252,8 @@ def test_periodic_save_refuses_a_model_that_took_nan_steps_on_every_rank():
     assert out[0][0] == [] and out[1][0] == []
     assert out[0][1] is not None and "another rank" in out[0][1]
     assert out[1][1] is not None and "first at iteration 3" in out[1][1]
+    assert out[0][2] is not None and "another rank" in out[0][2]
+    assert out[1][2] is not None and "first at iteration 3" in out[1][2]
 
 
 def _samples_case(rank, world):

@@ -373,7 +373,8 @@ def test_g12_config3_full_size_centred_head_vs_reference(tmp_path, golden_dir, d
     if dtype == "bf16":
         # REPORTED, bounded at 1.5 x the values measured on MI355X: loss 7.9e-4 (inside the 1e-3 loss bar on a spread-out encoder at the
         # real size), embeddings 5.4e-1 / keys 5.2e-1 of max |e|, min cosine 0.842
-        assert e_loss < 1.2e-3 and e_emb < 0.82 and e_key < 0.78 and cos > 0.76
+        # ... and the LOSS is held AT the north-star bar (1e-3), not above it
+        assert e_loss < 1e-3 and e_emb < 0.82 and e_key < 0.78 and cos > 0.76
         return
     assert e_loss < 1e-3 and e_emb < 1e-3 and e_key < 1e-3 and e_pre < 1e-3
     for k in ("nce_accuracy_mean", "cosine_sim", "cosine_sim_neg_max", "nce_softmax_weight_mean"):

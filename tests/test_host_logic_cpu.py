@@ -34,6 +34,21 @@ def test_queue_index_arithmetic_bit_exact_vs_reference_golden(name):
     assert enqueue_segments(8, 1, 8) == ([(0, 0, 1)], 1, True)        # ... the next write does
 
 
+def test_queue_index_closed_form_equals_the_oracles_loop():
+    """Two independent formulations of storage_queue.py:31-49 -- the product's closed-form modular arithmetic and the oracle's restated
+    recursion -- on every (tail, n, K) of a small exhaustive grid (tail AT maxsize, n = 0, exact fits, several laps) and a random
+    sweep at the real queue size."""
+    for K in (1, 2, 3, 7, 8):
+        for tail in range(K + 1):
+            for n in range(4 * K + 3):
+                assert enqueue_segments(tail, n, K) == vo.enqueue_segments(tail, n, K), (tail, n, K)
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        K = 65536
+        tail, n = int(rng.integers(0, K + 1)), int(rng.integers(0, 5 * K))
+        assert enqueue_segments(tail, n, K) == vo.enqueue_segments(tail, n, K), (tail, n, K)
+
+
 def test_state_dict_layout_matches_reference_and_loads_strictly():
     from vince_amd.config import make_args
     from vince_amd.models.vince_model import VinceModel

@@ -426,7 +426,10 @@ def test_g13_config5_multiframe_jigsaw_vs_reference_golden(dtype, coin):
           % (coin, dtype, e_terms, "  ".join("%s %.2e" % kv for kv in errs.items()), float(np.median(list(ratios.values()))),
              max(ratios.values()), max(ratios, key=ratios.get)))
     if dtype == "bf16":
-        assert np.isfinite(e_terms) and e_terms < 0.2     # reported
+        # REPORTED, bounded at 1.5 x what was measured on MI355X: loss terms 1.6e-3 (key side jigsawed) /
+        # 3.9e-3 (query side), embeddings 1e-1 / 2e-1 of max |e| -- a bf16 config-5 loss that drifts further is a regression
+        assert np.isfinite(e_terms) and e_terms < 6e-3, e_terms
+        assert max(errs.values()) < 0.3, errs
         return
     assert e_terms < 1e-3 and max(errs.values()) < 1e-3, (e_terms, errs)
     np.testing.assert_allclose([float(met[k]) for k in sorted(met)], g[p + "metrics"], rtol=2e-3, atol=2e-4)

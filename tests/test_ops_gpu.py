@@ -972,6 +972,23 @@ def test_bf16_stores_round_to_nearest_even_like_the_reference():
     assert torch.equal(got[63], want)
 
 
+@pytest.mark.parametrize("pieces", [1, 2, 3, 1023, 4097, 65537])
+def test_stream_copy_copies_every_byte(pieces):
+    """The library's own copy kernel (the streaming ceiling of bench.py's roofline leg) in every shape, on piece counts that are odd /
+    below one wavefront / ragged against the grid: each shape must move ALL bytes (the 32-bytes-per-lane shape dropped
+    the last 16-byte piece of an odd count)."""
+    from vince_amd import _lib
+    L = _lib.lib()
+    nbytes = pieces * 16
+    src = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    for mode in range(6):        # bit 0 = non-temporal; bits 1-2 = shape
+        for blocks in (1, 7, 64):
+            dst = torch.zeros_like(src)
+            _lib.check(L.vince_stream_copy(dst.data_ptr(), src.data_ptr(), nbytes, blocks, mode, st))
+            assert torch.equal(dst, src), (mode, blocks)
+
+
 def test_nonfinite_loss_latch():
     """The per-iteration finite-loss assertion of the reference (solvers/vince_solver.py:446-452) as a device-side latch: finite
     values leave it alone, NaN / +-inf count and keep the FIRST offending step."""

@@ -53,6 +53,32 @@ def test_x3h_forward_conv_is_as_good_as_fp32(cfg, xscale):
     np.testing.assert_allclose(stats.sum(0)[:, 0].cpu().numpy(), o.sum(0).numpy(), rtol=1e-5, atol=1e-3 * xscale)
 
 
+def test_x3h_operands_past_the_half_range_fail_loudly():
+    """The IEEE-half split scales activations by 2^4 and weights by 2^8 (csrc/common.h X3_XSHIFT / X3_WSHIFT).  Just inside the range
+    (|x| = 4000, |w| = 250) the product is still fp32-grade; past it (|x| >= 4095, |w| * 2^8 >= 65520 -- e.g. a folded eval weight
+    w * gamma * invstd with a near-zero running variance) the result must be NaN / inf, never a finite saturated number."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, p = 2, 8, 8, 64, 64, 1, 1, 0
+    d = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / Ci) ** 0.5)
+    x = rnd(N, Ci, H, W, seed=1)
+    x = x / x.abs().max()
+
+    def run(xx, ww):
+        wk3, _ = weights_krsc(ww, torch.float32, x3=True)
+        out = torch.empty(N, d.Ho, d.Wo, Co, device=DEV)
+        ops.conv_igemm(d, to_nhwc(xx, torch.float32), wk3, out, x3="h")
+        return from_nhwc(out)
+
+    ok = run(x * 4000.0, w)
+    assert _err(ok, F.conv2d(x.double() * 4000.0, w.double())) < 4e-6
+    assert not torch.isfinite(run(x * 4200.0, w)).all(), "an activation past 65520 / 2^4 must not saturate silently"
+    wbig = w / w.abs().max()
+    okw = run(x, wbig * 250.0)
+    assert _err(okw, F.conv2d(x.double(), wbig.double() * 250.0)) < 4e-6
+    assert not torch.isfinite(run(x, wbig * 300.0)).all(), "a weight past 65520 / 2^8 must not saturate silently"
+
+
 @pytest.mark.parametrize("cfg", CONVS)
 def test_x3b_gradients_vs_fp64(cfg):
     """Input and weight gradients through bfloat16 hi / lo halves (fp32's exponent range: dy of order 1e-6 here) against fp64 autograd:

@@ -163,6 +163,10 @@ PROTOTYPES = {
 _LIB = None
 
 
+# include/vince_hip.h VINCE_ABI_VERSION (tests/test_abi_cpu.py holds the two together)
+ABI_VERSION = 5
+
+
 def lib():
     """The loaded library.  Raises if it has not been built (python -m vince_amd.build)."""
     global _LIB
@@ -180,6 +184,10 @@ def lib():
             fn = getattr(L, name)   # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        built = L.vince_abi_version()
+        if built != ABI_VERSION:
+            raise RuntimeError("vince_amd: %s was built with ABI version %d, these bindings are version %d -- rebuild "
+                               "(python -m vince_amd.build --force)" % (getattr(L, "_name", LIB_PATH), built, ABI_VERSION))
         _LIB = L
     return _LIB
 

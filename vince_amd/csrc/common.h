@@ -176,6 +176,7 @@ constexpr int X3_XSHIFT = 4;   // activations: |x| < 2^(16 - 4); lo normal down 
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(2))) __fp16 fp16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16v8_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16v2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -184,9 +185,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 template <typename T, bool WEIGHT> __device__ __forceinline__ void x3_split_pair(float x0, float x1, uint32_t& h, uint32_t& l) {
     if constexpr (X3<T>::half) {
         constexpr float K = (float)(1 << (WEIGHT ? X3_WSHIFT : X3_XSHIFT));
-        const float a = x0 * K, b = x1 * K;
-        const fp16x2_t hp = __builtin_amdgcn_cvt_pkrtz(a, b);          // hi by truncation: a - hi is exact in fp32
-        const fp16x2_t lp = __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]);
+        // Both halves by v_cvt_pk_f16_f32 (round to nearest even, OVERFLOW -> INF): a - hi is exact in fp32 either way, and a scaled
+        // operand past the half range (|x| >= 65520 / 2^shift) becomes inf - inf = NaN in the products -- loud, where the
+        // round-toward-zero conversion saturated both halves at 65504 and produced a finite, silently wrong result.
+        const f32x2_t ab = {x0 * K, x1 * K};
+        const f16x2v_t hp = __builtin_convertvector(ab, f16x2v_t);
+        const f32x2_t res = {ab[0] - (float)hp[0], ab[1] - (float)hp[1]};
+        const f16x2v_t lp = __builtin_convertvector(res, f16x2v_t);
         __builtin_memcpy(&h, &hp, 4);
         __builtin_memcpy(&l, &lp, 4);
     } else {

@@ -40,7 +40,7 @@ long vince_measure_knob(const char* name, long dflt) {   // measurement build: V
 #endif
 
 extern "C" const char* vince_last_error(void) { return g_err; }
-extern "C" int vince_abi_version(void) { return 1; }
+extern "C" int vince_abi_version(void) { return VINCE_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Per-kernel event timing (bench.py's roofline leg): while enabled, the instrumented launchers bracket every launch

@@ -692,13 +692,16 @@ __global__ __launch_bounds__(256) void stream_copy_shape_kernel(const f32x4_t* _
     auto st = [&](size_t k, f32x4_t v) { if (NT) __builtin_nontemporal_store(v, dst + k); else dst[k] = v; };
     if constexpr (SHAPE == 1) {
         const size_t stride = (size_t)gridDim.x * 512;     // 16-byte pieces per grid pass
-        for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2; i + 1 < n16; i += 2 * stride) {
-            const bool two = i + stride + 1 < n16;
+        for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2; i < n16; i += 2 * stride) {
+            if (i + 1 >= n16) { st(i, ld(i)); break; }     // an odd piece count: the last 16 bytes travel alone
+            const size_t j = i + stride;
+            const bool two = j + 1 < n16;
             const f32x4_t a0 = ld(i), a1 = ld(i + 1);
             f32x4_t b0, b1;
-            if (two) { b0 = ld(i + stride); b1 = ld(i + stride + 1); }
+            if (two) { b0 = ld(j); b1 = ld(j + 1); }
             st(i, a0); st(i + 1, a1);
-            if (two) { st(i + stride, b0); st(i + stride + 1, b1); }
+            if (two) { st(j, b0); st(j + 1, b1); }
+            else if (j < n16) st(j, ld(j));
         }
     } else {
         const size_t per = ((n16 + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;

@@ -49,7 +49,13 @@ struct Blk {
 
 constexpr size_t NONE = (size_t)-1;
 // Gram-statistics residual join: conv3 reductions up to this length; replicas of the column sums
-constexpr int GRAM_MAX_K = 128, GRAM_R = 4;
+constexpr int GRAM_R = 4;
+// (knob `gram_max_k`: 256 also sends layer3's bottlenecks down the Gram route in no-grad forwards -- the Gram matrix through the
+// weight-gradient launch, the finalize reading it from L2, the join in the implicit-GEMM kernel's epilogue)
+int gram_max_k() {
+    static const int k = (int)vince_knob("gram_max_k", 128);
+    return k;
+}
 constexpr int NDY_MAX = 8;          // most slots the dY ring of the backward pass can be given (VINCE_KNOBS=dy_slots)
 
 }  // namespace
@@ -329,7 +335,7 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
     t->off_gram = P.ws;
     for (Blk& b : t->blocks) {
         b.gram = b.colsum = NONE;
-        if (b.nconv == 3 && b.c[2].Ci <= GRAM_MAX_K) {
+        if (b.nconv == 3 && b.c[2].Ci <= gram_max_k()) {
             b.gram = P.ws; P.ws = align_up(P.ws + (size_t)b.c[2].Ci * b.c[2].Ci * sizeof(float));
             b.colsum = P.ws; P.ws = align_up(P.ws + (size_t)GRAM_R * b.c[2].Ci * sizeof(double));
         }

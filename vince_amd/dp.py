@@ -121,17 +121,24 @@ class GradientReducer:
             return
         # ONE collective per step over every extra parameter, whether or not this rank's batch gave it a gradient (a rank whose batch
         # carried no labelled data contributes zeros): the collective sequence can then never differ between ranks
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in extra])
+        # One "touched" flag per parameter rides at the end of the same buffer: a parameter NO rank produced a gradient for keeps
+        # grad = None, so that the optimiser skips it exactly as a single-process run does (torch SGD applies weight decay and
+        # momentum to a zero gradient, but not to a missing one -- ADVICE r4)
+        dev = extra[0].device
+        touched = torch.tensor([0.0 if p.grad is None else 1.0 for p in extra], device=dev)
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in extra] + [touched])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        any_touched = (flat[-len(extra):] > 0).tolist()      # (one host read per step, only when side decoders exist)
         flat.div_(w)
         off = 0
-        for p in extra:
+        for p, hit in zip(extra, any_touched):
             n = p.numel()
-            g = flat[off:off + n].view_as(p).to(p.dtype)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
+            if hit:
+                g = flat[off:off + n].view_as(p).to(p.dtype)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
             off += n
 
     def reduce_after_backward(self):

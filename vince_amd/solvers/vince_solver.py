@@ -229,7 +229,8 @@ class VinceSolver(BaseSolver):
                 "num_frames": num_frames, "batch_type": "images", "batch_size": data.shape[0]}
 
     def reset_epoch(self):
-        self.check_loss_latch()    # (once per epoch: the loaders' epoch boundary synchronises anyway)
+        # (once per epoch: the loaders' epoch boundary synchronises anyway; every rank gets here together, so the verdict is shared)
+        self.check_loss_latch(shared=True)
         super().reset_epoch()
         self.queue_model.train()   # the key encoder never leaves train mode (vince_solver.py:337)
         self.drawn_this_epoch = False
@@ -308,18 +309,7 @@ class VinceSolver(BaseSolver):
         # The reference asserts a finite loss BEFORE every backward (vince_solver.py:446), so what it saves is always finite; here the
         # check is a device-side latch, read now: a model that has taken NaN steps is not written (and old checkpoints are not pruned).
         # Under sync every rank reaches this point, so the verdict is shared first -- one rank raising alone would strand its peers.
-        bad = None
-        try:
-            self.check_loss_latch()
-        except AssertionError as e:
-            bad = e
-        if w > 1 and sync:
-            flag = torch.tensor([1.0 if bad is not None else 0.0], device=self.model.device)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-            if bad is None and float(flag) > 0:
-                bad = AssertionError("non-finite loss on another rank")
-        if bad is not None:
-            raise bad
+        self.check_loss_latch(shared=sync)
         if r == 0:
             self.model.save(self.iteration, num_to_keep)
         if w > 1 and sync:
@@ -343,14 +333,24 @@ class VinceSolver(BaseSolver):
             self._loss_latch = torch.zeros(2, dtype=torch.int64, device=loss.device)
         ops.nonfinite_latch(loss.detach().float().reshape(1), self.iteration, self._loss_latch)
 
-    def check_loss_latch(self, context=None):
-        """Host side of the per-iteration finite-loss check: raises with the FIRST offending iteration (synchronises)."""
-        if self._loss_latch is None:
-            return
-        n, first = (int(v) for v in self._loss_latch.tolist())
-        if n:
-            raise AssertionError("non-finite loss in %d iteration(s), first at iteration %d%s"
-                                 % (n, first - 1, "" if context is None else " (now: %r)" % (context,)))
+    def check_loss_latch(self, context=None, shared=False):
+        """Host side of the per-iteration finite-loss check: raises with the FIRST offending iteration (synchronises).
+        shared=True -- only at points EVERY rank reaches at the same iteration (log iterations, the epoch boundary, the periodic
+        save): the verdict is MAX-reduced over the ranks first, so that all of them raise together; a rank raising alone would leave
+        its peers blocked in the next gradient all-reduce / key all-gather."""
+        bad = None
+        if self._loss_latch is not None:
+            n, first = (int(v) for v in self._loss_latch.tolist())
+            if n:
+                bad = AssertionError("non-finite loss in %d iteration(s), first at iteration %d%s"
+                                     % (n, first - 1, "" if context is None else " (now: %r)" % (context,)))
+        if shared and dp.world()[0] > 1:
+            flag = torch.tensor([1.0 if bad is not None else 0.0], device=self.model.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if bad is None and float(flag) > 0:
+                bad = AssertionError("non-finite loss on another rank")
+        if bad is not None:
+            raise bad
 
     def run_train_iteration(self):
         began = time.time()
@@ -444,7 +444,7 @@ class VinceSolver(BaseSolver):
             # the only host synchronisation of the step: scalar read-back for the meters (the reference's
             # assert torch.isfinite(loss), vince_solver.py:446, synchronises every step)
             vals = {k: float(v.detach()) for k, v in loss_dict.items()}
-            self.check_loss_latch(vals)
+            self.check_loss_latch(vals, shared=True)
             for name, v in vals.items():
                 self.loss_meters[name].update(v)
             if "total_loss" in self.loss_meters:       # (a meter the reference keeps beside the named terms)
