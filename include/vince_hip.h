@@ -51,7 +51,7 @@ const char* vince_last_error(void);
 /* Bumped whenever an exported signature, a struct layout or a dtype code changes.  vince_abi_version() returns the value the library
  * was BUILT with; a binding compares it at load (vince_amd/_lib.py: a stale .so behind VINCE_HIP_LIB would otherwise be called with
  * shifted arguments). */
-#define VINCE_ABI_VERSION 5
+#define VINCE_ABI_VERSION 6
 int vince_abi_version(void);
 
 /* Measurement aid (bench.py): while enabled, every conv_igemm / conv_wgrad launch is bracketed by a hipEvent pair on
@@ -579,6 +579,12 @@ int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, const float*
  * recorded -- the data-parallel layer enqueues that bucket's gradient all-reduce behind the event at that moment, while the host is
  * still enqueueing the rest of backward (vince_amd/dp.py).  NULL clears it. */
 int vince_trunk_set_bucket_callback(vince_trunk_t t, void (*cb)(int32_t, void*), void* user);
+/* Deferred stem join.  With a hipEvent_t set here, vince_trunk_backward returns with `stream` waiting for every weight gradient
+ * EXCEPT conv1's (resnet.py:170; the last launch of backward, ~200 us alone on the machine at ResNet-50 / B = 256) and records the
+ * event behind that launch instead: the gradient of params[0] is final only after the event; everything else as before.  The caller
+ * steps every other parameter while the stem's weight gradient runs (optim.FlatSGD.step(defer_stem=True)).  NULL (default): the
+ * stream waits for all of them. */
+int vince_trunk_set_stem_event(vince_trunk_t t, void* event);
 /* grads: float pointers parallel to params (accumulated into; zero them first).  dpooled: float[N][C].
  * Gradient buckets for data parallelism: after the backward of residual block event_blocks[e] (blocks are numbered in
  * forward order; backward visits them last to first) has been enqueued, hipEvent_t events[e] is recorded on `stream`;

@@ -666,6 +666,48 @@ def test_solver_runs_and_advances_queue():
     assert set(met.keys()) == {"nce_accuracy_mean", "nce_softmax_weight_mean", "cosine_sim", "cosine_sim_neg_max"}
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_deferred_stem_join_steps_the_same_parameters(dtype, monkeypatch):
+    """The solver's default single-process step leaves backward before conv1's weight gradient has landed and steps / averages
+    conv1.weight behind an event (engine deferred stem join, FlatSGD.step(defer_stem=True), VinceQueueModel.param_update).  The
+    joined order (VINCE_DEFER_STEM=0) must produce the same parameters: three steps of both from the same seeds, query and key
+    encoder compared tensor by tensor (fp32 weight gradients are summed with float atomics, hence a tolerance; a conv1.weight that
+    missed its step, or was stepped with a partial gradient, is off by the whole update)."""
+    from vince_amd.config import make_args
+    from vince_amd.data_source import SyntheticFrames
+    from vince_amd.solvers.vince_solver import VinceSolver
+
+    def run(defer):
+        monkeypatch.setenv("VINCE_DEFER_STEM", "1" if defer else "0")
+        torch.manual_seed(11)
+        args = make_args(backbone="ResNet18", batch_size=16, vince_queue_size=64, input_size=(64, 64), compute_dtype=dtype,
+                         batch_source=SyntheticFrames(16, 64, 64, 1, device=DEV, seed=5, iterations=10 ** 6), base_lr=0.03)
+        solver = VinceSolver(args)
+        assert solver.defer_stem == defer and solver.model.defer_stem_join == defer
+        solver.reset_epoch()
+        before = solver.model.feature_extractor.model.trunk_params[0].detach().clone()
+        for _ in range(3):
+            solver.run_train_iteration()
+            assert solver.model._deferred_step is None and not solver.model._stem_pending     # nothing left for later
+        torch.cuda.synchronize()
+        q = {n: p.detach().float().cpu().clone() for n, p in solver.model.named_parameters()}
+        k = {n: p.detach().float().cpu().clone() for n, p in solver.queue_model.queue_network.named_parameters()}
+        moved = float((solver.model.feature_extractor.model.trunk_params[0].detach() - before).abs().max())
+        return q, k, moved
+
+    qa, ka, moved_a = run(True)
+    qb, kb, moved_b = run(False)
+    assert moved_a > 0 and moved_b > 0
+    tol = 2e-4 if dtype == "fp32" else 2e-2
+    for name in qa:
+        scale = float(qb[name].abs().max()) + 1e-12
+        assert float((qa[name] - qb[name]).abs().max()) / scale < tol, name
+        assert float((ka[name] - kb[name]).abs().max()) / (float(kb[name].abs().max()) + 1e-12) < tol, name
+    conv1 = "feature_extractor.model.conv1.weight"
+    step = float((qa[conv1] - qb[conv1]).abs().max())
+    assert step < 0.05 * moved_b, (step, moved_b)      # the two orders agree far inside one update of conv1.weight
+
+
 def test_solver_c5_mode_jigsaw_multiframe_and_val():
     """Config C5's mode at toy size: 4 frames per clip, inter-batch + self-batch positives, jigsaw head, then run_val."""
     from vince_amd.config import make_args

@@ -100,6 +100,9 @@ struct vince_trunk {
     // host callback of vince_trunk_backward: invoked right after bucket event e has been recorded (vince_trunk_set_bucket_callback)
     void (*bucket_cb)(int32_t, void*) = nullptr;
     void* bucket_cb_user = nullptr;
+    // vince_trunk_set_stem_event: the caller's stream leaves backward WITHOUT waiting for the stem's weight gradient (the last launch of
+    // the step, alone on the machine); this event is recorded behind it instead
+    hipEvent_t stem_event = nullptr;
 };
 
 namespace {
@@ -429,6 +432,11 @@ extern "C" int vince_trunk_set_bucket_callback(vince_trunk_t t, void (*cb)(int32
     VINCE_CHECK_ARG(t, VINCE_E_ARG, "vince_trunk_set_bucket_callback: null handle");
     t->bucket_cb = cb;
     t->bucket_cb_user = user;
+    return VINCE_OK;
+}
+extern "C" int vince_trunk_set_stem_event(vince_trunk_t t, void* event) {
+    VINCE_CHECK_ARG(t, VINCE_E_ARG, "vince_trunk_set_stem_event: null handle");
+    t->stem_event = (hipEvent_t)event;
     return VINCE_OK;
 }
 extern "C" int32_t vince_trunk_num_params(vince_trunk_t t) { return t ? t->nparams : 0; }
@@ -1299,11 +1307,24 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             RC(bn_bwd(c, sb, DA, nullptr, false, t->off_ystem, (int64_t)N * t->sH * t->sW, DY, nullptr, grads));
         }
     }
+    if (t->stem_event && overlap) {
+        // Deferred stem join (vince_trunk_set_stem_event): the caller's stream waits for every weight gradient BUT the stem's -- whatever
+        // it enqueues next (the optimiser over every other parameter, the key encoder's EMA) runs beside that launch, which is
+        // otherwise alone on the machine at the very end of the step (~200 us at ResNet-50, B = 256) -- and the stem's gradient is
+        // final once stem_event has passed.  Its dY slot stays marked pending, so the next backward still waits before reusing it.
+        VINCE_CHECK_HIP(hipEventRecord(t->ev_join, t->side));
+        VINCE_CHECK_HIP(hipStreamWaitEvent(main_s, t->ev_join, 0));
+        for (int i = 0; i < t->ndy; ++i) t->wg_pending[i] = false;
+        RC(wgrad_async(stem_desc(t), at(workspace, t->off_x0), grads[t->stem.param], 3));
+        VINCE_CHECK_HIP(hipEventRecord(t->stem_event, t->side));
+        return VINCE_OK;
+    }
     RC(wgrad_async(stem_desc(t), at(workspace, t->off_x0), grads[t->stem.param], 3));
     if (overlap) {   // the caller's stream continues only after every weight gradient has landed
         VINCE_CHECK_HIP(hipEventRecord(t->ev_join, t->side));
         VINCE_CHECK_HIP(hipStreamWaitEvent(main_s, t->ev_join, 0));
         for (int i = 0; i < t->ndy; ++i) t->wg_pending[i] = false;
     }
+    if (t->stem_event) VINCE_CHECK_HIP(hipEventRecord(t->stem_event, main_s));   // (streams serialised: already final here)
     return VINCE_OK;
 }

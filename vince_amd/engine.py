@@ -146,6 +146,10 @@ class Trunk:
                                          ctypes.c_void_p(workspace.data_ptr()), ctypes.c_void_p(dpooled.data_ptr()),
                                          grad_ptrs, blocks, events, n, ops.stream_ptr()))
 
+    def set_stem_event(self, event):
+        """torch.cuda.Event (already recorded once, so its handle exists) or None: see include/vince_hip.h vince_trunk_set_stem_event."""
+        check(lib().vince_trunk_set_stem_event(self._h, None if event is None else ctypes.c_void_p(event.cuda_event)))
+
     def set_bucket_callback(self, fn):
         """fn(e) is called from inside backward() right after bucket event e has been recorded (None clears it)."""
         if fn is None:

@@ -252,6 +252,11 @@ class VinceModel(BaseModel):
         self._bn_version, self._fold_version, self._wcache_folded = 0, None, None
         self._grad_zero_pending = True
         self._flat = self._flat_grad = None
+        # Deferred stem join (engine.Trunk.set_stem_event; opt-in, VinceSolver sets it for single-process runs): backward returns
+        # before conv1's weight gradient -- the last launch of the step -- has landed; FlatSGD.step(defer_stem=True) and
+        # VinceQueueModel.param_update step / average every OTHER parameter beside it and conv1.weight behind the event.
+        self.defer_stem_join = False
+        self._stem_event, self._stem_pending, self._deferred_step = None, False, None
         self._build_flat()
 
     # ------------------------------------------------------------------------------------------ flat storage
@@ -345,6 +350,7 @@ class VinceModel(BaseModel):
         self._param_version += 1
 
     def zero_grad(self, set_to_none=True):
+        self.finish_deferred_step()
         self._grad_zero_pending = True
         self._touched = {"trunk": False, "embedding": False, "jigsaw": False}
         if hasattr(self, "imagenet_decoders"):
@@ -382,6 +388,7 @@ class VinceModel(BaseModel):
         return t
 
     def _ensure_weights(self, trunk):
+        self.finish_deferred_step()
         if self._wcache is None:
             self._wcache = torch.empty(trunk.wc_bytes, dtype=torch.uint8, device=self._flat.device)
         if self._wcache_version != self._param_version:
@@ -511,8 +518,27 @@ class VinceModel(BaseModel):
         self._touched["trunk"] = True
         # data parallel: the reducer's hook runs inside the engine call, right after each bucket's event is recorded
         s["trunk"].set_bucket_callback(self._bucket_hook if self._bucket_events else None)
+        defer = self.defer_stem_join and not self._bucket_events
+        if defer and self._stem_event is None:
+            self._stem_event = torch.cuda.Event()
+            self._stem_event.record()            # (torch creates the hipEvent lazily; the engine needs a live handle)
+        s["trunk"].set_stem_event(self._stem_event if defer else None)
         s["trunk"].backward(self._param_ptrs, self._wcache, self._saved_ws, dpool_total.contiguous(), self._grad_ptrs,
                             bucket_events=self._bucket_events)
+        self._stem_pending = defer
+
+    def finish_stem_grad(self):
+        """Makes the current stream wait for conv1's weight gradient of the last backward (no-op unless defer_stem_join is on)."""
+        if self._stem_pending:
+            torch.cuda.current_stream().wait_event(self._stem_event)
+            self._stem_pending = False
+
+    def finish_deferred_step(self):
+        """Runs what FlatSGD.step(defer_stem=True) left for later: the optimiser step of conv1.weight behind the stem event."""
+        fn, self._deferred_step = self._deferred_step, None
+        if fn is not None:
+            fn()
+        self.finish_stem_grad()
 
     def _run_encoder(self, data, jigsaw=False, orders=None, with_head=True):
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.feature_extractor.model.trunk_params)
@@ -716,7 +742,15 @@ class VinceQueueModel(BaseModel):
         with torch.no_grad():
             kflat, _, _, n_ema = self.queue_network.flat_parameters()
             qflat, _, _, _ = encoder_model.flat_parameters()
-            ops.ema_flat(kflat[:n_ema], qflat[:n_ema], float(momentum))
+            if getattr(encoder_model, "_deferred_step", None) is not None:
+                # the optimiser left conv1.weight (flat range [0, n1)) for behind the stem event: average everything else now, beside
+                # the stem's weight gradient, then finish that step and average the first range
+                n1 = encoder_model._offs[1]
+                ops.ema_flat(kflat[n1:n_ema], qflat[n1:n_ema], float(momentum))
+                encoder_model.finish_deferred_step()
+                ops.ema_flat(kflat[:n1], qflat[:n1], float(momentum))
+            else:
+                ops.ema_flat(kflat[:n_ema], qflat[:n_ema], float(momentum))
         self.queue_network._touch()
 
     def vince_update(self, encoder_model):

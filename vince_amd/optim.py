@@ -31,7 +31,11 @@ class FlatSGD:
     def zero_grad(self, set_to_none=True):
         self.model.zero_grad()
 
-    def step(self):
+    def step(self, defer_stem=False):
+        """defer_stem=True (VinceSolver's loop; only meaningful when the model runs with defer_stem_join): every parameter but
+        conv1.weight is stepped now -- beside the stem's weight gradient, still running on the engine's side stream -- and
+        conv1.weight's own step is left as model._deferred_step, which VinceQueueModel.param_update / the next forward / zero_grad
+        finish behind the stem event.  The default completes everything before returning."""
         lr = float(self.param_groups[0]["lr"])
         flat, grad, n_train, _ = self.model.flat_parameters()
         if self.momentum_buffer.device != flat.device:
@@ -45,6 +49,21 @@ class FlatSGD:
             # an idle range's flat gradient is all zeros here (the whole buffer is cleared before backward): the kernel then
             # applies exactly weight decay + momentum, which is what torch 1.4 does with an in-place-zeroed .grad
             if b > a and role in self._ever_touched:
+                if role == "trunk" and getattr(self.model, "_stem_pending", False):
+                    # conv1.weight is the first tensor of the flat buffer: [a, n1); its gradient is final behind the stem event only
+                    n1 = self.model._offs[1]
+                    ops.sgd_flat(flat[n1:b], grad[n1:b], self.momentum_buffer[n1:b], lr, self.momentum, self.weight_decay,
+                                 self.grad_scale)
+
+                    def finish(a=a, n1=n1, lr=lr, scale=self.grad_scale):
+                        self.model.finish_stem_grad()
+                        f, g, _, _ = self.model.flat_parameters()
+                        ops.sgd_flat(f[a:n1], g[a:n1], self.momentum_buffer[a:n1], lr, self.momentum, self.weight_decay, scale)
+                    if defer_stem:
+                        self.model._deferred_step = finish
+                    else:
+                        finish()
+                    continue
                 ops.sgd_flat(flat[a:b], grad[a:b], self.momentum_buffer[a:b], lr, self.momentum, self.weight_decay,
                              self.grad_scale)
         self.model._touch()

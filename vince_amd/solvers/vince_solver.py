@@ -122,6 +122,12 @@ class VinceSolver(BaseSolver):
             self.optimizer.grad_scale = 1.0 / w
             if hasattr(self.model, "imagenet_decoders"):
                 self.reducer.sync_extra_parameters(self.model.imagenet_decoders.parameters())
+        # single process: the optimiser and the key encoder's EMA run beside the stem's weight gradient, the last launch of backward
+        # (engine deferred stem join; under data parallelism the last gradient bucket needs that gradient first, so it stays joined).
+        # VINCE_DEFER_STEM=0: off (A/B measurements)
+        self.defer_stem = (self.reducer is None and self.model.device.type == "cuda"
+                           and os.environ.get("VINCE_DEFER_STEM", "1") != "0")
+        self.model.defer_stem_join = self.defer_stem
         self.print_optimizer()
 
     def setup_model(self):
@@ -429,7 +435,10 @@ class VinceSolver(BaseSolver):
         loss.backward()
         if self.reducer is not None:
             self.reducer.reduce_after_backward()
-        self.optimizer.step()
+        if getattr(self, "defer_stem", False):
+            self.optimizer.step(defer_stem=True)     # (conv1.weight's step is finished inside vince_update below)
+        else:
+            self.optimizer.step()
         lap("backward_time")
 
         for image_batch, output in zip(batch_parts, outputs):
