@@ -51,7 +51,7 @@ const char* vince_last_error(void);
 /* Bumped whenever an exported signature, a struct layout or a dtype code changes.  vince_abi_version() returns the value the library
  * was BUILT with; a binding compares it at load (vince_amd/_lib.py: a stale .so behind VINCE_HIP_LIB would otherwise be called with
  * shifted arguments). */
-#define VINCE_ABI_VERSION 6
+#define VINCE_ABI_VERSION 7
 int vince_abi_version(void);
 
 /* Measurement aid (bench.py): while enabled, every conv_igemm / conv_wgrad launch is bracketed by a hipEvent pair on
@@ -486,14 +486,18 @@ size_t vince_infonce_workspace_bytes(const vince_infonce_desc* d);
 /* outputs: pos[B][P] raw cosines of the positives (P = frames), row_max[B], neg_sum[B] (sum of exp(s - row_max)
  * over negatives), dists[B][P], softmax_weights[B][P], scalars[8] = {loss mean, softmax_weight mean,
  * accuracy mean, mean positive cosine, mean row-max negative cosine, 0,0,0}. */
+/* logits: optional float[B][Bk + K] -- the raw cosines, in-batch columns first (what the reference materialises as
+ * `vince_similarities`, vince_model.py:207-242); a training forward stores them so that vince_infonce_bwd reads them back instead of
+ * recomputing them.  NULL: not written. */
 int vince_infonce_fwd(const vince_infonce_desc* d, const float* q, const float* inb, const float* queue,
                       float* pos, float* row_max, float* neg_sum, float* dists, float* softmax_weights,
-                      float* scalars, void* workspace, void* stream);
+                      float* scalars, float* logits, void* workspace, void* stream);
 /* dq[B][D] += dloss/dq (atomic fp32; zero it first).  grad_scale: device pointer to the upstream scalar gradient.
+ * logits: the matrix vince_infonce_fwd stored for the same operands, or NULL (recomputed with exact fp32 products).
  * wmat: optional float[B][Bk] receiving dloss/dlogit for the in-batch columns (self-similarity column-side grad). */
 int vince_infonce_bwd(const vince_infonce_desc* d, const float* q, const float* inb, const float* queue,
                       const float* pos, const float* row_max, const float* neg_sum, const float* grad_scale,
-                      float* dq, float* wmat, void* stream);
+                      const float* logits, float* dq, float* wmat, void* stream);
 
 /* similarity_cross_entropy on MATERIALISED similarities [B][cols] with an arbitrary boolean mask (uint8, P positives in
  * every row) -- utils/loss_util.py:7-62 as called by VinceModel.loss with a caller-provided tensor.  dists /

@@ -669,43 +669,55 @@ def test_solver_runs_and_advances_queue():
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_deferred_stem_join_steps_the_same_parameters(dtype, monkeypatch):
     """The solver's default single-process step leaves backward before conv1's weight gradient has landed and steps / averages
-    conv1.weight behind an event (engine deferred stem join, FlatSGD.step(defer_stem=True), VinceQueueModel.param_update).  The
-    joined order (VINCE_DEFER_STEM=0) must produce the same parameters: three steps of both from the same seeds, query and key
-    encoder compared tensor by tensor (fp32 weight gradients are summed with float atomics, hence a tolerance; a conv1.weight that
-    missed its step, or was stepped with a partial gradient, is off by the whole update)."""
+    conv1.weight behind an event (engine deferred stem join, FlatSGD.step(defer_stem=True), VinceQueueModel.param_update).
+    (1) Inside one run: after the first step the gradient buffer holds the COMPLETE stem gradient g, so conv1.weight must equal
+    w - lr (g + wd w) (torch SGD's first step, momentum buffer empty) and the key encoder's copy m k + (1 - m) w_new -- an optimiser
+    that ran before the gradient had landed, or an EMA before the step, misses by a visible fraction of the update.
+    (2) fp32: the joined order (VINCE_DEFER_STEM=0) from the same seeds gives the same parameters (float atomics: a tolerance; the bf16
+    backward is not run-to-run reproducible at this toy size -- its stem gradient varies by percents -- so (1) carries that dtype).
+    Later steps only check that nothing is left pending; the free-running golden tests (test_solver_free_running_*) hold the same
+    default step to the reference over two iterations."""
     from vince_amd.config import make_args
     from vince_amd.data_source import SyntheticFrames
     from vince_amd.solvers.vince_solver import VinceSolver
+    lr, wd, m = 0.03, 1e-4, 0.999
 
     def run(defer):
         monkeypatch.setenv("VINCE_DEFER_STEM", "1" if defer else "0")
         torch.manual_seed(11)
         args = make_args(backbone="ResNet18", batch_size=16, vince_queue_size=64, input_size=(64, 64), compute_dtype=dtype,
-                         batch_source=SyntheticFrames(16, 64, 64, 1, device=DEV, seed=5, iterations=10 ** 6), base_lr=0.03)
+                         batch_source=SyntheticFrames(16, 64, 64, 1, device=DEV, seed=5, iterations=10 ** 6), base_lr=lr)
         solver = VinceSolver(args)
         assert solver.defer_stem == defer and solver.model.defer_stem_join == defer
         solver.reset_epoch()
-        before = solver.model.feature_extractor.model.trunk_params[0].detach().clone()
-        for _ in range(3):
-            solver.run_train_iteration()
-            assert solver.model._deferred_step is None and not solver.model._stem_pending     # nothing left for later
+        conv1 = solver.model.feature_extractor.model.trunk_params[0]
+        kconv1 = solver.queue_model.queue_network.feature_extractor.model.trunk_params[0]
+        w0, k0 = conv1.detach().clone(), kconv1.detach().clone()
+        mom = float(solver.queue_model.vince_momentum)
+        solver.run_train_iteration()
+        assert solver.model._deferred_step is None and not solver.model._stem_pending     # nothing left for later
         torch.cuda.synchronize()
+        g = conv1.grad.detach().clone()            # (a strided view into the flat gradient buffer) complete by now
+        want = w0 - lr * (g + wd * w0)
+        moved = float((want - w0).abs().max())
+        assert moved > 0
+        assert float((conv1.detach() - want).abs().max()) < 1e-3 * moved + 1e-9, "conv1.weight was stepped with a partial gradient"
+        kwant = mom * k0 + (1.0 - mom) * want
+        assert float((kconv1.detach() - kwant).abs().max()) < 1e-3 * (1.0 - mom) * moved + 1e-9, "the key encoder averaged a stale conv1.weight"
         q = {n: p.detach().float().cpu().clone() for n, p in solver.model.named_parameters()}
         k = {n: p.detach().float().cpu().clone() for n, p in solver.queue_model.queue_network.named_parameters()}
-        moved = float((solver.model.feature_extractor.model.trunk_params[0].detach() - before).abs().max())
-        return q, k, moved
+        for _ in range(3):
+            ld, _ = solver.run_train_iteration()
+            assert solver.model._deferred_step is None and not solver.model._stem_pending
+        assert np.isfinite(float(ld["nce_loss"]))
+        return q, k
 
-    qa, ka, moved_a = run(True)
-    qb, kb, moved_b = run(False)
-    assert moved_a > 0 and moved_b > 0
-    tol = 2e-4 if dtype == "fp32" else 2e-2
-    for name in qa:
-        scale = float(qb[name].abs().max()) + 1e-12
-        assert float((qa[name] - qb[name]).abs().max()) / scale < tol, name
-        assert float((ka[name] - kb[name]).abs().max()) / (float(kb[name].abs().max()) + 1e-12) < tol, name
-    conv1 = "feature_extractor.model.conv1.weight"
-    step = float((qa[conv1] - qb[conv1]).abs().max())
-    assert step < 0.05 * moved_b, (step, moved_b)      # the two orders agree far inside one update of conv1.weight
+    qa, ka = run(True)
+    qb, kb = run(False)
+    if dtype == "fp32":
+        for name in qa:
+            assert float((qa[name] - qb[name]).abs().max()) / (float(qb[name].abs().max()) + 1e-12) < 2e-5, name
+            assert float((ka[name] - kb[name]).abs().max()) / (float(kb[name].abs().max()) + 1e-12) < 2e-5, name
 
 
 def test_solver_c5_mode_jigsaw_multiframe_and_val():

@@ -573,6 +573,15 @@ def test_infonce_vs_oracle(B, K, D, mode, T):
     dq = torch.zeros(B, D, device=DEV)
     ops.infonce_bwd(r, qg, kg, queueg, torch.tensor([1.7], device=DEV), dq)
     assert_close(dq, qq.grad, torch.float32, f32=2e-4, what="infonce dq")
+    # the training route: the forward stores its logits (split-half products: fp32-grade), backward reads them back
+    r2 = ops.infonce_fwd(qg, kg, queueg, T, frames=frames, offdiag_neg=inter, save_logits=True)
+    assert torch.equal(r2.scalars, r.scalars) and torch.equal(r2.dists, r.dists)
+    want = torch.cat([qq.detach() @ kk.t(), qq.detach() @ queue.t()], dim=1).double()
+    assert r2.logits.shape == want.shape
+    assert float((r2.logits.cpu().double() - want).abs().max()) < 1e-6, "stored logits"
+    dq2 = torch.zeros(B, D, device=DEV)
+    ops.infonce_bwd(r2, qg, kg, queueg, torch.tensor([1.7], device=DEV), dq2)
+    assert_close(dq2, qq.grad, torch.float32, f32=2e-4, what="infonce dq from stored logits")
 
 
 def test_infonce_self_similarity():

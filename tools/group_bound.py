@@ -56,6 +56,26 @@ with torch.no_grad():
 
     a = timed(seq)
     b = timed(two_streams)
+
+
+def two_streams_grad():
+    # D: the training step's own pair -- the query encoder GRAD-ENABLED (saves what backward reads) beside the no-grad key encoder
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side), torch.no_grad():
+        k.get_embeddings({"data": x2})
+    q.get_embeddings({"data": x1})
+    main.wait_stream(side)
+
+
+def one_grad():
+    q.get_embeddings({"data": x1})
+
+
+d = timed(two_streams_grad)
+d1 = timed(one_grad)
+print("D grad-enabled query + no-grad key on two streams %.3f ms (grad-enabled forward alone %.3f ms)" % (d, d1))
+with torch.no_grad():
     del k
     torch.cuda.empty_cache()
     big = model(2 * B)

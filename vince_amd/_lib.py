@@ -127,8 +127,8 @@ PROTOTYPES = {
     "vince_colsum": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "vince_nonfinite_latch": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "vince_infonce_workspace_bytes": (c_size_t, [P(InfoNCEDesc)]),
-    "vince_infonce_fwd": (c_int, [P(InfoNCEDesc)] + [c_void_p] * 11),
-    "vince_infonce_bwd": (c_int, [P(InfoNCEDesc)] + [c_void_p] * 10),
+    "vince_infonce_fwd": (c_int, [P(InfoNCEDesc)] + [c_void_p] * 12),
+    "vince_infonce_bwd": (c_int, [P(InfoNCEDesc)] + [c_void_p] * 11),
     "vince_sce_rows_fwd": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
     "vince_sce_rows_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p,
@@ -165,7 +165,7 @@ _LIB = None
 
 
 # include/vince_hip.h VINCE_ABI_VERSION (tests/test_abi_cpu.py holds the two together)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def lib():

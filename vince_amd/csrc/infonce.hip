@@ -3,11 +3,19 @@
 // Replaces vince_model.py:207-242 (torch.bmm / torch.mm logits, positive mask), utils/loss_util.py:7-62
 // (similarity_cross_entropy) and vince_model.py:314-342 (get_metrics).  The B x (Bk+K) logit matrix (67 MB at
 // B=256, K=65536) is never written: every workgroup holds a 64-row query tile in registers, streams 128-row
-// slabs of the key/queue matrix through LDS, forms 16x16 logit tiles on the fp32 matrix cores
-// (v_mfma_f32_16x16x4_f32 -- exact fp32, the contraction is only ~4 GFLOP) and keeps per-row online-softmax
+// slabs of the key/queue matrix through LDS, forms 16x16 logit tiles on the matrix cores and keeps per-row online-softmax
 // state (running max, sum of exp over negatives, max negative cosine) in registers; rows are reduced across
 // the 16 lanes that share them with wavefront shuffles.  A second tiny kernel merges the per-part partials and
 // produces the loss, the per-positive distances and the four metrics.
+//
+// Logits (round 5): SPLIT-HALF products instead of exact fp32 MFMAs.  Both operands are unit vectors; every element x becomes
+// hi = half(x * 2^8), lo = half(x * 2^8 - hi) (csrc/common.h x3_split: 22 significand bits, lo halves stay normal down to |x| ~ 5e-4,
+// absolute steps of 2e-10 below) and a logit is hi*lo + lo*hi + hi*hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation:
+// |error| <= ~2^-22 * sum |q_i k_i| <= 2.4e-7 on a value in [-1, 1] -- fp32's own rounding -- at 96 MFMAs of 16 cycles per
+// 16 x 128 tile where v_mfma_f32_16x16x4_f32 took 256 of 32.  The queue slab is split ONCE per workgroup on its way into LDS
+// (the same 4 bytes per element: [8 hi halves | 8 lo halves] per group of 8).  Training forwards also WRITE the logits
+// (B x (Bk + K) floats, 67 MB at B = 256, K = 65536 -- 13 us of HBM time) so that backward reads them back instead of
+// recomputing them next to its own dq contraction.
 //
 // Loss definition (NOT plain softmax cross-entropy): for row i with positives P_i and negatives N_i,
 //   dist_ip = -( s_ip - log( exp(s_ip) + sum_{n in N_i} exp(s_in) ) ),   loss = mean over all (i, p)
@@ -33,6 +41,7 @@ struct InfoParams {
     float* dq;
     float* wmat;
     float* part;   // [3][P][B]
+    float* logits; // optional [B][Bk + K]: written by the forward, read by backward (nullptr: backward recomputes them)
 };
 
 template <int D>
@@ -100,6 +109,73 @@ __device__ inline void load_q_frags(const InfoParams& p, int rowbase, int lane, 
     }
 }
 
+// ---- split-half logits (see the header) ------------------------------------------------------------------------------------
+constexpr float LOGIT_UNSCALE = 1.f / (float)(1 << (2 * X3_WSHIFT));
+
+// Stage slab rows [row0, row0+128) as half pairs: the 8 floats of group j of a row become 16 bytes of hi halves + 16 bytes of lo
+// halves at byte j*32 of the row (the row keeps its fp32 footprint and stride), zero rows past nrows.
+template <int D>
+__device__ inline void stage_slab_split(unsigned char* lds, const float* __restrict__ src, int row0, int nrows, int tid) {
+    constexpr int GPR = D / 8;
+    for (int c = tid; c < SL * GPR; c += 256) {
+        const int r = c / GPR, j = c % GPR;
+        uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0;
+        if (row0 + r < nrows) {
+            const float* sp = src + (size_t)(row0 + r) * D + j * 8;
+            f0 = *(const uint4*)sp;
+            f1 = *(const uint4*)(sp + 4);
+        }
+        uint4 hi, lo;
+        x3_split<x3h_t, true>(f0, f1, hi, lo);
+        *(uint4*)(lds + r * ISmem<D>::SRS + j * 32) = hi;
+        *(uint4*)(lds + r * ISmem<D>::SRS + j * 32 + 16) = lo;
+    }
+}
+
+// A operand of v_mfma_f32_16x16x32_f16: lane holds query row (lane & 15), k = ks*32 + (lane >> 4)*8 .. +8
+template <int D>
+__device__ inline void load_q_split(const InfoParams& p, int rowbase, int lane, uint4 (&qh)[D / 32], uint4 (&ql)[D / 32]) {
+    const int row = rowbase + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) {
+        uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0;
+        if (row < p.d.B) {
+            const float* sp = p.q + (size_t)row * D + ks * 32 + (lane >> 4) * 8;
+            f0 = *(const uint4*)sp;
+            f1 = *(const uint4*)(sp + 4);
+        }
+        x3_split<x3h_t, true>(f0, f1, qh[ks], ql[ks]);
+    }
+}
+
+__device__ __forceinline__ f32x4_t mfma_h(const uint4& a, const uint4& b, f32x4_t c) {
+    f16x8_t av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+}
+
+// logits tile from a slab staged by stage_slab_split: acc[ct][r] = q[row (lane>>4)*4 + r] . slab[ct*16 + (lane&15)]
+template <int D>
+__device__ inline void logits_tile_split(const unsigned char* slab, const uint4 (&qh)[D / 32], const uint4 (&ql)[D / 32], f32x4_t (&acc)[8], int lane) {
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) acc[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* base = slab + (lane & 15) * ISmem<D>::SRS + (lane >> 4) * 32;
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const uint4 bh = *(const uint4*)(base + ct * 16 * ISmem<D>::SRS + ks * 128);
+            const uint4 bl = *(const uint4*)(base + ct * 16 * ISmem<D>::SRS + ks * 128 + 16);
+            acc[ct] = mfma_h(qh[ks], bl, acc[ct]);     // small terms first
+            acc[ct] = mfma_h(ql[ks], bh, acc[ct]);
+            acc[ct] = mfma_h(qh[ks], bh, acc[ct]);
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) acc[ct] *= LOGIT_UNSCALE;
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void infonce_fwd_partial(const InfoParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ISmem<D>::SLAB];
@@ -114,8 +190,9 @@ __global__ __launch_bounds__(256) void infonce_fwd_partial(const InfoParams p) {
     const float invT = p.d.inv_temperature;
     const int F = p.d.frames;
 
-    float4 qf[D / 16];
-    load_q_frags<D>(p, rowbase, lane, qf);
+    uint4 qh[D / 32], ql[D / 32];
+    load_q_split<D>(p, rowbase, lane, qh, ql);
+    const int ldl = p.d.Bk + p.d.K, colbase = is_inb ? 0 : p.d.Bk;      // row length / first column of this source in p.logits
 
     float m[4], s[4], nm[4];
 #pragma unroll
@@ -123,10 +200,10 @@ __global__ __launch_bounds__(256) void infonce_fwd_partial(const InfoParams p) {
 
     for (int slab = slab0; slab < slab1; ++slab) {
         __syncthreads();
-        stage_slab<D>(smem, src, slab * SL, nsrc, tid);
+        stage_slab_split<D>(smem, src, slab * SL, nsrc, tid);
         __syncthreads();
         f32x4_t acc[8];
-        logits_tile<D>(smem, qf, acc, lane);
+        logits_tile_split<D>(smem, qh, ql, acc, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rowg = rowbase + (lane >> 4) * 4 + r;
@@ -136,6 +213,7 @@ __global__ __launch_bounds__(256) void infonce_fwd_partial(const InfoParams p) {
             for (int ct = 0; ct < 8; ++ct) {
                 const int cg = slab * SL + ct * 16 + (lane & 15);
                 float raw = acc[ct][r];
+                if (p.logits && rowg < p.d.B && cg < nsrc) p.logits[(size_t)rowg * ldl + colbase + cg] = raw;
                 bool neg = cg < nsrc;
                 if (is_inb && neg) {
                     const bool is_pos = (cg / F) == (rowg / F);
@@ -260,7 +338,9 @@ __global__ __launch_bounds__(256) void infonce_bwd_kernel(const InfoParams p) {
     unsigned char* wt = smem + ISmem<D>::SLAB + wave * ISmem<D>::WT;
 
     float4 qf[D / 16];
-    load_q_frags<D>(p, rowbase, lane, qf);
+    const bool saved = p.logits != nullptr;        // (uniform) the forward of this step stored its logits: read, do not recompute
+    if (!saved) load_q_frags<D>(p, rowbase, lane, qf);
+    const int ldl = p.d.Bk + p.d.K, colbase = is_inb ? 0 : p.d.Bk;
 
     // per-row constants for this lane's 4 rows
     const float gs = p.grad_scale[0] * invT / ((float)B * (float)F);
@@ -282,11 +362,22 @@ __global__ __launch_bounds__(256) void infonce_bwd_kernel(const InfoParams p) {
     for (int dt = 0; dt < D / 16; ++dt) dacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     for (int slab = slab0; slab < slab1; ++slab) {
+        f32x4_t acc[8];
+        if (saved) {   // requested before the staging barrier so that the loads fly beside it
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                const int cg = slab * SL + ct * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rowg = rowbase + (lane >> 4) * 4 + r;
+                    acc[ct][r] = (cg < nsrc && rowg < B) ? p.logits[(size_t)rowg * ldl + colbase + cg] : 0.f;
+                }
+            }
+        }
         __syncthreads();
         stage_slab<D>(smem, src, slab * SL, nsrc, tid);
         __syncthreads();
-        f32x4_t acc[8];
-        logits_tile<D>(smem, qf, acc, lane);
+        if (!saved) logits_tile<D>(smem, qf, acc, lane);
         // dloss/dlogit (times 1/T) -> wave-private LDS tile [16 rows][128 cols]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -452,7 +543,7 @@ extern "C" size_t vince_infonce_workspace_bytes(const vince_infonce_desc* d) {
 
 extern "C" int vince_infonce_fwd(const vince_infonce_desc* d, const float* q, const float* inb, const float* queue,
                                  float* pos, float* row_max, float* neg_sum, float* dists, float* softmax_weights,
-                                 float* scalars, void* workspace, void* stream) {
+                                 float* scalars, float* logits, void* workspace, void* stream) {
     InfoParams p;
     int rc = fill_params(d, p);
     if (rc != VINCE_OK) return rc;
@@ -460,7 +551,7 @@ extern "C" int vince_infonce_fwd(const vince_infonce_desc* d, const float* q, co
                     "vince_infonce_fwd: null pointer");
     VINCE_CHECK_ARG(d->K == 0 || queue, VINCE_E_ARG, "vince_infonce_fwd: queue missing");
     p.q = q; p.inb = inb; p.queue = queue; p.pos = pos; p.part = (float*)workspace;
-    p.row_max = nullptr; p.neg_sum = nullptr; p.grad_scale = nullptr; p.dq = nullptr; p.wmat = nullptr;
+    p.row_max = nullptr; p.neg_sum = nullptr; p.grad_scale = nullptr; p.dq = nullptr; p.wmat = nullptr; p.logits = logits;
     const int P = p.parts_inb + p.parts_q;
     dim3 grid((d->B + RT - 1) / RT, P);
     if (d->D == 64) hipLaunchKernelGGL(infonce_fwd_partial<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -474,14 +565,14 @@ extern "C" int vince_infonce_fwd(const vince_infonce_desc* d, const float* q, co
 
 extern "C" int vince_infonce_bwd(const vince_infonce_desc* d, const float* q, const float* inb, const float* queue,
                                  const float* pos, const float* row_max, const float* neg_sum, const float* grad_scale,
-                                 float* dq, float* wmat, void* stream) {
+                                 const float* logits, float* dq, float* wmat, void* stream) {
     InfoParams p;
     int rc = fill_params(d, p);
     if (rc != VINCE_OK) return rc;
     VINCE_CHECK_ARG(q && inb && pos && row_max && neg_sum && grad_scale && dq, VINCE_E_ARG, "vince_infonce_bwd: null pointer");
     VINCE_CHECK_ARG(d->K == 0 || queue, VINCE_E_ARG, "vince_infonce_bwd: queue missing");
     p.q = q; p.inb = inb; p.queue = queue; p.pos = (float*)pos; p.part = nullptr;
-    p.row_max = row_max; p.neg_sum = neg_sum; p.grad_scale = grad_scale; p.dq = dq; p.wmat = wmat;
+    p.row_max = row_max; p.neg_sum = neg_sum; p.grad_scale = grad_scale; p.dq = dq; p.wmat = wmat; p.logits = (float*)logits;
     const int P = p.parts_inb + p.parts_q;
     dim3 grid((d->B + RT - 1) / RT, P);
     if (d->D == 64) hipLaunchKernelGGL(infonce_bwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -85,7 +85,7 @@ struct vince_trunk {
     size_t off_fold;      // fold constants (scale, bias per BN channel + ones/zeros) inside a weight cache
     // weight-gradient side stream (created on first backward) + per-slot events of the dY ring
     hipStream_t side = nullptr;
-    hipEvent_t ev_dy[NDY_MAX] = {}, ev_wg[NDY_MAX] = {}, ev_join = nullptr;
+    hipEvent_t ev_dy[NDY_MAX] = {}, ev_wg[NDY_MAX] = {}, ev_join = nullptr, ev_alg = nullptr;
     bool wg_pending[NDY_MAX] = {};
     int ndy = 3;                     // slots of the dY ring in use (knob `dy_slots`, 3 .. NDY_MAX)
     // downsample-branch stream of the 4 stage-entry blocks (backward): its own dY buffer and events
@@ -421,6 +421,7 @@ extern "C" void vince_trunk_destroy(vince_trunk_t t) {
         hipStreamSynchronize(t->side);     // (the stream itself is shared by every engine instance of the process: it stays)
         for (int i = 0; i < t->ndy; ++i) { hipEventDestroy(t->ev_dy[i]); hipEventDestroy(t->ev_wg[i]); }
         hipEventDestroy(t->ev_join);
+        hipEventDestroy(t->ev_alg);
     }
     if (t->ds_stream) {
         hipStreamSynchronize(t->ds_stream);
@@ -1052,6 +1053,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_wg[i], hipEventDisableTiming));
         }
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+        VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_alg, hipEventDisableTiming));
     }
     // the downsample branch of a stage-entry block only meets the main chain again at the block-input gradient: it runs on a
     // third stream (VINCE_DS_STREAM=0: inline on the main stream)
@@ -1157,8 +1159,15 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             RC(vince_bn3_bwd_prepare(R, wk, c.sums(bn), bn.R, c.consts(bn, 2), c.consts(bn, 3), params[bn.gamma], rows_out,
                                      cv.Co, cv.Ci, ap.coef, ap.w2, 2 * cv.Co, (unsigned char*)ap.w2 + (size_t)cv.Co * 2, 2 * cv.Co, ap.nr,
                                      grads[bn.gamma], grads[bn.beta], stream));
+            // the finished weight gradient is nobody's input but the optimiser's: on the weight-gradient stream, behind the coefficients
+            // (ev_alg), off the chain of launches the input gradient below waits for
+            if (overlap) {
+                VINCE_CHECK_HIP(hipEventRecord(t->ev_alg, main_s));
+                VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_alg, 0));
+            }
             RC(vince_bn3_bwd_finish_dw(R, grads[cv.param], wk, (const float*)at(workspace, b.gram), (const double*)at(workspace, b.colsum),
-                                       GRAM_R, ap.coef, c.consts(bn, 2), c.consts(bn, 3), cv.Co, cv.Ci, stream));
+                                       GRAM_R, ap.coef, c.consts(bn, 2), c.consts(bn, 3), cv.Co, cv.Ci,
+                                       overlap ? (void*)t->side : stream));
             // da = (W^T diag(s)) g + nq a + nr in ONE launch: the reduction runs over g's 4w channels (tap 0) and then over a's w
             // channels (tap 1 = vince_conv_epi.in2), with the fused reduction of the BatchNorm below as the plain dgrad has it
             {

@@ -175,7 +175,9 @@ class _InfoNCEFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         qc = q.detach().contiguous()
         inbc = qc if self_sim else inb.detach().contiguous()
-        r = ops.infonce_fwd(qc, inbc, queue, temperature, frames=frames, offdiag_neg=offdiag_neg)
+        # (a forward that will be differentiated keeps its logits for backward: 67 MB at B = 256, K = 65536)
+        r = ops.infonce_fwd(qc, inbc, queue, temperature, frames=frames, offdiag_neg=offdiag_neg,
+                            save_logits=bool(ctx.needs_input_grad[0]))
         ctx.r, ctx.qc, ctx.inbc, ctx.queue, ctx.self_sim = r, qc, inbc, queue, self_sim
         ctx.mark_non_differentiable(r.scalars, r.dists, r.softmax_weights, r.pos)
         return r.scalars[0].clone(), r.scalars, r.dists, r.softmax_weights, r.pos

@@ -557,11 +557,12 @@ def nhwc_to_nchw_f32(x):
 
 # ------------------------------------------------------------------------------------------------ InfoNCE
 class InfoNCEResult:
-    __slots__ = ("desc", "pos", "row_max", "neg_sum", "dists", "softmax_weights", "scalars")
+    __slots__ = ("desc", "pos", "row_max", "neg_sum", "dists", "softmax_weights", "scalars", "logits")
 
 
-def infonce_fwd(q, inb, queue, temperature, frames=1, offdiag_neg=False):
-    """Fused similarity + loss + metrics.  q:[B,D] inb:[B,D] queue:[K,D] or None (all float32)."""
+def infonce_fwd(q, inb, queue, temperature, frames=1, offdiag_neg=False, save_logits=False):
+    """Fused similarity + loss + metrics.  q:[B,D] inb:[B,D] queue:[K,D] or None (all float32).
+    save_logits: also store the B x (Bk + K) raw cosines (r.logits) for infonce_bwd to read back instead of recomputing them."""
     require_gpu(q, inb, queue)
     B, D = q.shape
     K = 0 if queue is None else queue.shape[0]
@@ -579,9 +580,10 @@ def infonce_fwd(q, inb, queue, temperature, frames=1, offdiag_neg=False):
     r.dists = torch.empty(B, frames, device=q.device)
     r.softmax_weights = torch.empty(B, frames, device=q.device)
     r.scalars = torch.empty(8, device=q.device)
+    r.logits = torch.empty(B, inb.shape[0] + K, device=q.device) if save_logits else None
     check(lib().vince_infonce_fwd(ctypes.byref(d), _ptr(q), _ptr(inb), _ptr(queue), _ptr(r.pos), _ptr(r.row_max),
-                                  _ptr(r.neg_sum), _ptr(r.dists), _ptr(r.softmax_weights), _ptr(r.scalars), _ptr(ws),
-                                  stream_ptr()))
+                                  _ptr(r.neg_sum), _ptr(r.dists), _ptr(r.softmax_weights), _ptr(r.scalars), _ptr(r.logits),
+                                  _ptr(ws), stream_ptr()))
     return r
 
 
@@ -589,7 +591,8 @@ def infonce_bwd(r, q, inb, queue, grad_scale, dq, want_wmat=False):
     require_gpu(q, inb, queue, grad_scale, dq)
     wmat = torch.zeros(r.desc.B, r.desc.Bk, device=q.device) if want_wmat else None
     check(lib().vince_infonce_bwd(ctypes.byref(r.desc), _ptr(q), _ptr(inb), _ptr(queue), _ptr(r.pos), _ptr(r.row_max),
-                                  _ptr(r.neg_sum), _ptr(grad_scale), _ptr(dq), _ptr(wmat), stream_ptr()))
+                                  _ptr(r.neg_sum), _ptr(grad_scale), _ptr(getattr(r, "logits", None)), _ptr(dq), _ptr(wmat),
+                                  stream_ptr()))
     return wmat
 
 

@@ -369,6 +369,15 @@ class VinceSolver(BaseSolver):
 
         concat_batch, batch_parts = self.get_batch()
         lap("data_cache_time")
+        # measurement hook (tools/step_phases.py): a list here collects one CUDA event per phase boundary of this iteration
+        marks = getattr(self, "phase_marks", None)
+
+        def mark(name):
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((name, ev))
+        mark("start")
 
         # key encoder (no grad) and query encoder (vince_solver.py:397-406).  The two forwards are independent (different
         # weights, different workspaces), so the key encoder runs on a side HIP stream and its kernels fill the launch
@@ -399,6 +408,7 @@ class VinceSolver(BaseSolver):
             outputs = self.model.get_embeddings(concat_batch, jigsaw=jig_query, shuffle=True)
 
         lap("forward_time")
+        mark("forwards")
 
         loss_list, metrics_list = [], []
         batch_parts = self.model.split_dict_by_type(concat_batch["batch_types"], concat_batch["batch_sizes"],
@@ -429,6 +439,7 @@ class VinceSolver(BaseSolver):
         self._watch_loss(loss)
 
         lap("metrics_time")
+        mark("loss")
         self.optimizer.zero_grad()
         if self.reducer is not None:
             self.reducer.begin_step()
@@ -440,6 +451,7 @@ class VinceSolver(BaseSolver):
         else:
             self.optimizer.step()
         lap("backward_time")
+        mark("backward+sgd")
 
         for image_batch, output in zip(batch_parts, outputs):
             # update queue (after the optimizer step, before the EMA, vince_solver.py:497-499); with several ranks
@@ -447,6 +459,7 @@ class VinceSolver(BaseSolver):
             keys = gathered_keys if gathered_keys is not None else dp.gather_keys(output["queue_embeddings"])
             self.vince_queue.enqueue(keys, image_batch.get("queue_data_cpu"), image_batch["data_source"])
         self.queue_model.vince_update(self.model)
+        mark("enqueue+ema")
 
         step_no = self.logger_iteration
         if step_no % self.args.log_frequency == 0:
