@@ -653,7 +653,7 @@ def test_cpu_tensor_is_rejected():
 
 # ---------------------------------------------------------------------------------------------- Gram-statistics residual join
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N,hw,K,Co,ds", [(4, 14, 64, 256, False), (3, 9, 128, 512, True), (2, 5, 64, 256, True)])
+@pytest.mark.parametrize("N,hw,K,Co,ds", [(4, 14, 64, 256, False), (3, 9, 128, 512, True), (2, 5, 64, 256, True), (3, 14, 256, 1024, False)])
 def test_gram_statistics_join_vs_separate_passes(dtype, N, hw, K, Co, ds):
     """bn3(conv3(a)) + identity + ReLU (resnet.py:125-133) three ways: torch fp32/fp64 on the CPU, the engine's separate
     passes, and the Gram route -- column sums from the pass that writes a, Gram matrix through the weight-gradient kernel,
@@ -701,6 +701,27 @@ def test_gram_statistics_join_vs_separate_passes(dtype, N, hw, K, Co, ds):
     ops.conv_igemm(ops.conv_desc(N, hw, hw, K, Co, 1, 1, 0), x4, w3g.view(Co, 1, K), z, bias=consts[1], flags=EPI_ACCUMULATE | EPI_RELU,
                    out_scale=consts[0], id_scale=isc.to(DEV) if ds else None, id_shift=ish.to(DEV) if ds else None)
     assert_close(z.view(rows, Co), want.float(), dtype, f32=5e-5, bf16=3e-2, what="join")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("K,Co", [(64, 256), (96, 200), (128, 512), (256, 1024), (512, 64)])
+def test_bn_gram_finalize_alone_vs_fp64(dtype, K, Co):
+    """vince_bn_gram_finalize on a given Gram matrix: batch statistics of y = W a from G = a^T a and the column sums, against fp64 on
+    the CPU -- the bottleneck shapes (K = 64 / 128 / 256: one column of G per thread) and other K (one wavefront per channel)."""
+    ops = _ops()
+    rows = 5000
+    a = q(torch.relu(rnd(rows, K, seed=21) + 0.3), dtype).double()
+    w = q(rnd(Co, K, seed=22) * (2.0 / K) ** 0.5, dtype)
+    gram = (a.t() @ a).float().to(DEV).contiguous()
+    colsum = torch.zeros(4, K, dtype=torch.float64)
+    colsum[1] = a.sum(0)
+    y = a @ w.double().t()
+    rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+    consts = ops.bn_gram_finalize(gram, colsum.to(DEV), rows, w.to(DEV).to(dtype).contiguous(), torch.ones(Co, device=DEV),
+                                  torch.zeros(Co, device=DEV), rm, rv, None)
+    np.testing.assert_allclose(consts[2].cpu().numpy(), y.mean(0).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(consts[3].cpu().numpy(), (1.0 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)).numpy(), rtol=2e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * y.var(0, unbiased=True)).numpy(), rtol=2e-5)
 
 
 @pytest.mark.parametrize("rows,K", [(4 * 14 * 14, 64), (3 * 9 * 9, 128), (64 * 37 + 5, 64), (64 * 700 + 17, 128), (33, 128), (200704, 128)])

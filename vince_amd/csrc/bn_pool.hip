@@ -347,6 +347,89 @@ __global__ __launch_bounds__(256) void bn_gram_finalize_kernel(const float* __re
     }
 }
 
+// The same for K = 64 / 128 / 256 (round 5; the bottleneck shapes), arranged so that G crosses L2 -> CU once per WORKGROUP instead of
+// once per wavefront and nothing is staged: thread t owns column k2 = t % K of G and the K / 4 rows of its part (t / K), walks them
+// with coalesced row reads and keeps p[ch] = sum_k w[ch][k] G[k][k2] for the workgroup's GF2_NC channels in fp64; the contraction with
+// w[ch][k2] and the fold over the workgroup (wavefront shuffles, then four partials through LDS) happen once at the end.  At K = 256
+// (layer3: Co = 1024) the kernel above read the 256 KB matrix from L2 once per output channel and took 93 us; this one 256 times.
+constexpr int GF2_NC = 4;
+constexpr int gf2_threads(int K) { return K == 256 ? 1024 : K == 128 ? 512 : 256; }   // 4 row parts per column: a chain of K / 4 dependent-latency loads per thread
+template <typename T, int K>
+__global__ __launch_bounds__(gf2_threads(K)) void bn_gram_finalize2_kernel(const float* __restrict__ gram, const double* __restrict__ colsum,
+                                                                int R, double count, const T* __restrict__ W, int Co,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* running_mean, float* running_var, int64_t* nbt,
+                                                                float momentum, float eps, float* scale, float* shift,
+                                                                float* save_mean, float* save_invstd) {
+    constexpr int NT = gf2_threads(K), PARTS = NT / K, ROWS = K / PARTS, NWV = NT / 64;
+    __shared__ double mean_a[K];
+    __shared__ float wl[GF2_NC][K];
+    __shared__ double part[NWV][GF2_NC][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k2 = tid % K, k0 = (tid / K) * ROWS;
+    for (int k = tid; k < K; k += NT) {
+        double sk = 0;
+        for (int r = 0; r < R; ++r) sk += colsum[(size_t)r * K + k];
+        mean_a[k] = sk / count;
+    }
+    for (int i = tid; i < GF2_NC * K; i += NT) {
+        const int cc = blockIdx.x * GF2_NC + i / K, k = i % K;
+        float v = 0.f;
+        if (cc < Co) {
+            if constexpr (sizeof(T) == 4) v = ((const float*)W)[(size_t)cc * K + k];
+            else v = bf16_to_f32(((const bf16_t*)W)[(size_t)cc * K + k]);
+        }
+        wl[i / K][k] = v;
+    }
+    __syncthreads();
+    double p[GF2_NC];
+#pragma unroll
+    for (int c = 0; c < GF2_NC; ++c) p[c] = 0;
+    const float* __restrict__ gcol = gram + (size_t)k0 * K + k2;
+#pragma unroll 16
+    for (int k = 0; k < ROWS; ++k) {
+        const double g = (double)gcol[(size_t)k * K];
+#pragma unroll
+        for (int c = 0; c < GF2_NC; ++c) p[c] += (double)wl[c][k0 + k] * g;
+    }
+    double q[GF2_NC], mu[GF2_NC];
+#pragma unroll
+    for (int c = 0; c < GF2_NC; ++c) {
+        const double w2 = (double)wl[c][k2];
+        q[c] = p[c] * w2;
+        mu[c] = k0 == 0 ? w2 * mean_a[k2] : 0.0;      // (one part contributes the mean's dot product)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            q[c] += __shfl_xor(q[c], o, 64);
+            mu[c] += __shfl_xor(mu[c], o, 64);
+        }
+        if (lane == 0) { part[wave][c][0] = q[c]; part[wave][c][1] = mu[c]; }
+    }
+    __syncthreads();
+    if (tid < GF2_NC) {
+        const int c = blockIdx.x * GF2_NC + tid;
+        if (c < Co) {
+            double qq = 0, mm = 0;
+            for (int w = 0; w < NWV; ++w) { qq += part[w][tid][0]; mm += part[w][tid][1]; }
+            double var = qq / count - mm * mm;
+            if (var < 0) var = 0;
+            const float mean = (float)mm;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float scv = gamma[c] * invstd;
+            scale[c] = scv;
+            shift[c] = beta[c] - mean * scv;
+            if (save_mean) save_mean[c] = mean;
+            if (save_invstd) save_invstd[c] = invstd;
+            if (running_mean) {
+                const double unbiased = count > 1 ? var * count / (count - 1) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+            if (c == 0 && nbt) *nbt += 1;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const MaskArgs msk,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
@@ -905,6 +988,18 @@ extern "C" int vince_bn_gram_finalize(int dtype, const float* gram, const double
     VINCE_CHECK_ARG(K > 0 && K <= 512 && Co > 0 && K % CH_OF(dtype) == 0, VINCE_E_SHAPE,
                     "vince_bn_gram_finalize: K=%d (1..512, multiple of %d), Co=%d", K, CH_OF(dtype), Co);
     VINCE_CHECK_ARG(!running_mean == !running_var, VINCE_E_ARG, "vince_bn_gram_finalize: running_mean and running_var come together");
+    if (K == 64 || K == 128 || K == 256) {
+        const dim3 grid2((Co + GF2_NC - 1) / GF2_NC);
+#define GF2_LAUNCH(TT, KK)                                                                                                             \
+        hipLaunchKernelGGL((bn_gram_finalize2_kernel<TT, KK>), grid2, dim3(gf2_threads(KK)), 0, (hipStream_t)stream, gram, colsum, colsum_replicas, \
+                           (double)count, (const TT*)w, Co, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, \
+                           scale, shift, save_mean, save_invstd)
+        if (dtype == VINCE_F32) { if (K == 64) GF2_LAUNCH(float, 64); else if (K == 128) GF2_LAUNCH(float, 128); else GF2_LAUNCH(float, 256); }
+        else { if (K == 64) GF2_LAUNCH(bf16_t, 64); else if (K == 128) GF2_LAUNCH(bf16_t, 128); else GF2_LAUNCH(bf16_t, 256); }
+#undef GF2_LAUNCH
+        VINCE_CHECK_LAUNCH();
+        return VINCE_OK;
+    }
     const dim3 grid((Co + GF_NC - 1) / GF_NC);
     if (dtype == VINCE_F32)
         hipLaunchKernelGGL(bn_gram_finalize_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, gram, colsum, colsum_replicas,

@@ -163,7 +163,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
         for (int u = 0; u < UB; ++u) {
             const int row = row0 + (rb + u) * RPP;
             const uint32_t m = p0 + row;
-            ok[u] = cvalid && m < (uint32_t)p.M;
+            ok[u] = cvalid && m < (uint32_t)p.M && (NR % UB == 0 || rb + u < NR);     // (a batch size that does not divide the rows: ragged last batch)
             size_t opix = m;
             if (!identity_map) {
                 uint32_t n = fastdiv(m, p.div_howo);

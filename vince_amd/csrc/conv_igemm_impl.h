@@ -1,6 +1,9 @@
 // The implicit-GEMM convolution kernels and their tile selection (launch<T, CT, MODE>), shared by the translation units that
 // instantiate them: conv_igemm.hip (float, bf16) and conv_igemm_x3.hip (the split-half element types x3h_t / x3b_t).
 #pragma once
+#ifndef VINCE_UBM4
+#define VINCE_UBM4 2
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -518,7 +521,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
         return;
     }
     // rows in flight per thread in the epilogue: the 128-VGPR (4 workgroups/CU) configuration has no room for more than 2
-    conv_epilogue<T, CT, S::CRS, MODE, PTL, (MINW >= 4 ? 2 : 4), 256, WN>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
+    // (the forward residual join, MODE 2, reads the identity chunk of every row it stores: all of a thread's rows in flight at once --
+    // its accumulators are dead by then, so the registers are there; two at a time left four exposed round trips per tile)
+    conv_epilogue<T, CT, S::CRS, MODE, PTL, (MODE == 2 ? 8 : MINW >= 4 ? VINCE_UBM4 : 4), 256, WN>(p, smem, acc, tile, p0, c0, tid, lane, wave, wp, wc);
 }
 
 __global__ void relu_inplace_kernel(float* x, size_t n4) {
