@@ -51,7 +51,7 @@ const char* vince_last_error(void);
 /* Bumped whenever an exported signature, a struct layout or a dtype code changes.  vince_abi_version() returns the value the library
  * was BUILT with; a binding compares it at load (vince_amd/_lib.py: a stale .so behind VINCE_HIP_LIB would otherwise be called with
  * shifted arguments). */
-#define VINCE_ABI_VERSION 7
+#define VINCE_ABI_VERSION 8
 int vince_abi_version(void);
 
 /* Measurement aid (bench.py): while enabled, every conv_igemm / conv_wgrad launch is bracketed by a hipEvent pair on
@@ -569,6 +569,10 @@ const void* vince_trunk_spatial_ptr(vince_trunk_t t, const void* workspace);
  * vince_trunk_forward / _forward_folded with input == NULL. */
 void* vince_trunk_input_ptr(vince_trunk_t t, void* workspace, int32_t* row_width, int32_t* left);
 
+/* vince_trunk_prepare_weights in parts: 0 = every layer (the same launch), 1 = every layer BUT conv1 (resnet.py:170), 2 = conv1 alone.
+ * With the deferred stem join (vince_trunk_set_stem_event) conv1.weight is stepped last, behind its own event: the caller rebuilds the
+ * compute copies of everything else beside the stem's weight gradient (part 1) and conv1's once it has been stepped (part 2). */
+int vince_trunk_prepare_weights_part(vince_trunk_t t, const float* const* params, void* wcache, int32_t part, void* stream);
 /* Inference with the BatchNorms FOLDED into the convolutions (eval mode, running statistics; the end-task feature
  * extraction of end_task_base_solver.py:199-212 / vince_model.py:97-117 `extract_features`): no BatchNorm pass at all.
  * _prepare_weights_folded writes w * gamma/sqrt(var+eps) (compute dtype) and the per-channel bias beta - mean*scale into

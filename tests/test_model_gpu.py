@@ -704,6 +704,16 @@ def test_deferred_stem_join_steps_the_same_parameters(dtype, monkeypatch):
         assert float((conv1.detach() - want).abs().max()) < 1e-3 * moved + 1e-9, "conv1.weight was stepped with a partial gradient"
         kwant = mom * k0 + (1.0 - mom) * want
         assert float((kconv1.detach() - kwant).abs().max()) < 1e-3 * (1.0 - mom) * moved + 1e-9, "the key encoder averaged a stale conv1.weight"
+        # the compute-dtype weight copies were rebuilt ahead of the next forward in two parts (everything but conv1 beside the stem's
+        # weight gradient, conv1 behind its step): they must equal a fresh full rebuild from the stepped parameters, byte for byte
+        for net in (solver.model, solver.queue_model.queue_network):
+            if defer:
+                assert net._wcache_version == net._param_version, "the early rebuild did not declare the cache current"
+            have = net._wcache.clone()
+            next(iter(net._trunks.values())).prepare_weights(net._param_ptrs, net._wcache)
+            torch.cuda.synchronize()
+            if defer:
+                assert torch.equal(have, net._wcache), "weight cache rebuilt in parts differs from a full rebuild"
         q = {n: p.detach().float().cpu().clone() for n, p in solver.model.named_parameters()}
         k = {n: p.detach().float().cpu().clone() for n, p in solver.queue_model.queue_network.named_parameters()}
         for _ in range(3):
@@ -1180,8 +1190,9 @@ def test_backward_with_a_deeper_dy_ring_and_the_old_wgrad_kernel_gives_the_same_
         assert d < max(3 * noise, 1e-3) and d < 0.3, (tag, d, noise)
 
 
-def test_bench_multi_rank_launch_contract_on_one_gpu():
-    """The driver's N > 1 launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) with four
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_multi_rank_launch_contract_on_one_gpu(ranks):
+    """The driver's N > 1 launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) with N = 2 and 4
     ranks sharing this GPU through gloo (VINCE_BENCH_ONE_GPU=1): rendezvous from the environment, bucketed gradient
     all-reduce, key all-gather, max-over-ranks timing -- and exactly ONE JSON line, printed by rank 0, for the whole job."""
     import json
@@ -1193,16 +1204,17 @@ def test_bench_multi_rank_launch_contract_on_one_gpu():
         port = sock.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VINCE_BENCH_ONE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1",
            "--backbone", "ResNet18", "--batch", "16", "--size", "64", "--queue", "512", "--embed", "64", "--no-extras"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 4 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp4" and d["config"]["frames_per_step"] == 128
+    assert d["n_gpus"] == ranks and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 16 * ranks and d["config"]["parallelism"] == "dp%d" % ranks
+    assert d["config"]["frames_per_step"] == 32 * ranks
     assert d["config"]["workload"].startswith("not a BASELINE configuration")
     assert np.isfinite(d["config"]["final_loss"])
 

@@ -156,6 +156,7 @@ PROTOTYPES = {
                                            c_void_p]),
     "vince_trunk_set_bucket_callback": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vince_trunk_set_stem_event": (c_int, [c_void_p, c_void_p]),
+    "vince_trunk_prepare_weights_part": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_trunk_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                      c_void_p]),
     "vince_trunk_num_blocks": (c_int32, [c_void_p]),
@@ -165,7 +166,7 @@ _LIB = None
 
 
 # include/vince_hip.h VINCE_ABI_VERSION (tests/test_abi_cpu.py holds the two together)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def lib():

@@ -720,7 +720,8 @@ namespace {
 
 // Batched weight prep shared by the training cache (scale == nullptr) and the BatchNorm-folded inference cache
 // (fold_scale: float[sum of BN channels] in BN order, inside the cache).  `which` selects the cached descriptor table.
-int prepare_common(vince_trunk* t, const float* const* params, void* wcache, const float* fold_scale, int which, void* stream) {
+// part: 0 = every layer, 1 = every layer but the stem (table entry 0), 2 = the stem alone (vince_trunk_prepare_weights_part)
+int prepare_common(vince_trunk* t, const float* const* params, void* wcache, const float* fold_scale, int which, void* stream, int part = 0) {
     std::vector<vince_prep_entry> tab;
     auto scale_of = [&](const BnL& b) -> const float* { return fold_scale ? fold_scale + b.consts / 4 : nullptr; };
     auto add = [&](const ConvL& c, const BnL& b) {
@@ -760,7 +761,10 @@ int prepare_common(vince_trunk* t, const float* const* params, void* wcache, con
         t->prep_table_dev[which] = dev_table;
     }
     // (VINCE_F32X3: the split-half weight layout -- IEEE half pairs in the forward copies, bfloat16 pairs in the transposed ones)
-    return vince_prepare_weights_batched(t->cf == VINCE_F32X3H ? VINCE_F32X3 : t->sdtype, (const vince_prep_entry*)dev_table, (int32_t)tab.size(), stream);
+    const vince_prep_entry* first = (const vince_prep_entry*)dev_table + (part == 1 ? 1 : 0);
+    const int32_t count = part == 0 ? (int32_t)tab.size() : part == 1 ? (int32_t)tab.size() - 1 : 1;
+    if (count <= 0) return VINCE_OK;
+    return vince_prepare_weights_batched(t->cf == VINCE_F32X3H ? VINCE_F32X3 : t->sdtype, first, count, stream);
 }
 
 // fold constants inside a folded weight cache: scale[c] and bias[c] per BN channel (BN order, offset b.consts / 4), then
@@ -774,6 +778,12 @@ inline float* fold_ones(vince_trunk* t, void* wcache) { return fold_bias(t, wcac
 extern "C" int vince_trunk_prepare_weights(vince_trunk_t t, const float* const* params, void* wcache, void* stream) {
     VINCE_CHECK_ARG(t && params && wcache, VINCE_E_ARG, "vince_trunk_prepare_weights: null pointer");
     return prepare_common(t, params, wcache, nullptr, 0, stream);
+}
+
+extern "C" int vince_trunk_prepare_weights_part(vince_trunk_t t, const float* const* params, void* wcache, int32_t part, void* stream) {
+    VINCE_CHECK_ARG(t && params && wcache, VINCE_E_ARG, "vince_trunk_prepare_weights_part: null pointer");
+    VINCE_CHECK_ARG(part >= 0 && part <= 2, VINCE_E_ARG, "vince_trunk_prepare_weights_part: part %d (0 all, 1 all but the stem, 2 the stem)", part);
+    return prepare_common(t, params, wcache, nullptr, 0, stream, part);
 }
 
 extern "C" int vince_trunk_prepare_weights_folded(vince_trunk_t t, const float* const* params, float* const* bn_running,

@@ -76,8 +76,13 @@ class Trunk:
         except Exception:
             pass
 
-    def prepare_weights(self, param_ptrs, wcache):
-        check(lib().vince_trunk_prepare_weights(self._h, param_ptrs, ctypes.c_void_p(wcache.data_ptr()), ops.stream_ptr()))
+    def prepare_weights(self, param_ptrs, wcache, part=0):
+        """part: 0 every layer, 1 every layer but the stem, 2 the stem alone (include/vince_hip.h vince_trunk_prepare_weights_part)."""
+        if part == 0:
+            check(lib().vince_trunk_prepare_weights(self._h, param_ptrs, ctypes.c_void_p(wcache.data_ptr()), ops.stream_ptr()))
+        else:
+            check(lib().vince_trunk_prepare_weights_part(self._h, param_ptrs, ctypes.c_void_p(wcache.data_ptr()), int(part),
+                                                         ops.stream_ptr()))
 
     def forward(self, param_ptrs, wcache, bn_running_ptrs, bn_nbt_ptrs, data, workspace, pooled, train_bn, perm=None,
                 jigsaw_src=None, save=True):

@@ -398,6 +398,20 @@ class VinceModel(BaseModel):
             self._head_t = _TransposedHeads(self._head_params)
             self._wcache_version = self._param_version
 
+    def prepare_weights_early(self, part):
+        """The compute-dtype weight copies rebuilt AHEAD of the next forward (engine.Trunk.prepare_weights parts 1 / 2), for the callers
+        that step conv1.weight behind the stem event: part 1 right after every other parameter has been stepped -- the launch then runs
+        beside the stem's weight gradient instead of at the head of the next forward -- part 2 once conv1.weight is final.
+        `weights_current()` declares the cache up to date afterwards.  False: nothing to rebuild yet (no forward has run)."""
+        if self._wcache is None or not self._trunks or os.environ.get("VINCE_EARLY_PREP", "1") == "0":   # (=0: A/B measurements)
+            return False
+        next(iter(self._trunks.values())).prepare_weights(self._param_ptrs, self._wcache, part=part)
+        return True
+
+    def weights_current(self):
+        self._head_t = _TransposedHeads(self._head_params)
+        self._wcache_version = self._param_version
+
     def _ensure_folded_weights(self, trunk):
         """Inference cache: BatchNorms folded into the conv weights (eval mode only).  Rebuilt when parameters change
         (_touch) or a train-mode forward has moved the running statistics."""
@@ -749,10 +763,14 @@ class VinceQueueModel(BaseModel):
                 # the stem's weight gradient, then finish that step and average the first range
                 n1 = encoder_model._offs[1]
                 ops.ema_flat(kflat[n1:n_ema], qflat[n1:n_ema], float(momentum))
+                early = self.queue_network.prepare_weights_early(1)      # (beside the stem's weight gradient, like the two above)
                 encoder_model.finish_deferred_step()
                 ops.ema_flat(kflat[:n1], qflat[:n1], float(momentum))
-            else:
-                ops.ema_flat(kflat[:n_ema], qflat[:n_ema], float(momentum))
+                self.queue_network._touch()
+                if early and self.queue_network.prepare_weights_early(2):
+                    self.queue_network.weights_current()
+                return
+            ops.ema_flat(kflat[:n_ema], qflat[:n_ema], float(momentum))
         self.queue_network._touch()
 
     def vince_update(self, encoder_model):

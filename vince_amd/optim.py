@@ -43,6 +43,7 @@ class FlatSGD:
         if getattr(self.model, "_grad_zero_pending", False):   # zero_grad() with no backward since: gradients are zero
             grad.zero_()
             self.model._grad_zero_pending = False
+        deferred_trunk = None
         for role, (a, b) in self.model._segments.items():
             if self.model._touched.get(role, False):
                 self._ever_touched.add(role)
@@ -55,17 +56,26 @@ class FlatSGD:
                     ops.sgd_flat(flat[n1:b], grad[n1:b], self.momentum_buffer[n1:b], lr, self.momentum, self.weight_decay,
                                  self.grad_scale)
 
+                    early = [False]
+
                     def finish(a=a, n1=n1, lr=lr, scale=self.grad_scale):
                         self.model.finish_stem_grad()
                         f, g, _, _ = self.model.flat_parameters()
                         ops.sgd_flat(f[a:n1], g[a:n1], self.momentum_buffer[a:n1], lr, self.momentum, self.weight_decay, scale)
+                        if early[0] and self.model.prepare_weights_early(2):
+                            self.model.weights_current()     # (runs after step() has bumped the parameter version)
                     if defer_stem:
                         self.model._deferred_step = finish
+                        deferred_trunk = early
                     else:
                         finish()
                     continue
                 ops.sgd_flat(flat[a:b], grad[a:b], self.momentum_buffer[a:b], lr, self.momentum, self.weight_decay,
                              self.grad_scale)
+        if deferred_trunk is not None:
+            # every parameter but conv1.weight has its new value: rebuild their compute copies now, beside the stem's weight gradient
+            # (the head ranges were stepped by the launches above; the trunk's table entry 0 follows in finish())
+            deferred_trunk[0] = self.model.prepare_weights_early(1)
         self.model._touch()
         if self._extra is not None:
             for g in self._extra.param_groups:
