@@ -1002,6 +1002,30 @@ def test_bf16_stores_round_to_nearest_even_like_the_reference():
     assert torch.equal(got[63], want)
 
 
+@pytest.mark.parametrize("rows,cin,cout", [(16, 512, 512), (144, 512, 64), (16, 4608, 512), (256, 2048, 2048), (256, 2048, 128)])
+def test_head_linear_split_half_vs_fp64(rows, cin, cout):
+    """The projection head's Linear layers (vince_model.py:38-42) as split-half products of bfloat16 halves -- what a bf16-trunk model
+    runs (models/vince_model.py _HeadCopies) -- against fp64: forward (bias + ReLU, the tiny-M reduction split over workgroups with
+    atomics) within 2e-5 of max |y|, both gradients within 5e-5; and operands far outside the IEEE-half range stay finite (the reason
+    the head takes bfloat16 halves, not the trunk's IEEE-half ones)."""
+    ops = _ops()
+    x = torch.relu(rnd(rows, cin, seed=31)).to(DEV)
+    w = (rnd(cout, cin, seed=32) * (2.0 / cin) ** 0.5).to(DEV)
+    b = (rnd(cout, seed=33) * 0.1).to(DEV)
+    wk, wt = ops.prepare_weight(w.view(cout, 1, cin), torch.float32, want_transposed=True, x3="b")
+    y = ops.linear_fwd(x, wk, b, relu=True, x3="b")
+    ref = torch.relu(x.double() @ w.double().t() + b.double())
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert torch.isfinite(ops.linear_fwd(x * 1e6, wk, b, relu=True, x3="b")).all()
+    dy = (rnd(rows, cout, seed=34) * 1e-3).to(DEV)
+    dw, db = torch.zeros(cout, cin, device=DEV), torch.zeros(cout, device=DEV)
+    dx = ops.linear_bwd(x, wt, dy, dw, db, x3=True)
+    rdx, rdw = dy.double() @ w.double(), dy.double().t() @ x.double()
+    assert float((dx.double() - rdx).abs().max() / rdx.abs().max()) < 5e-5
+    assert float((dw.double() - rdw).abs().max() / rdw.abs().max()) < 5e-5
+    np.testing.assert_allclose(db.cpu().numpy(), dy.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
 @pytest.mark.parametrize("pieces", [1, 2, 3, 1023, 4097, 65537])
 def test_stream_copy_copies_every_byte(pieces):
     """The library's own copy kernel (the streaming ceiling of bench.py's roofline leg) in every shape, on piece counts that are odd /

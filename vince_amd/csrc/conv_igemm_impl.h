@@ -699,6 +699,28 @@ int launch_x3(ConvParams& p, hipStream_t stream) {
         }
         if (x3_cfg == 1 && cpt % 8 == 0 && p.total_chunks % 8 == 0 && k_elems > 128) {
             p.nkt = p.total_chunks / 8;
+            // Tiny-M GEMMs (the projection MLP: 256 rows = 2 pixel tiles): split the reduction over grid.y as the fp32 path does --
+            // partial sums meet in a zeroed output through fp32 atomics, ReLU runs afterwards (round 5: the head through split-half
+            // products, 3 x 16-bit MFMAs per product against exact fp32 MFMAs at a sixteenth of that rate)
+            const long tiles = (long)p.ptiles * p.ctiles;
+            int splits = 1;
+            if (MODE == 0 && !p.e.stats && tiles < 128 && p.nkt >= 16 && p.d.osh == 1 && p.d.osw == 1 && p.d.OH == p.d.Ho && p.d.OW == p.d.Wo) {
+                splits = (int)min((long)(p.nkt / 8), (256 + tiles - 1) / tiles);
+                if (splits < 2) splits = 1;
+            }
+            if (splits > 1) {
+                const int relu = p.e.flags & VINCE_EPI_RELU;
+                p.e.flags &= ~VINCE_EPI_RELU;
+                p.kt_per_split = (p.nkt + splits - 1) / splits;
+                splits = (p.nkt + p.kt_per_split - 1) / p.kt_per_split;
+                const size_t n = (size_t)p.M * p.d.Co;
+                if (int zrc = vince_zero_async(p.out, n * sizeof(float), stream)) return zrc;
+                hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 2, 2, PT, MODE, false, 1>), dim3(p.ptiles * p.ctiles, splits), dim3(256), 0, stream, p);
+                if (relu) hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)min((size_t)1024, (n / 4 + 255) / 256)), dim3(256), 0,
+                                             stream, (float*)p.out, n / 4);
+                VINCE_CHECK_LAUNCH();
+                return VINCE_OK;
+            }
             hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 8, 2, 2, PT, MODE, false, 1>), grid, dim3(256), 0, stream, p);
         } else if (k_elems >= x3_s3_min_k) {
             hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE, false, 1>), grid, dim3(256), 0, stream, p);

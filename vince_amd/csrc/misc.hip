@@ -234,6 +234,7 @@ template <typename T> __device__ __forceinline__ void x3_store_group(void* dst, 
     }
 }
 
+template <typename WKT>
 __device__ void prep_x3_entry(const vince_prep_entry& e, unsigned char* tile_raw) {
     const float* __restrict__ w = (const float*)e.w;
     const float* __restrict__ sc = e.scale;
@@ -251,7 +252,7 @@ __device__ void prep_x3_entry(const vince_prep_entry& e, unsigned char* tile_raw
                 const int k = k0 + i, kw = k / e.Cs, c = k - kw * e.Cs;
                 v[i] = (kw < e.Kw && c < e.Ci) ? w[((size_t)r * e.Kw + kw) * e.Ci + c] * m : 0.f;
             }
-            x3_store_group<x3h_t>(wk + ((size_t)r * e.Cip + k0) * 4, v);
+            x3_store_group<WKT>(wk + ((size_t)r * e.Cip + k0) * 4, v);
         }
         return;
     }
@@ -276,7 +277,7 @@ __device__ void prep_x3_entry(const vince_prep_entry& e, unsigned char* tile_raw
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) tile[row][grp * 16 + i] = v[i];
-                x3_store_group<x3h_t>(wk + off * 4, v);
+                x3_store_group<WKT>(wk + off * 4, v);
             }
             __syncthreads();
             {
@@ -299,7 +300,7 @@ __device__ void prep_x3_entry(const vince_prep_entry& e, unsigned char* tile_raw
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = (k0 + i) < e.Ci ? w[((size_t)co * e.T + t) * e.Ci + k0 + i] * m : 0.f;
-            x3_store_group<x3h_t>(wk + ((size_t)r * e.Cip + k0) * 4, v);
+            x3_store_group<WKT>(wk + ((size_t)r * e.Cip + k0) * 4, v);
         }
         if (wt) {
             const int64_t tg = (int64_t)e.Ci * e.T * (e.Co / 16);
@@ -318,11 +319,14 @@ __device__ void prep_x3_entry(const vince_prep_entry& e, unsigned char* tile_raw
 
 __global__ __launch_bounds__(256) void prepare_weights_batched_x3_kernel(const vince_prep_entry* __restrict__ table) {
     __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 65 * 4];
-    prep_x3_entry(table[blockIdx.y], tile);
+    prep_x3_entry<x3h_t>(table[blockIdx.y], tile);
 }
+// WKT: the element type of the forward copy -- x3h_t (IEEE half pairs: the trunk's forward launches) or x3b_t (bfloat16 pairs: fp32's
+// exponent range at 2^-16 per product, for operands no BatchNorm keeps inside the half range: the projection head)
+template <typename WKT>
 __global__ __launch_bounds__(256) void prepare_weight_x3_kernel(const vince_prep_entry e) {
     __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 65 * 4];
-    prep_x3_entry(e, tile);
+    prep_x3_entry<WKT>(e, tile);
 }
 
 template <typename T>
@@ -483,13 +487,14 @@ extern "C" int vince_prepare_weight(int dtype, const float* w, void* wk, void* w
                                     int32_t Cip, void* stream) {
     VINCE_CHECK_ARG(w && wk && Co > 0 && T > 0 && Ci > 0 && Cip >= Ci, VINCE_E_ARG, "vince_prepare_weight: bad arguments");
     const int64_t total = (int64_t)Co * T * Cip;
-    if (dtype == VINCE_F32X3) {   // split-half layout: wk = IEEE half pairs (forward), wt = bfloat16 pairs (gradients)
+    if (dtype == VINCE_F32X3 || dtype == VINCE_F32X3B) {   // split-half layout: wk = IEEE half pairs (VINCE_F32X3B: bfloat16 pairs), wt = bfloat16 pairs (gradients)
         VINCE_CHECK_ARG(Cip % 16 == 0 && (!wt || Co % 16 == 0), VINCE_E_SHAPE,
                         "vince_prepare_weight: the split-half layout needs Cip (and Co for the transposed copy) to be multiples of 16");
         vince_prep_entry e;
         e.w = w; e.wk = wk; e.wt = wt; e.scale = nullptr;
         e.Co = Co; e.T = T; e.Ci = Ci; e.Cip = Cip; e.Cs = e.Kw = 0;
-        hipLaunchKernelGGL(prepare_weight_x3_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, e);
+        if (dtype == VINCE_F32X3B) hipLaunchKernelGGL(prepare_weight_x3_kernel<x3b_t>, dim3(512), dim3(256), 0, (hipStream_t)stream, e);
+        else hipLaunchKernelGGL(prepare_weight_x3_kernel<x3h_t>, dim3(512), dim3(256), 0, (hipStream_t)stream, e);
         VINCE_CHECK_LAUNCH();
         return VINCE_OK;
     }

@@ -138,6 +138,34 @@ class _TransposedHeads(dict):
         return wt
 
 
+class _HeadCopies(dict):
+    """Split-half compute copies of the head Linears (round 5, bf16 trunk only: the projection MLP as hi*hi + hi*lo + lo*hi of BFLOAT16
+    halves -- three 16-bit MFMAs per product, 2^-16 per product, fp32's exponent range -- instead of exact fp32 MFMAs at a sixteenth of
+    that rate; the fp32 and x3 trunks, the modes held to the reference's 1e-3 bar, keep the exact fp32 head).  bfloat16 halves, not the
+    IEEE-half halves of the trunk's forward: nothing normalises the head's operands, and a half-range overflow (|x| >= 4095) turns
+    into NaN by design (csrc/common.h) -- a toy run that diverges for a few steps must not die of its head.
+    ops.prepare_weight(x3="b") gives the forward copy and, where a backward will follow, the transposed one in ONE launch, which also
+    replaces the W^T launches of _TransposedHeads.  Made on first use after every parameter update."""
+
+    def __init__(self, params):
+        super().__init__()
+        self._params = {id(p): p for p in params if p.dim() == 2}
+
+    def copies(self, key, need_t):
+        have = self.get(key)
+        if have is None or (need_t and have[1] is None):
+            p = self._params[key]
+            co, ci = p.shape
+            have = ops.prepare_weight(p.data.view(co, 1, ci), torch.float32, want_transposed=need_t, x3="b")
+            self[key] = have
+        return have
+
+
+def head_x3():
+    """VINCE_HEAD_X3=0: the head stays on exact fp32 MFMAs (cross-check / A-B switch)."""
+    return os.environ.get("VINCE_HEAD_X3", "1") != "0"
+
+
 class LazySimilarities:
     """Stand-in for the reference's ``vince_similarities`` tensor: shape is known, values are produced on demand."""
 
@@ -396,6 +424,7 @@ class VinceModel(BaseModel):
         if self._wcache_version != self._param_version:
             trunk.prepare_weights(self._param_ptrs, self._wcache)
             self._head_t = _TransposedHeads(self._head_params)
+            self._head_c = _HeadCopies(self._head_params)
             self._wcache_version = self._param_version
 
     def prepare_weights_early(self, part):
@@ -410,6 +439,7 @@ class VinceModel(BaseModel):
 
     def weights_current(self):
         self._head_t = _TransposedHeads(self._head_params)
+        self._head_c = _HeadCopies(self._head_params)
         self._wcache_version = self._param_version
 
     def _ensure_folded_weights(self, trunk):
@@ -480,17 +510,23 @@ class VinceModel(BaseModel):
         # cannot see through, and every discarded model would keep its workspaces: tens of GB per solver at the benchmark size)
         saved = dict(trunk=trunk, pooled=pooled.detach(), jigsaw=jigsaw)
         if with_head:
+            hx3 = head_x3() and self.compute_dtype == torch.bfloat16
+
+            def lin(x, layer, relu=False):   # one head Linear: split-half products on its prepared copy, or exact fp32 MFMAs
+                if hx3 and layer.weight.shape[0] % 16 == 0 and layer.weight.shape[1] % 16 == 0:
+                    return ops.linear_fwd(x, self._head_c.copies(id(layer.weight), bool(save))[0], layer.bias.data, relu=relu, x3="b")
+                return ops.linear_fwd(x, layer.weight.data, layer.bias.data, relu=relu)
             if jigsaw:   # vince_model.py:161-171
-                f = ops.linear_fwd(pooled, self.jigsaw_linear.weight.data, self.jigsaw_linear.bias.data)
+                f = lin(pooled, self.jigsaw_linear)
                 c = f.shape[1]
                 idx = orders.to(f.device).unsqueeze(-1).expand(n, 9, c)
                 g = torch.gather(f.view(n, 9, c), 1, idx).reshape(n, 9 * c).contiguous()
-                hid = ops.linear_fwd(g, self.jigsaw_embedding[0].weight.data, self.jigsaw_embedding[0].bias.data, relu=True)
-                pre = ops.linear_fwd(hid, self.jigsaw_embedding[2].weight.data, self.jigsaw_embedding[2].bias.data)
+                hid = lin(g, self.jigsaw_embedding[0], relu=True)
+                pre = lin(hid, self.jigsaw_embedding[2])
                 saved.update(g=g, hid=hid, orders=orders.to(f.device))
             else:        # vince_model.py:175-177
-                hid = ops.linear_fwd(pooled, self.embedding[0].weight.data, self.embedding[0].bias.data, relu=True)
-                pre = ops.linear_fwd(hid, self.embedding[2].weight.data, self.embedding[2].bias.data)
+                hid = lin(pooled, self.embedding[0], relu=True)
+                pre = lin(hid, self.embedding[2])
                 saved.update(hid=hid)
             emb, norms = ops.l2norm_fwd(pre)   # F.normalize(dim=1), vince_model.py:180
             saved.update(pre=pre.detach(), norms=norms)
@@ -513,21 +549,28 @@ class VinceModel(BaseModel):
             if d_pre is not None:
                 dpre = d_pre.contiguous().float() if dpre is None else dpre + d_pre
             self._touched["jigsaw" if s["jigsaw"] else "embedding"] = True
+            hx3 = head_x3() and self.compute_dtype == torch.bfloat16
+
+            def lbwd(x, layer, dy):          # gradients of one head Linear, on the route its forward took
+                w = layer.weight
+                if hx3 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0:
+                    return ops.linear_bwd(x, self._head_c.copies(id(w), True)[1], dy, hg[id(w)], hg[id(layer.bias)], x3=True)
+                return ops.linear_bwd(x, ht[id(w)], dy, hg[id(w)], hg[id(layer.bias)])
             if s["jigsaw"]:
                 l0, l2, lj = self.jigsaw_embedding[0], self.jigsaw_embedding[2], self.jigsaw_linear
-                dh = ops.linear_bwd(s["hid"], ht[id(l2.weight)], dpre, hg[id(l2.weight)], hg[id(l2.bias)])
+                dh = lbwd(s["hid"], l2, dpre)
                 dh = ops.relu_bwd(dh, s["hid"])
-                dg = ops.linear_bwd(s["g"], ht[id(l0.weight)], dh, hg[id(l0.weight)], hg[id(l0.bias)])
+                dg = lbwd(s["g"], l0, dh)
                 n, c = dg.shape[0], dg.shape[1] // 9
                 df = torch.zeros(n, 9, c, device=dg.device)
                 df.scatter_(1, s["orders"].unsqueeze(-1).expand(n, 9, c), dg.view(n, 9, c))
                 df = df.view(n * 9, c).contiguous()
-                dp = ops.linear_bwd(s["pooled"], ht[id(lj.weight)], df, hg[id(lj.weight)], hg[id(lj.bias)])
+                dp = lbwd(s["pooled"], lj, df)
             else:
                 l0, l2 = self.embedding[0], self.embedding[2]
-                dh = ops.linear_bwd(s["hid"], ht[id(l2.weight)], dpre, hg[id(l2.weight)], hg[id(l2.bias)])
+                dh = lbwd(s["hid"], l2, dpre)
                 dh = ops.relu_bwd(dh, s["hid"])
-                dp = ops.linear_bwd(s["pooled"], ht[id(l0.weight)], dh, hg[id(l0.weight)], hg[id(l0.bias)])
+                dp = lbwd(s["pooled"], l0, dh)
             dpool_total = dp if dpool_total is None else dpool_total + dp
         if dpool_total is None:
             return

@@ -267,12 +267,14 @@ def conv_wgrad_det(desc, x, dy, dw, ci_dw=None, scratch=None, x3=None):
 
 
 # ------------------------------------------------------------------------------------------------ linear layer helpers (fp32)
-def linear_fwd(x, weight, bias, relu=False):
-    """y = [relu](x @ weight.T + bias) on the fp32 MFMA path (vince_model.py:38-42)."""
+def linear_fwd(x, weight, bias, relu=False, x3=False):
+    """y = [relu](x @ weight.T + bias) (vince_model.py:38-42) on the fp32 MFMA path, or -- x3 = True / "h" / "b": `weight` is the
+    split-half copy prepare_weight(..., x3=...) returned (IEEE half pairs / bfloat16 pairs for "b") -- as split-half products."""
     rows, cin = x.shape
     cout = weight.shape[0]
     out = torch.empty(rows, cout, device=x.device, dtype=torch.float32)
-    conv_igemm(linear_desc(rows, cin, cout), x, weight, out, bias=bias, flags=EPI_RELU if relu else 0)
+    conv_igemm(linear_desc(rows, cin, cout), x, weight, out, bias=bias, flags=EPI_RELU if relu else 0,
+               x3=(x3 if x3 in ("h", "b") else "h") if x3 else None)
     return out
 
 
@@ -284,17 +286,18 @@ def nonfinite_latch(value, step, latch):
     check(lib().vince_nonfinite_latch(_ptr(value), int(step), _ptr(latch), stream_ptr()))
 
 
-def linear_bwd(x, weight_t, dy, dweight, dbias, need_dx=True):
-    """dweight += dy.T @ x ; dbias += dy.sum(0) ; returns dx = dy @ weight (weight_t = weight.T contiguous)."""
+def linear_bwd(x, weight_t, dy, dweight, dbias, need_dx=True, x3=False):
+    """dweight += dy.T @ x ; dbias += dy.sum(0) ; returns dx = dy @ weight (weight_t = weight.T contiguous; x3: the transposed
+    split-half copy of prepare_weight(..., x3=True) -- bfloat16 pairs -- and both gradient GEMMs as split-half products)."""
     rows, cin = x.shape
     cout = dy.shape[1]
-    conv_wgrad(linear_desc(rows, cin, cout), x, dy, dweight)
+    conv_wgrad(linear_desc(rows, cin, cout), x, dy, dweight, x3="b" if x3 else None)
     require_gpu(dbias)
     check(lib().vince_colsum(_ptr(dy), _ptr(dbias), rows, cout, stream_ptr()))
     if not need_dx:
         return None
     dx = torch.empty(rows, cin, device=x.device, dtype=torch.float32)
-    conv_igemm(linear_desc(rows, cout, cin), dy, weight_t, dx)
+    conv_igemm(linear_desc(rows, cout, cin), dy, weight_t, dx, x3="b" if x3 else None)
     return dx
 
 
@@ -534,7 +537,9 @@ def prepare_weight(w_master, dtype, cip=None, want_transposed=True, x3=False):
         raise TypeError("vince_amd: the split-half weight layout lives in float32-sized tensors")
     wk = torch.empty(Co, T, cip, device=w_master.device, dtype=dtype)
     wt = torch.empty(Ci, T, Co, device=w_master.device, dtype=dtype) if want_transposed else None
-    check(lib().vince_prepare_weight(VINCE_F32X3H if x3 else dtype_code(wk), _ptr(w_master), _ptr(wk), _ptr(wt), Co, T, Ci, cip, stream_ptr()))
+    # x3 = "b": the forward copy as bfloat16 pairs too (conv_igemm(..., x3="b") on it: fp32's exponent range, 2^-16 per product)
+    code = (VINCE_F32X3B if x3 == "b" else VINCE_F32X3H) if x3 else dtype_code(wk)
+    check(lib().vince_prepare_weight(code, _ptr(w_master), _ptr(wk), _ptr(wt), Co, T, Ci, cip, stream_ptr()))
     return wk, wt
 
 
