@@ -35,6 +35,8 @@ timeout 300 python bench.py --no-extras --input u8aug > $O/bench_u8aug.json 2>/d
 timeout 20 python tools/bench_brief.py $O/bench_u8aug.json u8aug
 # ---- round 4: the split-half mode (x3), the forward-only PMC pass, the copy ceilings
 bash tools/x3_profile.sh final_x3 > /dev/null 2>&1; cp gpurun_out/final_x3/kernel_stats_serialised.txt $O/x3_kernel_stats_serialised.txt; cp gpurun_out/final_x3/bench.json $O/x3_bench.json
+# (round 5: the x3 step profiled like the product -- per-layer roofline against 2.5 PF / 3, HBM bytes per step and family by PMC)
+cp gpurun_out/final_x3/layer_roofline.txt $O/x3_layer_roofline.txt; cp gpurun_out/final_x3/pmc_summary.txt $O/x3_pmc_summary.txt
 timeout 300 python tools/x3_micro.py final > $O/x3_micro.txt 2>&1
 bash tools/fwd_pmc.sh $O/fwd_pmc > /dev/null 2>&1; cp $O/fwd_pmc/fwd_pmc_summary.txt $O/fwd_pmc_summary.txt
 timeout 300 python tools/ceilings.py > $O/ceilings.txt 2>&1
@@ -43,6 +45,11 @@ timeout 300 python tools/xjoin_micro.py > $O/xjoin_micro.txt 2>&1
 timeout 200 python tools/dgrad_epi_micro.py > $O/dgrad_epi_micro.txt 2>&1
 # the full-size parity fixtures, with what each dtype measured against the reference printed (G9, G12: fp32 / x3 / bf16)
 timeout 1500 python -m pytest tests/test_full_size_gpu.py -q -s -k "g9 or g12" 2>&1 | grep -E "G9|G12|passed|failed" | cut -c1-600 > $O/full_size_parity.txt
+# ---- round 5: where the step's time is without a profiler, the grouped-launch bound, the same-box A/B of the round's switches
+timeout 300 python tools/step_phases.py 20 bf16 2>/dev/null | tail -1 > $O/step_phases.txt
+timeout 300 python tools/step_phases.py 10 x3 2>/dev/null | tail -1 >> $O/step_phases.txt
+timeout 400 python tools/group_bound.py 256 10 2>/dev/null | tail -2 > $O/group_bound.txt
+timeout 1500 python tools/ab.py 3 40 "BASE" "VINCE_DEFER_STEM=1" "VINCE_DEFER_STEM=0" "VINCE_EARLY_PREP=0" "VINCE_HEAD_X3=0" "VINCE_KNOBS=gram_max_k=128" > $O/ab.txt 2>&1
 export VINCE_GIT_HEAD=${VINCE_GIT_HEAD:-unknown}
 # the bench line once more, now that profiles/pmc_conv_igemm.json of THIS build exists (traffic_stale false)
 cp $O/pmc_conv_igemm.json profiles/pmc_conv_igemm.json

@@ -1,7 +1,8 @@
 """Per-layer roofline table from a VINCE_PROFILE_DUMP csv (one row per conv launch of the instrumented steps, each timed
 alone between hipEvents): for every distinct layer shape -- algorithmic FLOPs and bytes, time, TF/s, TB/s, and which roof
 binds it on this box (MFMA 2.5 PF dense bf16; HBM at the rate the library's own copy kernel reaches, default 5.28 TB/s).
-usage: layer_roofline.py dump.csv steps [hbm_TBs]"""
+usage: layer_roofline.py dump.csv steps [hbm_TBs] [x3]      (x3: the fp32-tagged launches ran as split-half products -- three 16-bit MFMAs
+per algorithmic product -- and are priced against 2.5 PF / 3 instead of the fp32 MFMA peak)"""
 import collections
 import csv
 import sys
@@ -10,6 +11,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 HBM = float(sys.argv[3]) if len(sys.argv) > 3 else 5.28
 PEAK = 2500.0
+F32_PEAK = PEAK / 3.0 if (len(sys.argv) > 4 and sys.argv[4] == "x3") else 157.3
 names = ["ig %s/%s%s" % (t, sh, e) for t in ("f32", "bf16") for sh in ("64", "64x256", "128", "128x256") for e in ("", " bwd")] + ["wg f32", "wg bf16", "m8 bf16/256x256", "m8 bf16/256x256 bwd"]
 agg = collections.OrderedDict()
 for r in rows:
@@ -37,12 +39,12 @@ for (tag, M, Co, K, taps, so, fl), (n, us, w) in sorted(agg.items(), key=lambda 
         nbytes = (M * sh * sh * ci + M * Co) * esz + Co * K * esz
         if "bwd" in names[tag] and (fl & 1):
             nbytes += M * Co * esz          # residual-gradient join: the old value of the output is read too
-    t_mfma = gflop / PEAK * 1e3 if esz == 2 else gflop / 157.3 * 1e3       # us
+    t_mfma = gflop / PEAK * 1e3 if esz == 2 else gflop / F32_PEAK * 1e3       # us
     t_hbm = nbytes / (HBM * 1e6)                                           # us
     roof = max(t_mfma, t_hbm)
     tot += us / steps
     tot_roof += roof * n / steps
     print("%-18s %8d %5d %5d %4d %4d %6.1f %8.2f %8.1f %8.1f %7.1f %7.2f %6.1f%% %5.1f%% %s (%.1f)" % (
         names[tag], M, Co, K, taps, so, n / steps, gflop, nbytes / 1e6, t_us, tf, nbytes / t_us / 1e6,
-        100 * tf / (PEAK if esz == 2 else 157.3), 100 * nbytes / t_us / 1e6 / HBM, "hbm" if t_hbm >= t_mfma else "mfma", roof))
+        100 * tf / (PEAK if esz == 2 else F32_PEAK), 100 * nbytes / t_us / 1e6 / HBM, "hbm" if t_hbm >= t_mfma else "mfma", roof))
 print("total %.2f ms/step measured, %.2f ms/step at the binding roof of every launch" % (tot / 1e3, tot_roof / 1e3))

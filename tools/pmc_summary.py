@@ -29,6 +29,11 @@ def tag_of(name):
         return "stem_pool_fwd"
     if "stem_bwd_kernel" in name or "stem_pool_bwd_kernel" in name:
         return "stem_bwd"
+    x3 = re.search(r"conv_igemm_dlds_kernelI5x3([hb])_tLi(\d+)ELi\d+ELi\d+ELi\d+ELi(\d+)EL[bi]([012])E", name)
+    if x3:      # the split-half element types (compute_dtype "x3"): fp32 tensors, IEEE-half (h) / bfloat16 (b) halves
+        return "conv_igemm<x3%s,%sch x %spx,%s>" % (x3.group(1), x3.group(2), x3.group(3), "bwd" if x3.group(4) in ("1", "2") else "fwd")
+    if "conv_wgrad_x3_kernel" in name:
+        return "conv_wgrad<x3b>"
     m = re.search(r"conv_igemm_dlds_kernelI([tf])Li(\d+)ELi\d+ELi\d+ELi\d+ELi(\d+)EL[bi]([012])E", name)
     if not m:
         m2 = re.search(r"conv_igemm_dlds_kernel<(unsigned short|float), (\d+), \d+, \d+, \d+, (\d+), (true|false|0|1|2)[,>]", name)

@@ -50,10 +50,14 @@ struct Blk {
 constexpr size_t NONE = (size_t)-1;
 // Gram-statistics residual join: conv3 reductions up to this length; replicas of the column sums
 constexpr int GRAM_R = 4;
-// (knob `gram_max_k`: 256 also sends layer3's bottlenecks down the Gram route in no-grad forwards -- the Gram matrix through the
-// weight-gradient launch, the finalize reading it from L2, the join in the implicit-GEMM kernel's epilogue)
+// 256 (round 5): layer3's bottlenecks take the Gram route too in NO-GRAD forwards (the key encoder, forward + InfoNCE) -- the Gram
+// matrix through the weight-gradient launch (15 + 7 us), vince_bn_gram_finalize with one column of G per thread (14 us), the join in
+// the implicit-GEMM kernel's epilogue (77 us) against conv3 with statistics (56) + the separate join pass (~75): the same time
+// (5.879 vs 5.865 ms per forward, 22.74 vs 22.77 ms per step), 6 fewer BatchNorm passes and 1.2 GB less HBM traffic per step.
+// Training forwards keep the separate passes there (backward reads y3; the streaming join kernel stops at K = 128).
+// knob `gram_max_k=128`: the round-4 arrangement (cross-check switch).
 int gram_max_k() {
-    static const int k = (int)vince_knob("gram_max_k", 128);
+    static const int k = (int)vince_knob("gram_max_k", 256);
     return k;
 }
 constexpr int NDY_MAX = 8;          // most slots the dY ring of the backward pass can be given (VINCE_KNOBS=dy_slots)
