@@ -16,11 +16,14 @@
 // so the 4w-wide tensors are read ONCE each (g by the raw wgrad and by the dgrad) and y is never stored.  W here is the bf16 copy the
 // forward multiplied with, so the implied y is exactly the forward's (unrounded) convolution output.
 //
-// Two small launches per block (w <= 256, 4w <= 1024: everything fits simple one-thread-per-output loops):
-//   bn3_prepare_derive_kernel   per output channel: the dot product, c1, c2, s, t, dgamma / dbeta (every workgroup, into LDS), then
-//                        wd = bf16(W^T diag(s)) [w][4w],  nq = bf16(-Q) [w][w] (row strides given: the engine interleaves them as the
+// Three small launches per block (w <= 256, 4w <= 1024: everything fits simple one-thread-per-output loops):
+//   bn3_prepare_kernel   per output channel: the dot product, c1, c2, s, t, dgamma / dbeta
+//   bn3_derive_kernel    wd = bf16(W^T diag(s)) [w][4w],  nq = bf16(-Q) [w][w] (row strides given: the engine interleaves them as the
 //                        two taps of ONE input-gradient launch, vince_conv_epi.in2),  nr = -r [w]
-//   bn3_finish_dw_kernel dW from R -- only the optimiser waits for it: the engine runs it on its weight-gradient stream
+//   bn3_finish_dw_kernel dW from R -- only the optimiser waits for it: the engine runs it on its weight-gradient stream (round 5)
+// Round 5 also tried the first two as ONE launch, every workgroup deriving all coefficients itself (a launch gap saved on backward's
+// critical path): one thread per channel (64 different rows per load instruction) 14-27 us, rows read coalesced by lane groups with
+// a shuffle fold (a chain of 64 dependent passes) 25-70 us -- against 11 + 6 us for the pair below.  Kept as two.
 #include <string.h>
 
 #include "common.h"
@@ -29,61 +32,43 @@ namespace {
 
 // coef layout: float[4][Co] = s, c1, c2, t
 constexpr int ALG_MAX_CO = 1024, ALG_MAX_K = 256;
-
-// ONE launch for the coefficients and the derived matrices (round 5; two launches before: a per-channel kernel and this one reading its
-// output -- ~10 us of launch latency per block on the critical path of backward, 7 blocks per step).  Every workgroup first derives ALL
-// per-channel coefficients itself (thread = channel: a K-long dot product <W[c,:], R[c,:]> and the fold of the sum replicas; Co x K
-// multiply-adds against one launch saved) into LDS; workgroup 0 also publishes them (coef, for bn3_finish_dw) and adds dgamma / dbeta.
-// Then, as before: blocks 0 .. K-1 produce row k of wd (and nr[k]); blocks K .. 2K-1 produce row k of nq.
-__global__ __launch_bounds__(256) void bn3_prepare_derive_kernel(const float* __restrict__ R, const bf16_t* __restrict__ W, const double* __restrict__ gsums,
-                                                                 int replicas, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                 const float* __restrict__ gamma, double inv_n, int Co, int K, float* __restrict__ coef,
-                                                                 bf16_t* __restrict__ wd, int wd_ld, bf16_t* __restrict__ nq, int nq_ld, float* __restrict__ nr,
-                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float cs[ALG_MAX_CO], cu[ALG_MAX_CO], ct[ALG_MAX_CO];   // s, s*c1 - t*mean, t
-    __shared__ float red[256];
-    __shared__ float tk[ALG_MAX_CO];
-    const int tid = threadIdx.x;
-    for (int c = tid; c < Co; c += 256) {
-        const float4* __restrict__ r4 = (const float4*)(R + (size_t)c * K);
-        const uint2* __restrict__ w4 = (const uint2*)(W + (size_t)c * K);
-        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < K / 4; ++k) {
-            const float4 r = r4[k];
-            const uint2 w = w4[k];
-            d0 += __uint_as_float(w.x << 16) * r.x;
-            d1 += __uint_as_float(w.x & 0xffff0000u) * r.y;
-            d2 += __uint_as_float(w.y << 16) * r.z;
-            d3 += __uint_as_float(w.y & 0xffff0000u) * r.w;
-        }
-        const double dot = (double)((d0 + d1) + (d2 + d3));
+__global__ __launch_bounds__(256) void bn3_prepare_kernel(const float* __restrict__ R, const bf16_t* __restrict__ W, const double* __restrict__ gsums,
+                                                          int replicas, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, double inv_n, int Co, int K, float* __restrict__ coef,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wavefront per channel
+    if (c >= Co) return;
+    float dot = 0.f;
+    for (int k = lane; k < K; k += 64) dot += bf16_to_f32(W[(size_t)c * K + k]) * R[(size_t)c * K + k];
+    dot = wave_sum(dot);
+    if (lane == 0) {
         double sg = 0;
         for (int r = 0; r < replicas; ++r) sg += gsums[((size_t)r * Co + c) * 2];
         const double is = invstd[c], mu = mean[c];
-        const double sgx = is * (dot - mu * sg);
-        const double sv = (double)gamma[c] * is, c1 = sg * inv_n, c2 = sgx * inv_n;
-        const float sf = (float)sv, c1f = (float)c1, tf = (float)(sv * c2 * is);
-        cs[c] = sf;
-        ct[c] = tf;
-        cu[c] = sf * c1f - tf * mean[c];
-        if (blockIdx.x == 0) {
-            coef[c] = sf;
-            coef[Co + c] = c1f;
-            coef[2 * Co + c] = (float)c2;
-            coef[3 * Co + c] = tf;
-            dgamma[c] += (float)sgx;
-            dbeta[c] += (float)sg;
-        }
+        const double sgx = is * ((double)dot - mu * sg);
+        const double s = (double)gamma[c] * is, c1 = sg * inv_n, c2 = sgx * inv_n;
+        coef[c] = (float)s;
+        coef[Co + c] = (float)c1;
+        coef[2 * Co + c] = (float)c2;
+        coef[3 * Co + c] = (float)(s * c2 * is);
+        dgamma[c] += (float)sgx;
+        dbeta[c] += (float)sg;
     }
-    __syncthreads();
+}
+
+// grid: blocks 0 .. K-1 produce row k of wd (and nr[k]); blocks K .. 2K-1 produce row k of nq
+__global__ __launch_bounds__(256) void bn3_derive_kernel(const bf16_t* __restrict__ W, const float* __restrict__ coef, const float* __restrict__ mean,
+                                                         int Co, int K, bf16_t* __restrict__ wd, int wd_ld, bf16_t* __restrict__ nq, int nq_ld, float* __restrict__ nr) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
     if ((int)blockIdx.x < K) {
         const int k = blockIdx.x;
         float acc = 0.f;
         for (int c = tid; c < Co; c += 256) {
             const float w = bf16_to_f32(W[(size_t)c * K + k]);
-            wd[(size_t)k * wd_ld + c] = f32_to_bf16(cs[c] * w);
-            acc += w * cu[c];
+            const float s = coef[c], c1 = coef[Co + c], t = coef[3 * Co + c];
+            wd[(size_t)k * wd_ld + c] = f32_to_bf16(s * w);
+            acc += w * (s * c1 - t * mean[c]);
         }
         red[tid] = acc;
         __syncthreads();
@@ -95,8 +80,9 @@ __global__ __launch_bounds__(256) void bn3_prepare_derive_kernel(const float* __
     } else {
         // nq[k][j] = -sum_c W[c][k] t[c] W[c][j].  Column k of W scaled by t is staged in LDS once; thread = (j, part): the Co
         // reduction is split over the 256 / K parts of a column (row c of W is read coalesced across j), folded through LDS.
+        __shared__ float tk[ALG_MAX_CO];
         const int k = blockIdx.x - K;
-        for (int c = tid; c < Co; c += 256) tk[c] = ct[c] * bf16_to_f32(W[(size_t)c * K + k]);
+        for (int c = tid; c < Co; c += 256) tk[c] = coef[3 * Co + c] * bf16_to_f32(W[(size_t)c * K + k]);
         __syncthreads();
         const int parts = 256 / K, j = tid % K, part = tid / K;
         float acc = 0.f;
@@ -147,8 +133,10 @@ extern "C" int vince_bn3_bwd_prepare(const float* R, const void* w_bf16, const d
     VINCE_CHECK_ARG(count > 0 && Co > 0 && Co <= ALG_MAX_CO && (K == 64 || K == 128 || K == 256), VINCE_E_SHAPE,
                     "vince_bn3_bwd_prepare: K=%d (64, 128 or 256), Co=%d (at most %d)", K, Co, ALG_MAX_CO);
     if (replicas <= 0 || replicas > VINCE_STATS_REPLICAS) replicas = VINCE_STATS_REPLICAS;
-    hipLaunchKernelGGL(bn3_prepare_derive_kernel, dim3(2 * K), dim3(256), 0, (hipStream_t)stream, R, (const bf16_t*)w_bf16, gsums, replicas,
-                       mean, invstd, gamma, 1.0 / (double)count, Co, K, coef, (bf16_t*)wd, wd_ld, (bf16_t*)nq, nq_ld, nr, dgamma, dbeta);
+    hipLaunchKernelGGL(bn3_prepare_kernel, dim3((Co + 3) / 4), dim3(256), 0, (hipStream_t)stream, R, (const bf16_t*)w_bf16, gsums, replicas,
+                       mean, invstd, gamma, 1.0 / (double)count, Co, K, coef, dgamma, dbeta);
+    hipLaunchKernelGGL(bn3_derive_kernel, dim3(2 * K), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_bf16, (const float*)coef, mean, Co, K,
+                       (bf16_t*)wd, wd_ld, (bf16_t*)nq, nq_ld, nr);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }

@@ -161,6 +161,14 @@ class _HeadCopies(dict):
         return have
 
 
+def _head_x3_shape(w):
+    """Which head Linears take the split-half route: both dimensions multiples of 16 (the split weight layout) and at most 2^23
+    elements -- the copies are rebuilt after every parameter update (read once, written twice), which a 2048 x 2048 weight repays in its
+    three GEMMs and the jigsaw head's 2048 x 18432 (151 MB, 64 rows per step) does not: 0.53 ms of preparation per step for GEMMs that
+    read the weight at the HBM rate either way (`profiles/r05_c5_kernel_stats_before_head_limit.txt`)."""
+    return w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0 and w.numel() <= (1 << 23)
+
+
 def head_x3():
     """VINCE_HEAD_X3=0: the head stays on exact fp32 MFMAs (cross-check / A-B switch)."""
     return os.environ.get("VINCE_HEAD_X3", "1") != "0"
@@ -513,7 +521,7 @@ class VinceModel(BaseModel):
             hx3 = head_x3() and self.compute_dtype == torch.bfloat16
 
             def lin(x, layer, relu=False):   # one head Linear: split-half products on its prepared copy, or exact fp32 MFMAs
-                if hx3 and layer.weight.shape[0] % 16 == 0 and layer.weight.shape[1] % 16 == 0:
+                if hx3 and _head_x3_shape(layer.weight):
                     return ops.linear_fwd(x, self._head_c.copies(id(layer.weight), bool(save))[0], layer.bias.data, relu=relu, x3="b")
                 return ops.linear_fwd(x, layer.weight.data, layer.bias.data, relu=relu)
             if jigsaw:   # vince_model.py:161-171
@@ -553,7 +561,7 @@ class VinceModel(BaseModel):
 
             def lbwd(x, layer, dy):          # gradients of one head Linear, on the route its forward took
                 w = layer.weight
-                if hx3 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0:
+                if hx3 and _head_x3_shape(w):
                     return ops.linear_bwd(x, self._head_c.copies(id(w), True)[1], dy, hg[id(w)], hg[id(layer.bias)], x3=True)
                 return ops.linear_bwd(x, ht[id(w)], dy, hg[id(w)], hg[id(layer.bias)])
             if s["jigsaw"]:
