@@ -91,6 +91,26 @@ def test_eval_bn_folding_matches_unfolded(arch, embed, dtype, monkeypatch):
             model.get_embeddings({"data": x})    # moves the running statistics
 
 
+def test_x3_folded_inference_weights_past_the_half_range_are_refused():
+    """an x3 model's inference cache folds gamma / sqrt(running_var + eps) into the weights BEFORE the IEEE-half split; a
+    near-zero running variance (1 / sqrt(1e-5) = 316) can push a folded weight past 255.9 x 2^8 -- the model must say which layer,
+    not hand back NaN features (nor, as before this round, finite wrong ones)."""
+    _, model = build("ResNet18", 64, "x3", 12)
+    x = vo.structured_frames(2, 64, 64, seed=77).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        ok = model.extract_features(x)["extracted_features"]
+    assert torch.isfinite(ok).all()
+    res = model.feature_extractor.model
+    gi = next(i for i, (_, kind, _, bn) in enumerate(res.plan.params) if kind == 1 and bn == 3)
+    with torch.no_grad():
+        res.bn_nodes()[3].running_var.zero_()          # 1 / sqrt(eps) = 316 ...
+        res.trunk_params[gi].data.fill_(8.0)           # ... x gamma 8 x max |w| ~ 0.2: far past 255.9
+    model._touch()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="IEEE-half range"):
+        model.extract_features(x)
+
+
 @pytest.mark.parametrize("arch,embed", [("ResNet18", 64), ("ResNet50", 128)])
 def test_g3_trunk_head_bf16_reported(arch, embed, record_property):
     """bf16 trunk against the fp32 reference.  53 stacked bf16 layers cannot hold 1e-3 on raw embeddings in general

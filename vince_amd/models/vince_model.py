@@ -456,8 +456,30 @@ class VinceModel(BaseModel):
         if self._wcache_folded is None:
             self._wcache_folded = torch.empty(trunk.wc_bytes, dtype=torch.uint8, device=self._flat.device)
         if self._fold_version != (self._param_version, self._bn_version):
+            if self.conv_x3:
+                self._check_folded_half_range()
             trunk.prepare_weights_folded(self._param_ptrs, self._bn_running_ptrs, self._wcache_folded)
             self._fold_version = (self._param_version, self._bn_version)
+
+    def _check_folded_half_range(self):
+        """x3 inference cache: a folded weight w * gamma / sqrt(running_var + eps) is split into IEEE-half halves after a scale of 2^8
+        (csrc/common.h X3_WSHIFT); a near-zero running variance can push it past the half range (|w'| >= 255.9), where the split turns
+        into inf / NaN by design.  Say WHICH layer before that happens (one host read per rebuild of the inference cache)."""
+        res = self.feature_extractor.model
+        bns, params, worst, names = res.bn_nodes(), res.plan.params, [], []
+        for i, (name, kind, _, _) in enumerate(params):
+            if kind != 0 or i + 1 >= len(params) or params[i + 1][1] != 1:
+                continue
+            node = bns[params[i + 1][3]]
+            scale = (res.trunk_params[i + 1].detach() / torch.sqrt(node.running_var + 1e-5)).abs()
+            worst.append((res.trunk_params[i].detach().abs().flatten(1).amax(1) * scale).max())
+            names.append(name)
+        vals = torch.stack(worst).tolist()
+        bad = [(n, v) for n, v in zip(names, vals) if not v * 256.0 < 65504.0]
+        if bad:
+            raise RuntimeError("VinceModel (compute_dtype x3): folded inference weights leave the IEEE-half range of the split-half "
+                               "products (|w * gamma / sqrt(var + eps)| must stay below 255.9): %s -- run extract_features with an "
+                               "fp32 or bf16 trunk, or VINCE_FOLD_BN=0" % ", ".join("%s %.1f" % b for b in bad[:4]))
 
     def _encode(self, data, jigsaw, orders, with_head, save):
         """Returns (spatial, pooled, prenorm, embeddings).  data: float32 NCHW on the GPU."""
