@@ -51,7 +51,7 @@ const char* vince_last_error(void);
 /* Bumped whenever an exported signature, a struct layout or a dtype code changes.  vince_abi_version() returns the value the library
  * was BUILT with; a binding compares it at load (vince_amd/_lib.py: a stale .so behind VINCE_HIP_LIB would otherwise be called with
  * shifted arguments). */
-#define VINCE_ABI_VERSION 8
+#define VINCE_ABI_VERSION 9
 int vince_abi_version(void);
 
 /* Measurement aid (bench.py): while enabled, every conv_igemm / conv_wgrad launch is bracketed by a hipEvent pair on
@@ -198,6 +198,10 @@ int vince_conv_expand_stats(int dtype, const void* x, const void* w, int64_t row
  * (dh + 1) * 3 + (dw + 1) (null: identity = the forward convolution).  H must be a multiple of 4. */
 int vince_conv3x3_strip(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                         const int32_t* tap_map, void* out, double* stats, int32_t replicas, void* stream);
+/* The same layer with the epilogue of the BatchNorm-folded inference forward (vince_trunk_forward_folded): out = [relu](conv + bias[co]),
+ * bias / ReLU applied to the bf16-rounded convolution output as vince_conv_igemm's epilogue does (bit-identical to it); no statistics. */
+int vince_conv3x3_strip_bias(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                             const float* bias, int32_t relu, void* out, void* stream);
 /* The INPUT GRADIENT of that layer through the same kernel (autograd of resnet.py:119-121 under loss.backward()): dx [N][H][56][64] =
  * conv3x3(dy, wt with the taps flipped), wt = the prepared [Ci][tap][Co] copy, with vince_conv_igemm's fused BatchNorm-backward reduction
  * of the BatchNorm + ReLU below (bnred with mask_scale / mask_shift, no mask bits; may be NULL): bnred->sums += (sum g, sum g * xhat) of

@@ -865,6 +865,27 @@ def test_conv3x3_image_strip_kernel(N, H):
     assert_close(out.permute(0, 3, 1, 2), wantf, torch.bfloat16, bf16=1e-2, what="strip conv, flipped taps")
 
 
+@pytest.mark.parametrize("N,H", [(3, 56), (5, 8), (1, 4)])
+def test_conv3x3_image_strip_kernel_bias_relu_epilogue(N, H):
+    """vince_conv3x3_strip_bias -- layer1's 3x3 in the BatchNorm-folded inference forward: out = relu(conv + bias) -- BIT-identical to
+    vince_conv_igemm's bias + ReLU epilogue on the same operands, and against torch on the CPU; without ReLU and without a bias too."""
+    ops = _ops()
+    from vince_amd._lib import EPI_RELU
+    x = rnd(N, H, 56, 64, seed=43).clamp_(min=0).to(DEV).bfloat16()
+    w = (rnd(64, 9, 64, seed=44) * (2.0 / 576) ** 0.5).to(DEV).bfloat16().contiguous()
+    b = (rnd(64, seed=45) * 0.3).to(DEV)
+    d = ops.conv_desc(N, H, 56, 64, 64, 3, 1, 1)
+    for bias, relu in ((b, True), (b, False), (None, True)):
+        out = torch.full((N, H, 56, 64), 5.0, device=DEV).bfloat16()
+        ops.conv3x3_strip_bias(x, w, out, bias=bias, relu=relu)
+        ref = torch.empty_like(out)
+        ops.conv_igemm(d, x, w, ref, bias=bias, flags=EPI_RELU if relu else 0)
+        assert torch.equal(out, ref), (bias is not None, relu)
+    want = torch.relu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().view(64, 3, 3, 64).permute(0, 3, 1, 2), b.cpu(), 1, 1))
+    ops.conv3x3_strip_bias(x, w, out, bias=b, relu=True)
+    assert_close(out.permute(0, 3, 1, 2), want, torch.bfloat16, bf16=1e-2, what="strip conv + bias + relu vs torch")
+
+
 @pytest.mark.parametrize("N,H", [(3, 56), (5, 8)])
 def test_conv3x3_image_strip_kernel_input_gradient_with_fused_bn_reduction(N, H):
     """vince_conv3x3_strip_dgrad (layer1's 3x3 input gradient through the image-strip kernel, taps flipped over the [Ci][tap][Co] weight

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "vince_conv_expand_join": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vince_conv3x3_strip": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "vince_conv3x3_strip_bias": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "vince_conv3x3_strip_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, P(BnReduce), c_int32, c_void_p]),
     "vince_conv_expand_stats": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_conv_expand_dgrad_masked": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_void_p, c_void_p,
@@ -166,7 +167,7 @@ _LIB = None
 
 
 # include/vince_hip.h VINCE_ABI_VERSION (tests/test_abi_cpu.py holds the two together)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def lib():

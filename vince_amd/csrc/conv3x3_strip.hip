@@ -60,11 +60,16 @@ struct XsParams {
     const float* br_invstd;
     const float* br_msc;
     const float* br_msh;
+    // BIAS (the BatchNorm-folded inference forward): out = [relu](conv + bias[co]) applied to the bf16-rounded convolution output, as
+    // vince_conv_igemm's epilogue does; no statistics
+    const float* bias;
+    int relu;
 };
 
-template <bool BNRED>
+template <bool BNRED, bool BIAS = false>
 __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[XS_BYTES + (BNRED ? 512 : 0)];
+    static_assert(!(BNRED && BIAS), "bias + ReLU is a forward epilogue");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XS_BYTES + ((BNRED || BIAS) ? 512 : 0)];
     unsigned char* const wsm = smem;
     unsigned char* const xsm = smem + XS_WB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -89,6 +94,9 @@ __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParam
         }
         if constexpr (BNRED) {
             if (tid < 128) ((float*)(smem + XS_BYTES))[tid] = tid < 64 ? p.br_msc[tid] : p.br_msh[tid - 64];
+        }
+        if constexpr (BIAS) {
+            if (tid < 64) ((float*)(smem + XS_BYTES))[tid] = p.bias ? p.bias[tid] : 0.f;
         }
         // the zero pixels of every ring row
         for (int i = tid; i < XS_RING * 2 * 8; i += XS_THREADS) {
@@ -218,6 +226,19 @@ __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParam
         auto epi_store = [&](int u, int pass, int sidx) {
             const int prow = lane / 4 + 16 * sidx, c = lane % 4;
             const size_t off = (size_t)(ppix0 + (uint32_t)(32 * u + prow)) * XS_C + (size_t)(pass * 32 + c * 8);
+            if constexpr (BIAS) {   // a lane stores the same 8 channels for the whole launch: their bias sits in the LDS table
+                float f[8], bv[8];
+                Chunk<bf16_t>::unpack(tval, f);
+                *(float4*)&bv[0] = *(const float4*)(ctab + pass * 32 + c * 8);
+                *(float4*)&bv[4] = *(const float4*)(ctab + pass * 32 + c * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f[e] += bv[e];
+                    if (p.relu) f[e] = fmaxf(f[e], 0.f);
+                }
+                *(uint4*)(out + off) = Chunk<bf16_t>::pack(f);
+                return;
+            }
             if constexpr (!(XS_ABLATE & 2)) *(uint4*)(out + off) = tval;
             float f[8];
             Chunk<bf16_t>::unpack(tval, f);
@@ -385,8 +406,10 @@ static int xs_num_cu() {
     return n_cu;
 }
 
+struct XsBias { const float* bias; int relu; };
 static int strip_common(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
-                        const int32_t* tap_map, void* out, double* stats, const vince_bn_reduce* bnred, int32_t replicas, void* stream) {
+                        const int32_t* tap_map, void* out, double* stats, const vince_bn_reduce* bnred, int32_t replicas, void* stream,
+                        const XsBias* bias_relu = nullptr) {
     VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv3x3_strip: bf16 only");
     VINCE_CHECK_ARG(x && w && out && N > 0, VINCE_E_ARG, "vince_conv3x3_strip: null pointer");
     VINCE_CHECK_ARG(Ci == XS_C && Co == XS_C && W == XS_W && H > 0 && H % XS_ROWS == 0, VINCE_E_UNSUPPORTED,
@@ -415,6 +438,11 @@ static int strip_common(int dtype, const void* x, const void* w, int32_t N, int3
         p.stats = bnred->sums;
         p.br_y = bnred->y; p.br_mean = bnred->mean; p.br_invstd = bnred->invstd; p.br_msc = bnred->mask_scale; p.br_msh = bnred->mask_shift;
         hipLaunchKernelGGL(conv3x3_strip_kernel<true>, dim3((unsigned)grid), dim3(XS_THREADS), 0, (hipStream_t)stream, p);
+    } else if (bias_relu) {
+        VINCE_CHECK_ARG(!stats, VINCE_E_ARG, "vince_conv3x3_strip_bias: no statistics in the bias + ReLU epilogue");
+        p.bias = bias_relu->bias;
+        p.relu = bias_relu->relu;
+        hipLaunchKernelGGL((conv3x3_strip_kernel<false, true>), dim3((unsigned)grid), dim3(XS_THREADS), 0, (hipStream_t)stream, p);
     } else {
         hipLaunchKernelGGL(conv3x3_strip_kernel<false>, dim3((unsigned)grid), dim3(XS_THREADS), 0, (hipStream_t)stream, p);
     }
@@ -428,6 +456,14 @@ static int strip_common(int dtype, const void* x, const void* w, int32_t N, int3
 extern "C" int vince_conv3x3_strip(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                                    const int32_t* tap_map, void* out, double* stats, int32_t replicas, void* stream) {
     return strip_common(dtype, x, w, N, H, W, Ci, Co, tap_map, out, stats, nullptr, replicas, stream);
+}
+
+// The same convolution with the epilogue of the BatchNorm-folded inference forward: out = [relu](conv(x, w) + bias[co]) -- bias and ReLU
+// applied to the bf16-rounded convolution output exactly as vince_conv_igemm's epilogue does (bit-identical to it); bias may be NULL.
+extern "C" int vince_conv3x3_strip_bias(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                                        const float* bias, int32_t relu, void* out, void* stream) {
+    const XsBias b{bias, relu};
+    return strip_common(dtype, x, w, N, H, W, Ci, Co, nullptr, out, nullptr, nullptr, 0, stream, &b);
 }
 
 // The INPUT GRADIENT of the same layer (autograd of resnet.py:119-121): dx = conv3x3(dy, W^T with the taps flipped) -- wt is the prepared

@@ -722,6 +722,16 @@ vince_bn_reduce bn_reduce_of(Ctx& c, const BnL& bn, const uint8_t* bits, bool se
 
 namespace {
 
+// Folded inference forward: a bottleneck's conv3 + bias + identity + ReLU through the persistent streaming kernel (csrc/conv_xjoin.hip)
+// where it applies -- bf16, K = 64 / 128, Co multiple of 256: layer1 / layer2 -- with bn3's scale as the kernel's out_scale instead of
+// folded into the weights (round 5: 4.4-5.2 TB/s against the implicit-GEMM join epilogue's 3.4).  `xjoin=0`: the epilogue everywhere.
+bool folded_xjoin_block(const vince_trunk* t, const Blk& b) {
+    static const bool on = (vince_knob("xjoin", 1) != 0) && (vince_knob("xjoin_folded", 1) != 0);
+    return on && t->sdtype == VINCE_BF16 && t->cf == VINCE_BF16 && b.nconv == 3 && (b.c[2].Ci == 64 || b.c[2].Ci == 128) &&
+           b.c[2].Co % 256 == 0 && b.c[2].k == 1 && b.c[2].stride == 1 &&
+           (unsigned long long)t->cfg.N * b.c[2].Hi * b.c[2].Wi * b.c[2].Ci * 2 < 0x7ff00000ull;
+}
+
 // Batched weight prep shared by the training cache (scale == nullptr) and the BatchNorm-folded inference cache
 // (fold_scale: float[sum of BN channels] in BN order, inside the cache).  `which` selects the cached descriptor table.
 // part: 0 = every layer, 1 = every layer but the stem (table entry 0), 2 = the stem alone (vince_trunk_prepare_weights_part)
@@ -748,7 +758,11 @@ int prepare_common(vince_trunk* t, const float* const* params, void* wcache, con
         tab.push_back(e);
     }
     for (const Blk& b : t->blocks) {
-        for (int ci = 0; ci < b.nconv; ++ci) add(b.c[ci], b.b[ci]);
+        for (int ci = 0; ci < b.nconv; ++ci) {
+            add(b.c[ci], b.b[ci]);
+            // (the streaming join multiplies by bn3's scale itself: its conv3 weights stay unfolded in the inference cache)
+            if (fold_scale && ci == b.nconv - 1 && folded_xjoin_block(t, b)) tab.back().scale = nullptr;
+        }
         if (b.has_ds) add(b.cd, b.bd);
     }
     void* dev_table = at(wcache, t->off_prep_table);
@@ -850,7 +864,17 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
         const Blk& b = t->blocks[bi];
         const void* in = cur;
         for (int ci = 0; ci < b.nconv - 1; ++ci) {
-            RC(conv(fwd_desc(t, b.c[ci]), b.c[ci], b.b[ci], in, at(workspace, b.a[ci]), VINCE_EPI_RELU));
+            const ConvL& cv = b.c[ci];
+            // layer1's 3x3 (64 -> 64 at 56 x 56, bf16): the image-strip kernel with the bias + ReLU epilogue (bit-identical output)
+            static const bool strip3x3 = (vince_knob("strip3x3", 1) != 0) && (vince_knob("xjoin_folded", 1) != 0);
+            if (strip3x3 && dtype == VINCE_BF16 && t->cf == VINCE_BF16 && cv.k == 3 && cv.stride == 1 && cv.Ci == 64 && cv.Co == 64 &&
+                cv.Wo == 56 && cv.Ho % 4 == 0 && cv.Hi == cv.Ho && cv.Wi == cv.Wo &&
+                (unsigned long long)N * cv.Hi * cv.Wi * cv.Ci * 2 < 0x7ff00000ull) {
+                RC(vince_conv3x3_strip_bias(dtype, in, at((void*)wcache, cv.wk), N, cv.Ho, cv.Wo, cv.Ci, cv.Co, bias + b.b[ci].consts / 4, 1,
+                                            at(workspace, b.a[ci]), stream));
+            } else {
+                RC(conv(fwd_desc(t, cv), cv, b.b[ci], in, at(workspace, b.a[ci]), VINCE_EPI_RELU));
+            }
             in = at(workspace, b.a[ci]);
         }
         const int L = b.nconv - 1;
@@ -863,7 +887,14 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
             VINCE_CHECK_HIP(hipMemcpyAsync(out, cur, (size_t)N * b.c[L].Ho * b.c[L].Wo * b.c[L].Co * t->esize,
                                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
         }
-        RC(conv(fwd_desc(t, b.c[L]), b.c[L], b.b[L], in, out, VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU));
+        if (folded_xjoin_block(t, b)) {
+            const ConvL& cv = b.c[L];
+            RC(vince_conv_expand_join(dtype, in, at((void*)wcache, cv.wk), (int64_t)N * cv.Ho * cv.Wo, cv.Ci, cv.Co,
+                                      fold_scale(t, (void*)wcache) + b.b[L].consts / 4, bias + b.b[L].consts / 4, out, nullptr, nullptr, out,
+                                      nullptr, nullptr, 1, stream));
+        } else {
+            RC(conv(fwd_desc(t, b.c[L]), b.c[L], b.b[L], in, out, VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU));
+        }
         cur = out;
     }
     RC(vince_avgpool_fwd(dtype, cur, pooled, N, t->outH * t->outW, t->outC, stream));

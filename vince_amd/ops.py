@@ -198,6 +198,16 @@ def conv3x3_strip(x, w, out, stats=None, replicas=0, tap_map=None):
     return out
 
 
+def conv3x3_strip_bias(x, w, out, bias=None, relu=True):
+    """out = [relu](conv3x3(x, w) + bias) for layer1's shape through the image-strip kernel: the epilogue of the BatchNorm-folded
+    inference forward (vince_conv3x3_strip_bias)."""
+    require_gpu(x, w, out, bias)
+    N, H, W, Ci = x.shape
+    check(lib().vince_conv3x3_strip_bias(dtype_code(x), _ptr(x), _ptr(w), N, H, W, Ci, w.shape[0], _ptr(bias), int(relu), _ptr(out),
+                                         stream_ptr()))
+    return out
+
+
 def conv_expand_dgrad(dy, wt, out, accumulate=False, acc_mask=None, bnred=None, replicas=0):
     """out (+)= dy @ wt.T through the streaming kernel with the gradient epilogues (vince_conv_expand_dgrad); dy [rows, K],
     wt [Co, K], out [rows, Co] in place."""
