@@ -533,7 +533,15 @@ class VinceModel(BaseModel):
         # never reads it past that point (the training loop) sets clone_spatial = False and gets the zero-copy view.
         spatial = trunk.spatial_view(ws)
         if getattr(self, "clone_spatial", True):
-            spatial = spatial.clone()
+            # (the view is channels-last over one dense block of the workspace: copied with the library's streaming copy -- torch's
+            # clone() of it becomes the runtime's blit, 25 pieces at 0.8 TB/s = 0.13 ms per 256 frames of ResNet-50)
+            n, c, h, w = spatial.shape
+            dense = spatial.permute(0, 2, 3, 1)
+            copy = torch.empty((n, h, w, c), dtype=spatial.dtype, device=spatial.device)
+            if dense.is_contiguous() and (copy.numel() * copy.element_size()) % 16 == 0:
+                spatial = ops.stream_copy(copy, dense).permute(0, 3, 1, 2)
+            else:
+                spatial = spatial.clone()
         pre = emb = None
         # (detached aliases: `pooled` and `pre` are also RETURNED through _EncodeFn, whose autograd node holds the model -- saving the
         # returned objects themselves would close a cycle model -> _saved -> tensor -> grad_fn -> ctx.model that Python's collector

@@ -553,6 +553,18 @@ def prepare_weight(w_master, dtype, cip=None, want_transposed=True, x3=False):
     return wk, wt
 
 
+def stream_copy(dst, src):
+    """dst <- src (same byte count, a multiple of 16; both dense) through the library's block-contiguous non-temporal copy kernel
+    (vince_stream_copy: ~6 TB/s where the runtime's device-to-device blit, which torch's clone() of a dense tensor turns into, moves
+    0.8 TB/s in 2 MB pieces)."""
+    require_gpu(dst, src)
+    nbytes = src.numel() * src.element_size()
+    if nbytes != dst.numel() * dst.element_size() or nbytes % 16:
+        raise ValueError("vince_amd: stream_copy needs equal byte counts, a multiple of 16")
+    check(lib().vince_stream_copy(_ptr(dst), _ptr(src), nbytes, 0, 5, stream_ptr()))
+    return dst
+
+
 def transpose_f32(x):
     """fp32 [R, C] -> [C, R] (LDS-tiled)."""
     require_gpu(x)
