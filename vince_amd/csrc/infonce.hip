@@ -273,11 +273,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void infonce_merge(const InfoParams 
         const int row = row0 + slot;
         const bool live = row < B;
         float M = NEG_BIG, nmx = NEG_BIG;
-        if (live)
-            for (int j = sub; j < P; j += MERGE_LPR) {
+        if (live) {
+#pragma unroll 8
+            for (int j = sub; j < P; j += MERGE_LPR) {      // (unrolled: eight partials' loads in flight instead of a chain of P / 4 round trips)
                 M = fmaxf(M, p.part[((size_t)0 * P + j) * B + row]);
                 nmx = fmaxf(nmx, p.part[((size_t)2 * P + j) * B + row]);
             }
+        }
 #pragma unroll
         for (int o = 1; o < MERGE_LPR; o <<= 1) {
             M = fmaxf(M, __shfl_xor(M, o, 64));
@@ -286,9 +288,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void infonce_merge(const InfoParams 
         if (live)
             for (int f = 0; f < F; ++f) M = fmaxf(M, p.pos[(size_t)row * F + f] * invT);   // row max over ALL columns
         float S = 0.f;
-        if (live)
+        if (live) {
+#pragma unroll 8
             for (int j = sub; j < P; j += MERGE_LPR)
                 S += p.part[((size_t)1 * P + j) * B + row] * __expf(p.part[((size_t)0 * P + j) * B + row] - M);
+        }
 #pragma unroll
         for (int o = 1; o < MERGE_LPR; o <<= 1) S += __shfl_xor(S, o, 64);
         if (live && sub == 0) {

@@ -535,9 +535,9 @@ class VinceModel(BaseModel):
         if getattr(self, "clone_spatial", True):
             # (the view is channels-last over one dense block of the workspace: copied with the library's streaming copy -- torch's
             # clone() of it becomes the runtime's blit, 25 pieces at 0.8 TB/s = 0.13 ms per 256 frames of ResNet-50)
-            n, c, h, w = spatial.shape
+            sn, sc, sh_, sw = spatial.shape
             dense = spatial.permute(0, 2, 3, 1)
-            copy = torch.empty((n, h, w, c), dtype=spatial.dtype, device=spatial.device)
+            copy = torch.empty((sn, sh_, sw, sc), dtype=spatial.dtype, device=spatial.device)
             if dense.is_contiguous() and (copy.numel() * copy.element_size()) % 16 == 0:
                 spatial = ops.stream_copy(copy, dense).permute(0, 3, 1, 2)
             else:
