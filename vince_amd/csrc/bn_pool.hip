@@ -13,6 +13,9 @@
 #include <algorithm>
 
 #include "common.h"
+#ifndef VINCE_BN_U
+#define VINCE_BN_U 4      // rows in flight per thread of the forward BatchNorm pass and the backward reduction (A/B: -DVINCE_BN_U=8)
+#endif
 
 namespace {
 
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + threadIdx.x / w.tpc;
     const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
     // 4 rows per trip with all loads issued first: more bytes in flight per wave (the kernel is a pure HBM stream)
-    constexpr int U = 4;
+    constexpr int U = VINCE_BN_U;
     for (int64_t rb = r0; active && rb < r1; rb += (int64_t)U * w.rpp) {
         uint4 yv[U], iv[U];
 #pragma unroll
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const int64_t r0 = (int64_t)blockIdx.y * w.rows_per_block + tr;
     const int64_t r1 = min(rows, (int64_t)(blockIdx.y + 1) * w.rows_per_block);
     if (cv) {
-        constexpr int U = 4;   // rows per trip, all loads issued before the arithmetic (more bytes in flight)
+        constexpr int U = VINCE_BN_U;   // rows per trip, all loads issued before the arithmetic (more bytes in flight)
         for (int64_t rb = r0; rb < r1; rb += (int64_t)U * w.rpp) {
             uint4 dv[U], yv[U];
 #pragma unroll
@@ -1053,7 +1056,11 @@ extern "C" int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_s
     if (replicas <= 0 || replicas > VINCE_STATS_REPLICAS) replicas = VINCE_STATS_REPLICAS;
     VINCE_CHECK_ARG(dz && y && mean && invstd && sums && rows > 0, VINCE_E_ARG, "vince_bn_bwd_reduce: bad arguments");
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_bwd_reduce: C=%d not a multiple of %d", C, CH_OF(dtype));
-    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), 2048);
+    // every workgroup ends with 2 C fp64 atomics: on a wide, short tensor (layer4's last block: 12544 x 2048) 1568 workgroups of 8 rows
+    // spent their time there (6.4 M atomics, 62 us for 103 MB); row blocks x C is held near 2^19
+    int target = (1 << 19) / (C > 0 ? C : 1);
+    target = target < 128 ? 128 : target > 2048 ? 2048 : target;
+    RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), target);
     dim3 grid(w.colgroups, w.rowblocks);
     VinceProfScope prof(VINCE_TAG_BN_BWD_REDUCE, (double)rows * C * ESZ_OF(dtype) * 2, stream);
     if (dtype == VINCE_F32)
