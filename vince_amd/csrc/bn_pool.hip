@@ -897,9 +897,23 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ 
     float s[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) s[e] = 0.f;
-    for (int p = 0; p < HW; ++p) {
+    const T* __restrict__ xp = x + (size_t)n * HW * C + (size_t)col * CH;
+    int p = 0;
+    for (; p + 7 <= HW; p += 7) {                  // seven pixels' chunks requested before they are added (HW = 49 at 224 x 224)
+        uint4 v[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) v[u] = *(const uint4*)(xp + (size_t)(p + u) * C);
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            float f[CH];
+            Chunk<T>::unpack(v[u], f);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) s[e] += f[e];
+        }
+    }
+    for (; p < HW; ++p) {
         float f[CH];
-        Chunk<T>::unpack(*(const uint4*)(x + ((size_t)n * HW + p) * C + (size_t)col * CH), f);
+        Chunk<T>::unpack(*(const uint4*)(xp + (size_t)p * C), f);
 #pragma unroll
         for (int e = 0; e < CH; ++e) s[e] += f[e];
     }
