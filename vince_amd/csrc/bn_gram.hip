@@ -31,11 +31,8 @@ __global__ __launch_bounds__(256) void bn_apply_gram_kernel(const bf16_t* __rest
 
     // train-mode finalize, as in bn_apply_kernel: every workgroup folds the statistic replicas of the K channels, workgroup 0 publishes
     for (int c = tid; c < K; c += 256) {
-        double s1 = 0, s2 = 0;
-        for (int r = 0; r < fin.replicas; ++r) {
-            s1 += fin.stats[((size_t)r * K + c) * 2];
-            s2 += fin.stats[((size_t)r * K + c) * 2 + 1];
-        }
+        double s1, s2;
+        fold_replicas(fin.stats, fin.replicas, K, c, s1, s2);
         const double cnt = (double)fin.count;
         const double m = s1 / cnt;
         double var = s2 / cnt - m * m;

@@ -160,11 +160,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
         for (int cl = threadIdx.x; cl < nch; cl += 256) {
             const int c = c_base + cl;
             if (c >= C) continue;
-            double s1 = 0, s2 = 0;
-            for (int r = 0; r < fin.replicas; ++r) {
-                s1 += fin.stats[((size_t)r * C + c) * 2];
-                s2 += fin.stats[((size_t)r * C + c) * 2 + 1];
-            }
+            double s1, s2;
+            fold_replicas(fin.stats, fin.replicas, C, c, s1, s2);
             const double cnt = (double)fin.count;
             const double m = s1 / cnt;
             double var = s2 / cnt - m * m;
@@ -538,11 +535,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (int cl = threadIdx.x; cl < nch; cl += 256) {
             const int c = c_base + cl;
             if (c >= C) continue;
-            double sg = 0, sgx = 0;
-            for (int r = 0; r < replicas; ++r) {
-                sg += sums[((size_t)r * C + c) * 2];
-                sgx += sums[((size_t)r * C + c) * 2 + 1];
-            }
+            double sg, sgx;
+            fold_replicas(sums, replicas, C, c, sg, sgx);
             fold[0][cl] = (float)(sg * inv_count);
             fold[1][cl] = (float)(sgx * inv_count);
             if (blockIdx.y == 0) {

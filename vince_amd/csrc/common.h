@@ -269,6 +269,28 @@ __device__ inline uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
     return base + s;
 }
 
+// (sum, sum of squares) of channel c folded over the R replicas of a double[R][C][2] statistics block: one 16-byte load per replica,
+// four replicas requested before they are added (the loop with one 8-byte load per iteration waited for a round trip to L2 per
+// replica and value: 32 in a row at R = 16, in the prologue of every BatchNorm pass over a large tensor).  Same summation order.
+__device__ __forceinline__ void fold_replicas(const double* __restrict__ stats, int R, int C, int c, double& s1, double& s2) {
+    typedef __attribute__((ext_vector_type(2))) double d2_t;
+    s1 = 0;
+    s2 = 0;
+    int r = 0;
+    for (; r + 4 <= R; r += 4) {
+        d2_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const d2_t*)(stats + ((size_t)(r + u) * C + c) * 2);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1 += v[u][0]; s2 += v[u][1]; }
+    }
+    for (; r < R; ++r) {
+        const d2_t v = *(const d2_t*)(stats + ((size_t)r * C + c) * 2);
+        s1 += v[0];
+        s2 += v[1];
+    }
+}
+
 // wave-level helpers (64 lanes)
 __device__ inline float wave_sum(float v) {
 #pragma unroll
