@@ -69,6 +69,7 @@ class GradientReducer:
             for ev in self.events:
                 ev.record()          # torch creates the underlying hipEvent lazily; the engine needs a live handle
             self.done = torch.cuda.Event()
+            self.done_most = torch.cuda.Event()      # every bucket but the last (stem + layer1): the deferred stem join (see reduce_after_backward)
             model._bucket_events = [(blk, ev) for (blk, _, _), ev in zip(self.plan, self.events) if blk is not None]
             # every bucket but the last is launched from INSIDE the engine's backward call, the moment its event has been recorded
             # (engine.Trunk.set_bucket_callback): the all-reduce of layer4 + heads is queued behind its event while the host is
@@ -156,17 +157,35 @@ class GradientReducer:
         cur = torch.cuda.current_stream()
         tail_event = torch.cuda.Event()
         tail_event.record(cur)
+        # Deferred stem join (round 5; models/vince_model.py defer_stem_join): backward has returned with conv1's weight gradient still
+        # in flight behind model._stem_event.  Only the LAST bucket (flat range [0, layer2): stem + layer1) contains it: that bucket's
+        # all-reduce waits for the event, and the compute stream is made to wait for every OTHER bucket only (done_most) -- the
+        # optimiser steps [layer2, end) beside the stem's weight gradient and the last all-reduce, then waits for `done` (model._late).
+        deferred = bool(getattr(self.model, "_stem_pending", False))
+        last = len(self.plan) - 1
         try:
             with torch.cuda.stream(self.comm_stream):
                 for e, (blk, a, b) in enumerate(self.plan):
                     if e in self._launched:
                         continue
+                    if deferred and e == last:
+                        self.done_most.record(self.comm_stream)
                     self.comm_stream.wait_event(tail_event)
+                    if deferred and a == 0:
+                        self.comm_stream.wait_event(self.model._stem_event)
                     self._reduce_bucket(a, b)
                 self.done.record(self.comm_stream)
         finally:
+            launched_last = last in self._launched
             self._launched.clear()
-        cur.wait_event(self.done)
+        if deferred and not launched_last and self.plan[last][1] == 0:
+            cur.wait_event(self.done_most)
+            done = self.done
+            self.model._late = (self.plan[last][2], lambda: torch.cuda.current_stream().wait_event(done))
+        else:
+            cur.wait_event(self.done)
+            if deferred:
+                self.model.finish_stem_grad()
 
     def begin_step(self):
         """Call before loss.backward(): forgets bucket launches of a step whose backward raised before reduce_after_backward ran."""

@@ -295,6 +295,9 @@ class VinceModel(BaseModel):
         # VinceQueueModel.param_update step / average every OTHER parameter beside it and conv1.weight behind the event.
         self.defer_stem_join = False
         self._stem_event, self._stem_pending, self._deferred_step = None, False, None
+        # data parallel: (flat offset below which gradients arrive late, waiter) set by the reducer -- the last gradient bucket
+        # (stem + layer1) instead of conv1.weight alone; _deferred_split: where FlatSGD actually split the step
+        self._late, self._deferred_split = None, None
         self._build_flat()
 
     # ------------------------------------------------------------------------------------------ flat storage
@@ -615,7 +618,7 @@ class VinceModel(BaseModel):
         self._touched["trunk"] = True
         # data parallel: the reducer's hook runs inside the engine call, right after each bucket's event is recorded
         s["trunk"].set_bucket_callback(self._bucket_hook if self._bucket_events else None)
-        defer = self.defer_stem_join and not self._bucket_events
+        defer = self.defer_stem_join      # (with gradient buckets too: dp.GradientReducer.reduce_after_backward holds the last bucket back)
         if defer and self._stem_event is None:
             self._stem_event = torch.cuda.Event()
             self._stem_event.record()            # (torch creates the hipEvent lazily; the engine needs a live handle)
@@ -840,11 +843,13 @@ class VinceQueueModel(BaseModel):
             kflat, _, _, n_ema = self.queue_network.flat_parameters()
             qflat, _, _, _ = encoder_model.flat_parameters()
             if getattr(encoder_model, "_deferred_step", None) is not None:
-                # the optimiser left conv1.weight (flat range [0, n1)) for behind the stem event: average everything else now, beside
-                # the stem's weight gradient, then finish that step and average the first range
-                n1 = encoder_model._offs[1]
+                # the optimiser left conv1.weight (flat range [0, n1); under data parallelism the whole last gradient bucket) for behind
+                # the stem event: average everything else now, beside the stem's weight gradient, then finish that step and average
+                # the first range
+                n1 = encoder_model._deferred_split or encoder_model._offs[1]
                 ops.ema_flat(kflat[n1:n_ema], qflat[n1:n_ema], float(momentum))
-                early = self.queue_network.prepare_weights_early(1)      # (beside the stem's weight gradient, like the two above)
+                # (the early rebuild of the weight copies splits at conv1 only: single-process runs)
+                early = n1 == encoder_model._offs[1] and self.queue_network.prepare_weights_early(1)
                 encoder_model.finish_deferred_step()
                 ops.ema_flat(kflat[:n1], qflat[:n1], float(momentum))
                 self.queue_network._touch()

@@ -51,19 +51,26 @@ class FlatSGD:
             # applies exactly weight decay + momentum, which is what torch 1.4 does with an in-place-zeroed .grad
             if b > a and role in self._ever_touched:
                 if role == "trunk" and getattr(self.model, "_stem_pending", False):
-                    # conv1.weight is the first tensor of the flat buffer: [a, n1); its gradient is final behind the stem event only
-                    n1 = self.model._offs[1]
+                    # conv1.weight is the first tensor of the flat buffer: [a, n1); its gradient is final behind the stem event only.
+                    # Data parallel: the reducer holds back the whole last gradient bucket (model._late = (its end, a waiter)).
+                    late = getattr(self.model, "_late", None)
+                    n1 = late[0] if late else self.model._offs[1]
                     ops.sgd_flat(flat[n1:b], grad[n1:b], self.momentum_buffer[n1:b], lr, self.momentum, self.weight_decay,
                                  self.grad_scale)
 
                     early = [False]
 
-                    def finish(a=a, n1=n1, lr=lr, scale=self.grad_scale):
+                    def finish(a=a, n1=n1, lr=lr, scale=self.grad_scale, late=late):
+                        if late:
+                            late[1]()                        # the last bucket's all-reduce (which waited for the stem event)
+                            self.model._late = None
                         self.model.finish_stem_grad()
+                        self.model._deferred_split = None
                         f, g, _, _ = self.model.flat_parameters()
                         ops.sgd_flat(f[a:n1], g[a:n1], self.momentum_buffer[a:n1], lr, self.momentum, self.weight_decay, scale)
                         if early[0] and self.model.prepare_weights_early(2):
                             self.model.weights_current()     # (runs after step() has bumped the parameter version)
+                    self.model._deferred_split = n1
                     if defer_stem:
                         self.model._deferred_step = finish
                         deferred_trunk = early
@@ -72,7 +79,7 @@ class FlatSGD:
                     continue
                 ops.sgd_flat(flat[a:b], grad[a:b], self.momentum_buffer[a:b], lr, self.momentum, self.weight_decay,
                              self.grad_scale)
-        if deferred_trunk is not None:
+        if deferred_trunk is not None and self.model._deferred_split == self.model._offs[1]:
             # every parameter but conv1.weight has its new value: rebuild their compute copies now, beside the stem's weight gradient
             # (the head ranges were stepped by the launches above; the trunk's table entry 0 follows in finish())
             deferred_trunk[0] = self.model.prepare_weights_early(1)

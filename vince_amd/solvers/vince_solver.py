@@ -122,11 +122,10 @@ class VinceSolver(BaseSolver):
             self.optimizer.grad_scale = 1.0 / w
             if hasattr(self.model, "imagenet_decoders"):
                 self.reducer.sync_extra_parameters(self.model.imagenet_decoders.parameters())
-        # single process: the optimiser and the key encoder's EMA run beside the stem's weight gradient, the last launch of backward
-        # (engine deferred stem join; under data parallelism the last gradient bucket needs that gradient first, so it stays joined).
-        # VINCE_DEFER_STEM=0: off (A/B measurements)
-        self.defer_stem = (self.reducer is None and self.model.device.type == "cuda"
-                           and os.environ.get("VINCE_DEFER_STEM", "1") != "0")
+        # the optimiser and the key encoder's EMA run beside the stem's weight gradient, the last launch of backward (engine deferred stem
+        # join); under data parallelism the last gradient bucket (stem + layer1) is what arrives late: dp.GradientReducer holds its
+        # all-reduce behind the stem event and the optimiser steps that range last.  VINCE_DEFER_STEM=0: off (A/B measurements)
+        self.defer_stem = self.model.device.type == "cuda" and os.environ.get("VINCE_DEFER_STEM", "1") != "0"
         self.model.defer_stem_join = self.defer_stem
         self.print_optimizer()
 
