@@ -72,3 +72,10 @@ def test_product_path_refuses_cpu():
     from vince_amd import ops
     with pytest.raises(RuntimeError):
         ops.l2norm_fwd(torch.randn(4, 64))
+
+
+def test_driver_build_entry_point_passes():
+    """The driver's "does it build" check is __graft_entry__.build(): it must succeed against the library as built (it compared
+    the ABI version with a literal once, and failed from the first bump on)."""
+    import __graft_entry__ as entry
+    entry.build()

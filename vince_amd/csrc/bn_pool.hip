@@ -30,21 +30,29 @@ struct RowWalk {
     int nt;              // bit 0: non-temporal loads of the streamed inputs, bit 1: non-temporal stores (bn_nt_policy)
 };
 
-// 16-byte accesses with an optional `nt` hint: the element-wise BatchNorm passes touch every byte once, and the box's own copy
-// kernel streams 10-15 % faster with non-temporal loads / stores (tools/ceilings.py).  VINCE_BN_NT: bit mask (default 0 until
-// measured in the step), VINCE_BN_NT_MIN: smallest tensor (bytes) it applies to -- small tensors live in the 256 MB
-// Infinity Cache between producer and consumer and should stay there.
-__device__ __forceinline__ uint4 ld16(const void* ptr, int nt) {
-    if (nt) {
+// 16-byte accesses with a COMPILE-TIME `nt` hint.  (Rounds 2-4 carried the hint as a run-time argument -- `nt ? nontemporal_load(p) : *p`
+// -- which the compiler folds into one plain load: the ISA held no `nt` instruction and the "+-0.3 %" of round 2 measured nothing.)
+// What the hint buys (tools/micro/mall_micro, profiles/r05_mall_micro.txt): a read-only pass over a 392 MB tensor the previous launch
+// has just written runs at 4.0 TB/s with plain loads and 6.5 TB/s with nt loads; a copy 5.4 -> 5.9 TB/s.  In the step (same-box A/B,
+// profiles/r05_nt_ab.txt): nt LOADS in the apply passes -0.18 ... -0.22 ms on every box and for every tensor size (bn_nt_min_mb = 0 beats
+// 64, 128 loses the gain); nt stores -0.05 on one box, +0.25 on another (off); nt loads in the backward reduction neutral (off: the apply
+// pass reads the same two tensors again).  Measured and NOT kept, same A/B: the hint on the stem passes' and bn_apply_gram's loads
+// (neutral), on conv_xjoin's input LDS-DMA (neutral) and identity loads (+0.5 ms: the identity is the previous launch's output and
+// still cached), on conv_igemm's single-tap input LDS-DMA (+0.45 ms).
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const void* ptr) {
+    if constexpr (NT) {
         const f32x4_t v = __builtin_nontemporal_load((const f32x4_t*)ptr);
         uint4 r;
         __builtin_memcpy(&r, &v, 16);
         return r;
+    } else {
+        return *(const uint4*)ptr;
     }
-    return *(const uint4*)ptr;
 }
-__device__ __forceinline__ void st16(void* ptr, const uint4& v, int nt) {
-    if (nt) {
+template <bool NT>
+__device__ __forceinline__ void st16(void* ptr, const uint4& v) {
+    if constexpr (NT) {
         f32x4_t t;
         __builtin_memcpy(&t, &v, 16);
         __builtin_nontemporal_store(t, (f32x4_t*)ptr);
@@ -52,10 +60,11 @@ __device__ __forceinline__ void st16(void* ptr, const uint4& v, int nt) {
         *(uint4*)ptr = v;
     }
 }
+// bit 0: nt loads of the streamed inputs, bit 1: nt stores.  VINCE_KNOBS: bn_nt (policy bits for tensors of at least bn_nt_min_mb MB)
 inline int bn_nt_policy(int64_t rows, int C, int esize) {
-    static const int mask = VINCE_MEASURE_KNOB("bn_nt", 0);
-    static const long long min_bytes = VINCE_MEASURE_KNOB("bn_nt_min", (64ll << 20));
-    return (long long)rows * C * esize >= min_bytes ? mask : 0;
+    static const int mask = (int)vince_knob("bn_nt", 1);
+    static const long long min_bytes = (long long)vince_knob("bn_nt_min_mb", 0) << 20;
+    return (long long)rows * C * esize >= min_bytes ? (mask & 3) : 0;
 }
 
 inline RowWalk make_rowwalk(int64_t rows, int C, int CH, int target_blocks = 2048) {
@@ -143,7 +152,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
     if (save_invstd) save_invstd[c] = invstd;
 }
 
-template <typename T>
+template <typename T, int NT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ idn,
                                                        const float* __restrict__ ids, const float* __restrict__ idt,
@@ -211,8 +220,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             const int64_t r = rb + (int64_t)u * w.rpp;
             if (r < r1) {
                 const size_t off = (size_t)r * C + (size_t)col * CH;
-                yv[u] = ld16(y + off, w.nt & 1);
-                if (idn) iv[u] = ld16(idn + off, w.nt & 1);
+                yv[u] = ld16<(NT & 1) != 0>(y + off);
+                if (idn) iv[u] = ld16<(NT & 1) != 0>(idn + off);
             }
         }
 #pragma unroll
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                 for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
             }
             const uint4 pv = Chunk<T>::pack(f);
-            st16(out + off, pv, w.nt & 2);
+            st16<(NT & 2) != 0>(out + off, pv);
             if (want_sum) {   // sum what a reader of `out` will see (the rounded values)
                 float q[CH];
                 Chunk<T>::unpack(pv, q);
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(gf2_threads(K)) void bn_gram_finalize2_kernel(const
     }
 }
 
-template <typename T>
+template <typename T, int NT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, const MaskArgs msk,
                                                             const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, double* sums,
@@ -460,8 +469,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 const int64_t r = rb + (int64_t)u * w.rpp;
                 if (r < r1) {
                     const size_t off = (size_t)r * C + (size_t)col * CH;
-                    dv[u] = *(const uint4*)(dz + off);
-                    yv[u] = *(const uint4*)(y + off);
+                    dv[u] = ld16<NT != 0>(dz + off);
+                    yv[u] = ld16<NT != 0>(y + off);
                 }
             }
 #pragma unroll
@@ -517,7 +526,7 @@ __global__ void bn_bwd_fold_kernel(double* sums, int C, float* dgamma, float* db
 #ifndef BWD_APPLY_ROWS
 #define BWD_APPLY_ROWS 2
 #endif
-template <typename T, bool R2>
+template <typename T, bool R2, int NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const MaskArgs msk,
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
@@ -583,8 +592,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 const int64_t r = rb + (int64_t)u * w.rpp;
                 if (r < r1) {
                     const size_t off = (size_t)r * C + (size_t)col * CH;
-                    dv[u] = ld16(dz + off, w.nt & 1);
-                    yv[u] = ld16(y + off, w.nt & 1);
+                    dv[u] = ld16<(NT & 1) != 0>(dz + off);
+                    yv[u] = ld16<(NT & 1) != 0>(y + off);
                     if constexpr (R2) { if (y2) y2v[u] = *(const uint4*)(y2 + off); }
                 }
             }
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 float o[CH];
 #pragma unroll
                 for (int e = 0; e < CH; ++e) o[e] = ca[e] * g[e] + (cb[e] * yy[e] + cc[e]);
-                st16(dy + off, Chunk<T>::pack(o), w.nt & 2);
+                st16<(NT & 2) != 0>(dy + off, Chunk<T>::pack(o));
                 if constexpr (R2) if (y2) {
                     float y2f[CH];
                     Chunk<T>::unpack(y2v[u], y2f);
@@ -975,6 +984,18 @@ extern "C" int vince_bn_finalize(const double* stats, int64_t count, int32_t C, 
     return VINCE_OK;
 }
 
+// the BatchNorm apply pass in the instantiation the row walk's nt policy asks for (plain / nt loads / nt loads + stores)
+static void launch_bn_apply(int dtype, dim3 grid, hipStream_t stream, const void* y, const float* scale, const float* shift, const void* identity,
+                            const float* id_scale, const float* id_shift, void* out, uint8_t* mask_out, int64_t rows, int32_t C, int relu,
+                            const RowWalk& w, const vince_bn_train& fin) {
+#define VINCE_BN_APPLY(TT, NN)                                                                                                         \
+    hipLaunchKernelGGL((bn_apply_kernel<TT, NN>), grid, dim3(256), 0, stream, (const TT*)y, scale, shift, (const TT*)identity, id_scale, \
+                       id_shift, (TT*)out, mask_out, rows, C, relu, w, fin)
+    if (dtype == VINCE_F32) { if (w.nt == 3) VINCE_BN_APPLY(float, 3); else if (w.nt & 1) VINCE_BN_APPLY(float, 1); else VINCE_BN_APPLY(float, 0); }
+    else { if (w.nt == 3) VINCE_BN_APPLY(bf16_t, 3); else if (w.nt & 1) VINCE_BN_APPLY(bf16_t, 1); else VINCE_BN_APPLY(bf16_t, 0); }
+#undef VINCE_BN_APPLY
+}
+
 extern "C" int vince_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* identity,
                               const float* id_scale, const float* id_shift, void* out, uint8_t* mask_out, int64_t rows,
                               int32_t C, int relu, void* stream) {
@@ -986,12 +1007,7 @@ extern "C" int vince_bn_apply(int dtype, const void* y, const float* scale, cons
     VinceProfScope prof(VINCE_TAG_BN_APPLY, (double)rows * C * ESZ_OF(dtype) * (identity ? 3 : 2) + (mask_out ? (double)rows * C / CH_OF(dtype) : 0), stream);
     vince_bn_train fin;
     memset(&fin, 0, sizeof(fin));
-    if (dtype == VINCE_F32)
-        hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, scale, shift,
-                           (const float*)identity, id_scale, id_shift, (float*)out, mask_out, rows, C, relu, w, fin);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, scale,
-                           shift, (const bf16_t*)identity, id_scale, id_shift, (bf16_t*)out, mask_out, rows, C, relu, w, fin);
+    launch_bn_apply(dtype, grid, (hipStream_t)stream, y, scale, shift, identity, id_scale, id_shift, out, mask_out, rows, C, relu, w, fin);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
@@ -1010,12 +1026,7 @@ extern "C" int vince_bn_train_apply(int dtype, const void* y, const vince_bn_tra
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_target_blocks());
     dim3 grid(w.colgroups, w.rowblocks);
     VinceProfScope prof(VINCE_TAG_BN_APPLY, (double)rows * C * ESZ_OF(dtype) * (identity ? 3 : 2) + (mask_out ? (double)rows * C / CH_OF(dtype) : 0), stream);
-    if (dtype == VINCE_F32)
-        hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y, nullptr, nullptr,
-                           (const float*)identity, id_scale, id_shift, (float*)out, mask_out, rows, C, relu, w, fin);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, nullptr,
-                           nullptr, (const bf16_t*)identity, id_scale, id_shift, (bf16_t*)out, mask_out, rows, C, relu, w, fin);
+    launch_bn_apply(dtype, grid, (hipStream_t)stream, y, nullptr, nullptr, identity, id_scale, id_shift, out, mask_out, rows, C, relu, w, fin);
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
@@ -1071,12 +1082,16 @@ extern "C" int vince_bn_bwd_reduce(int dtype, const void* dz, const void* mask_s
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), target);
     dim3 grid(w.colgroups, w.rowblocks);
     VinceProfScope prof(VINCE_TAG_BN_BWD_REDUCE, (double)rows * C * ESZ_OF(dtype) * 2, stream);
-    if (dtype == VINCE_F32)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dz,
-                           msk, (const float*)y, mean, invstd, sums, rows, C, w, replicas);
-    else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dz,
-                           msk, (const bf16_t*)y, mean, invstd, sums, rows, C, w, replicas);
+    // nt loads here are their own policy bit (4): the apply pass that follows reads dz and y again
+    static const bool reduce_nt = (vince_knob("bn_nt", 1) & 4) != 0;
+#define VINCE_BWD_REDUCE(TT, NN)                                                                                   \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, NN>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)dz, msk, \
+                       (const TT*)y, mean, invstd, sums, rows, C, w, replicas)
+    static const long long reduce_nt_min = (long long)vince_knob("bn_nt_min_mb", 0) << 20;
+    const bool rnt = reduce_nt && (long long)rows * C * ESZ_OF(dtype) >= reduce_nt_min;
+    if (dtype == VINCE_F32) { if (rnt) VINCE_BWD_REDUCE(float, 1); else VINCE_BWD_REDUCE(float, 0); }
+    else { if (rnt) VINCE_BWD_REDUCE(bf16_t, 1); else VINCE_BWD_REDUCE(bf16_t, 0); }
+#undef VINCE_BWD_REDUCE
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
@@ -1105,14 +1120,17 @@ extern "C" int vince_bn_bwd_apply(int dtype, const void* dz, const void* mask_sr
     VinceProfScope prof(VINCE_TAG_BN_BWD_APPLY, (double)rows * C * ESZ_OF(dtype) * (3 + (g_out ? 1 : 0) + (r2.y ? 1 : 0)) +
                         (mask_bits ? (double)rows * C / CH_OF(dtype) : 0), stream);
     const double inv_count = 1.0 / (double)count;
-#define VINCE_BWD_APPLY(TT, RR)                                                                                          \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, RR>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)dz, msk,       \
+#define VINCE_BWD_APPLY_N(TT, RR, NN)                                                                                    \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, RR, NN>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)dz, msk,       \
                        (const TT*)y, mean, invstd, gamma, sums, inv_count, (TT*)dy, (TT*)g_out, dgamma, dbeta, rows, C, w, \
                        replicas, r2)
+#define VINCE_BWD_APPLY(TT, RR)                                                                                          \
+    do { if (w.nt == 3) VINCE_BWD_APPLY_N(TT, RR, 3); else if (w.nt & 1) VINCE_BWD_APPLY_N(TT, RR, 1); else VINCE_BWD_APPLY_N(TT, RR, 0); } while (0)
     const bool has_r2 = r2.y != nullptr;
     if (dtype == VINCE_F32) { if (has_r2) VINCE_BWD_APPLY(float, true); else VINCE_BWD_APPLY(float, false); }
     else { if (has_r2) VINCE_BWD_APPLY(bf16_t, true); else VINCE_BWD_APPLY(bf16_t, false); }
 #undef VINCE_BWD_APPLY
+#undef VINCE_BWD_APPLY_N
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
 }
