@@ -812,6 +812,62 @@ def test_conv_expand_join_streaming_kernel(rows, K, Co, ds):
     assert torch.equal(bits, out2 > 0) or float((bits != (out2 > 0)).float().mean()) < 1e-3   # mask == (relu output > 0) up to -0 / tiny
 
 
+@pytest.mark.parametrize("rows,ds,save", [(4 * 56 * 56, False, 0), (128 * 37 + 5, True, 0), (3 * 56 * 56 + 17, False, 2), (1000, True, 1), (37, False, 2)])
+def test_conv_expand_join_next_block_conv1_fused(rows, ds, save):
+    """vince_conv_expand_join_next (csrc/conv_xjoin.hip, NEXT): the join of a layer1 bottleneck + the following block's conv1
+    (resnet.py:117: 1x1, 256 -> 64) on the block output while it is in LDS.  Everything the join alone writes is unchanged, bit for
+    bit; y_next equals vince_conv_igemm's output for that layer on the stored block output, bit for bit (same MFMA steps in the same
+    order); its BatchNorm statistics equal the sums of the stored values; ragged row counts, the affine identity, all three save modes."""
+    ops = _ops()
+    K, Co, C2 = 64, 256, 64
+    x = rnd(rows, K, seed=1).clamp_(min=0)
+    w = rnd(Co, K, seed=2) * (2.0 / Co) ** 0.5
+    w2 = rnd(C2, Co, seed=8) * (2.0 / C2) ** 0.5
+    idn = rnd(rows, Co, seed=3)
+    sc, sh = torch.rand(Co, generator=torch.Generator().manual_seed(4)) + 0.5, rnd(Co, seed=5) * 0.3
+    isc, ish = torch.rand(Co, generator=torch.Generator().manual_seed(6)) + 0.5, rnd(Co, seed=7) * 0.2
+    xg, wg, w2g = x.to(DEV).bfloat16(), w.to(DEV).bfloat16().contiguous(), w2.to(DEV).bfloat16().contiguous()
+    kw = dict(id_scale=isc.to(DEV) if ds else None, id_shift=ish.to(DEV) if ds else None)
+
+    def extras():
+        yraw = torch.zeros(rows, Co, device=DEV).bfloat16() if save == 2 else None
+        mask = torch.zeros(rows * Co // 8, device=DEV, dtype=torch.uint8) if save else None
+        return yraw, mask
+
+    # the two launches it replaces
+    out_a = torch.empty(rows, Co, device=DEV).bfloat16()
+    yraw_a, mask_a = extras()
+    ops.conv_expand_join(xg, wg, sc.to(DEV), sh.to(DEV), idn.to(DEV).bfloat16().contiguous(), out=out_a, y_raw=yraw_a, mask_out=mask_a, **kw)
+    y_a = torch.empty(1, rows, 1, C2, device=DEV).bfloat16()
+    st_a = torch.zeros(ops.STATS_REPLICAS, C2, 2, device=DEV, dtype=torch.float64)
+    ops.conv_igemm(ops.conv_desc(1, rows, 1, Co, C2, 1, 1, 0), out_a.view(1, rows, 1, Co), w2g.view(C2, 1, Co), y_a, stats=st_a)
+    # the fused launch
+    out_b = torch.empty(rows, Co, device=DEV).bfloat16()
+    yraw_b, mask_b = extras()
+    y_b = torch.full((rows + 64, C2), 7.0, device=DEV).bfloat16()          # 64 guard rows behind the tensor
+    st_b = torch.zeros(ops.STATS_REPLICAS, C2, 2, device=DEV, dtype=torch.float64)
+    ops.conv_expand_join_next(xg, wg, sc.to(DEV), sh.to(DEV), idn.to(DEV).bfloat16().contiguous(), w2g, y_b, out=out_b, y_raw=yraw_b,
+                              mask_out=mask_b, stats_next=st_b, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out_b, out_a)
+    if save == 2:
+        assert torch.equal(yraw_b, yraw_a)
+    if save:
+        assert torch.equal(mask_b, mask_a)
+    assert float((y_b[rows:].float() - 7.0).abs().max()) == 0.0
+    assert torch.equal(y_b[:rows], y_a.view(rows, C2))
+    yf = y_b[:rows].double()
+    got = st_b.sum(0)
+    np.testing.assert_allclose(got[:, 0].cpu().numpy(), yf.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(got[:, 1].cpu().numpy(), (yf * yf).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(got.cpu().numpy(), st_a.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    # in place on the identity (the no-grad forward's arrangement)
+    z = idn.to(DEV).bfloat16().contiguous()
+    y_c = torch.empty(rows, C2, device=DEV).bfloat16()
+    ops.conv_expand_join_next(xg, wg, sc.to(DEV), sh.to(DEV), z, w2g, y_c, **kw)
+    assert torch.equal(z, out_a) and torch.equal(y_c, y_a.view(rows, C2))
+
+
 def test_similarity_cross_entropy_unequal_positives_use_float():
     """utils/loss_util.py:25-36,46-48 on the HIP row kernel, against the reference's own numbers (tests/golden/g2u_loss_unequal.npz)
     incl. the process-wide cached decision (App. D item 2) and the failure the reference has when an equal-count mask came

@@ -60,6 +60,8 @@ PROTOTYPES = {
     "vince_conv_igemm": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, P(ConvEpi), c_void_p]),
     "vince_conv_expand_join": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "vince_conv_expand_join_next": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_conv3x3_strip": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_conv3x3_strip_bias": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "vince_conv3x3_strip_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, P(BnReduce), c_int32, c_void_p]),
@@ -167,7 +169,7 @@ _LIB = None
 
 
 # include/vince_hip.h VINCE_ABI_VERSION (tests/test_abi_cpu.py holds the two together)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 def lib():

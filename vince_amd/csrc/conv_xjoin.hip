@@ -48,11 +48,20 @@ struct XjParams {
     const float* br_mean;
     const float* br_invstd;
     double* br_sums;
+    // NEXT mode (the join + the FOLLOWING bottleneck's conv1, vince_conv_expand_join_next): y2[p][c1] = sum_k w2[c1][k] out[p][k]
+    const void* w2;       // [64][256] bf16
+    void* y2;             // [rows][64] bf16: the next conv1's raw output
+    double* stats2;       // double[replicas2][64][2]: (sum, sum of squares) of the stored y2
+    uint32_t w2_bytes;
+    int replicas2;
     uint32_t rows, Co, x_bytes, w_bytes;
     int ptiles, cgroups, relu, replicas;
 };
 
-template <int K, int STAGES>
+constexpr int XJ_N2 = 64;           // NEXT mode: output channels of the fused second convolution (layer1's conv1: 256 -> 64)
+constexpr int XJ_K2 = 256;          // ... and its reduction length = this launch's Co
+
+template <int K, int STAGES, bool NEXT = false>
 struct XjSmem {
     static constexpr int NKT = K / 32;                      // 64-byte K blocks per row
     static constexpr int WB = NKT * XJ_CG * 64;             // resident weights
@@ -65,7 +74,13 @@ struct XjSmem {
     static constexpr int CHW = K == 64 ? 64 : 32;
     static constexpr int TBUF = 32 * CHW * 2;
     static constexpr int OFF_T = WB + STAGES * XB + TAB;
-    static constexpr int BYTES = OFF_T + XJ_CONSUMERS * TBUF;
+    // NEXT: the eight per-consumer buffers become two SHARED ones (one per 64-pixel half): 32 pixels x all 256 output channels, 512-byte
+    // rows, 16-byte chunk c of row r at slot c ^ (r & 15) -- the four consumers of a half write their 64-channel stripes, store them
+    // from there as before, and two of them then read whole rows as the MFMA operand of the second convolution.  Same 32 KB.
+    static constexpr int ABUF = 32 * XJ_K2 * 2;
+    static constexpr int OFF_W2 = OFF_T + XJ_CONSUMERS * TBUF;
+    static constexpr int BYTES = OFF_W2 + (NEXT ? XJ_N2 * XJ_K2 * 2 : 0);
+    static_assert(!NEXT || (K == 64 && 2 * ABUF == XJ_CONSUMERS * TBUF), "NEXT: K = 64 only");
 };
 
 // PLAIN: the same streaming structure for an expand convolution on its own (resnet.py:123 without the join: grad-enabled
@@ -79,9 +94,17 @@ struct XjSmem {
 // its saved conv output) -- the join in the MFMA layout with out_old requested a unit ahead, the reduction after the
 // transposition where a lane owns the same 8 channels for the whole launch.
 // SAVE: 0 nothing beside `out`; 1 the ReLU mask bytes (the forward of the BatchNorm-backward algebra); 2 mask bytes + the raw conv output
-template <int K, int STAGES, bool ID_AFFINE, int SAVE, bool PLAIN = false, bool DGRAD = false>
+// NEXT: the FOLLOWING bottleneck's first convolution (resnet.py:117, 1x1, 256 -> 64, layer1) on the block output while it is in LDS:
+// its 411 MB re-read from HBM -- the whole cost of that launch -- goes.  Per 32-pixel unit: the four consumers of a pixel half write
+// their stripes of `out` into the shared buffer (barrier), two of them multiply the 32 x 256 rows with the resident 64 x 256 weights
+// (one 32-channel tile each, 16 x v_mfma_f32_32x32x16_bf16, K ascending: the same products in the same order as vince_conv_igemm's
+// launch, so y2 is BIT-IDENTICAL to it), store y2 as 64-byte row pieces straight from the accumulators (lane = channel) and keep
+// that channel's (sum, sum of squares) in two registers for the whole launch.  Four barriers per tile instead of one (the loader
+// counts along): stripes of unit 0 complete / read / stripes of unit 1 complete / (next tile's) read.
+template <int K, int STAGES, bool ID_AFFINE, int SAVE, bool PLAIN = false, bool DGRAD = false, bool NEXT = false>
 __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p) {
-    using S = XjSmem<K, STAGES>;
+    using S = XjSmem<K, STAGES, NEXT>;
+    static_assert(!NEXT || (!PLAIN && !DGRAD), "NEXT rides on the join");
     constexpr int NKT = S::NKT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES];
     unsigned char* const wsm = smem;
@@ -126,6 +149,15 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             const uint32_t off = co < p.Co ? (co * (uint32_t)K + (uint32_t)(kt * 32 + dchunk * 8)) * 2u : OOB;
             lds_dma16(__builtin_amdgcn_readfirstlane(smem_base + kt * (XJ_CG * 64) + rb * 64), off, rsrc_w);
         }
+        if constexpr (NEXT) {
+            // w2 rows of 512 bytes; one DMA instruction = 2 rows; lane -> (row, physical slot), logical chunk = slot ^ (row & 15)
+            const v4i_t rsrc_w2 = make_rsrc(p.w2, p.w2_bytes);
+            for (int pc = wave; pc < XJ_N2 / 2; pc += XJ_CONSUMERS + 1) {
+                const int r = pc * 2 + (lane >> 5), slot = lane & 31;
+                const uint32_t off = (uint32_t)(r * XJ_K2 + ((slot ^ (r & 15)) * 8)) * 2u;
+                lds_dma16(__builtin_amdgcn_readfirstlane(smem_base + S::OFF_W2 + pc * 1024), off, rsrc_w2);
+            }
+        }
         for (int i = tid; DGRAD && i < XJ_CG; i += XJ_THREADS) {
             const int c = c0 + i;
             const bool ok = (uint32_t)c < p.Co && p.br_y != nullptr;
@@ -169,6 +201,11 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                   // B(t)
             issue_x(t + STAGES - 1);                        // into the stage tile t-1 occupied
+            if constexpr (NEXT) {                           // the consumers' three stripe barriers of this tile
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+            }
         }
         return;
     }
@@ -204,7 +241,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) dst[j][gp] = ok ? *(const uint4*)(idn + off + j * 32 + gp * 16) : make_uint4(0, 0, 0, 0);
     };
-    unsigned char* const tbuf = smem + S::OFF_T + wave * S::TBUF;
+    unsigned char* const tbuf = smem + S::OFF_T + (NEXT ? wp * S::ABUF : wave * S::TBUF);
     constexpr int CHW = S::CHW, CPR = CHW / 8;              // channels / 16-byte chunks per buffer row
     constexpr int NPASS = 64 / CHW;                         // buffer passes per unit (1: whole 64-channel rows, 2: per MFMA tile j)
     constexpr int LPR = CPR;                                // lanes that share a pixel row when storing
@@ -227,7 +264,8 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                 const int j = NPASS == 1 ? jj : pass;
                 const int cpos = (NPASS == 1 ? j * 4 : 0) + 2 * gp + khalf;
                 const int swz = NPASS == 1 ? (row & 7) : ((row >> 1) & 3);
-                *(uint4*)(tbuf + row * (CHW * 2) + ((cpos ^ swz) * 16)) = pk[j][gp];
+                if constexpr (NEXT) *(uint4*)(tbuf + row * (XJ_K2 * 2) + (((wc * 8 + cpos) ^ (row & 15)) * 16)) = pk[j][gp];
+                else *(uint4*)(tbuf + row * (CHW * 2) + ((cpos ^ swz) * 16)) = pk[j][gp];
             }
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
@@ -235,7 +273,8 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         for (int sidx = 0; sidx < NST; ++sidx) {
             const int prow = lane / LPR + (64 / LPR) * sidx, c = lane % LPR;
             const int swz = NPASS == 1 ? (prow & 7) : ((prow >> 1) & 3);
-            const uint4 val = *(const uint4*)(tbuf + prow * (CHW * 2) + ((c ^ swz) * 16));
+            const uint4 val = NEXT ? *(const uint4*)(tbuf + prow * (XJ_K2 * 2) + (((wc * 8 + c) ^ (prow & 15)) * 16))
+                                   : *(const uint4*)(tbuf + prow * (CHW * 2) + ((c ^ swz) * 16));
             const uint32_t pix = pix0 + (uint32_t)prow;
             if (pix < p.rows) {
                 const size_t off = (size_t)pix * p.Co + (size_t)(c0 + wc * 64 + (NPASS == 1 ? 0 : pass * 32) + c * 8);
@@ -397,10 +436,54 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             }
         if (t < ntiles) {                                   // (uniform)
             const uint32_t pix0 = (uint32_t)(first + t * step) * XJ_PX + (uint32_t)(wp * 64 + i * 32);
+            if constexpr (NEXT) {
+                // the shared buffer still holds unit 0's rows for the two wavefronts multiplying them: nobody overwrites before they are done
+                if (i == 1) __builtin_amdgcn_s_barrier();
+                if constexpr (SAVE == 2) stage_store(rpk, 0, yraw, nullptr, pix0);   // raw output first: the buffer must END UP holding `out`
+                stage_store(opk, 0, out, SAVE ? p.mask_out : nullptr, pix0);
+            } else {
 #pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                stage_store(opk, pass, out, SAVE ? p.mask_out : nullptr, pix0);
-                if constexpr (SAVE == 2) stage_store(rpk, pass, yraw, nullptr, pix0);
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    stage_store(opk, pass, out, SAVE ? p.mask_out : nullptr, pix0);
+                    if constexpr (SAVE == 2) stage_store(rpk, pass, yraw, nullptr, pix0);
+                }
+            }
+        }
+    };
+    // NEXT: the second convolution of unit (t, i) for this pixel half, channel tile (wc & 1) -- run by the consumers with (wc >> 1) == i
+    float s2 = 0.f, q2 = 0.f;                               // statistics of channel (wc & 1) * 32 + (lane & 31), this lane's pixel rows
+    auto gemm2 = [&](int t, int i) {
+        const int sz = lane & 15;                           // (row & 15) of both operands' rows: lane & 31 within a 32-row tile
+        const unsigned char* const arow = tbuf + (lane & 31) * (XJ_K2 * 2);
+        const unsigned char* const brow = smem + S::OFF_W2 + ((wc & 1) * 32 + (lane & 31)) * (XJ_K2 * 2);
+        f32x16_t c2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c2[e] = 0.f;
+#pragma unroll 4
+        for (int s = 0; s < XJ_K2 / 16; ++s) {
+            const int slot = ((2 * s + khalf) ^ sz) * 16;
+            const uint4 af = *(const uint4*)(arow + slot), bf = *(const uint4*)(brow + slot);
+            bf16x8_t av, bv;
+            __builtin_memcpy(&av, &af, 16);
+            __builtin_memcpy(&bv, &bf, 16);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c2, 0, 0, 0);
+        }
+        // C[pixel][channel]: lane = channel column, register r = pixel row (r & 3) + 8 (r >> 2) + 4 khalf: 32 lanes store 64 consecutive bytes
+        const uint32_t pix0 = (uint32_t)(first + t * step) * XJ_PX + (uint32_t)(wp * 64 + i * 32);
+        bf16_t* __restrict__ y2 = (bf16_t*)p.y2 + (size_t)((wc & 1) * 32 + (lane & 31));
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const uint32_t u = pack_bf16x2(c2[r], c2[r + 1]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t pix = pix0 + (uint32_t)(((r + h) & 3) + 8 * ((r + h) >> 2) + 4 * khalf);
+                if (pix < p.rows) {
+                    const uint32_t b16 = h ? (u >> 16) : (u & 0xffffu);
+                    y2[(size_t)pix * XJ_N2] = (bf16_t)b16;
+                    const float f = __uint_as_float(b16 << 16);
+                    s2 += f;
+                    q2 += f * f;
+                }
             }
         }
     };
@@ -417,7 +500,28 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             __builtin_amdgcn_s_barrier();                   // B(t): the loader has seen tile t land
             run_unit(oA, t, 0);
             load_ids(oA, t + 1, 0);
+            if constexpr (NEXT) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();               // every stripe of unit 0 is in the shared buffers
+                if ((wc >> 1) == 0) gemm2(t, 0);
+            }
             run_unit(oB, t, 1);
+            if constexpr (NEXT) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();               // ... of unit 1 (B(t + 1) keeps the next tile's stripes behind these reads)
+                if ((wc >> 1) == 1) gemm2(t, 1);
+            }
+        }
+    }
+    if constexpr (NEXT) {
+        if (p.stats2) {                                     // the two lane halves hold the same channel: fold, one fp64 atomic pair per channel and wavefront
+            s2 += __shfl_xor(s2, 32, 64);
+            q2 += __shfl_xor(q2, 32, 64);
+            if (lane < 32) {
+                double* dst = p.stats2 + ((size_t)(blockIdx.x % (unsigned)p.replicas2) * XJ_N2 + (size_t)((wc & 1) * 32 + lane)) * 2;
+                unsafeAtomicAdd(dst, (double)s2);
+                unsafeAtomicAdd(dst + 1, (double)q2);
+            }
         }
     }
     if constexpr (PLAIN || DGRAD) {
@@ -552,10 +656,36 @@ static int expand_dgrad_common(int dtype, const void* dy, const void* wt, int64_
     return VINCE_OK;
 }
 
+static int expand_join_common(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
+                              const float* out_scale, const float* out_shift, const void* identity,
+                              const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
+                              int relu, const void* w_next, void* y_next, double* stats_next, int32_t replicas_next, void* stream);
+
 extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                                       const float* out_scale, const float* out_shift, const void* identity,
                                       const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
                                       int relu, void* stream) {
+    return expand_join_common(dtype, x, w, rows, K, Co, out_scale, out_shift, identity, id_scale, id_shift, out, y_raw, mask_out, relu,
+                              nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int vince_conv_expand_join_next(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
+                                           const float* out_scale, const float* out_shift, const void* identity,
+                                           const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
+                                           int relu, const void* w_next, int32_t Co_next, void* y_next, double* stats_next,
+                                           int32_t replicas_next, void* stream) {
+    VINCE_CHECK_ARG(w_next && y_next, VINCE_E_ARG, "vince_conv_expand_join_next: null pointer");
+    VINCE_CHECK_ARG(K == 64 && Co == XJ_K2 && Co_next == XJ_N2, VINCE_E_UNSUPPORTED,
+                    "vince_conv_expand_join_next: K=%d Co=%d Co_next=%d (64, 256, 64: layer1)", K, Co, Co_next);
+    VINCE_CHECK_ARG((((uintptr_t)w_next | (uintptr_t)y_next) & 15) == 0, VINCE_E_ALIGN, "vince_conv_expand_join_next: pointers must be 16-byte aligned");
+    return expand_join_common(dtype, x, w, rows, K, Co, out_scale, out_shift, identity, id_scale, id_shift, out, y_raw, mask_out, relu,
+                              w_next, y_next, stats_next, replicas_next, stream);
+}
+
+static int expand_join_common(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
+                              const float* out_scale, const float* out_shift, const void* identity,
+                              const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
+                              int relu, const void* w_next, void* y_next, double* stats_next, int32_t replicas_next, void* stream) {
     VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_expand_join: bf16 only (fp32 runs vince_conv_igemm's join epilogue)");
     VINCE_CHECK_ARG(x && w && out_scale && out_shift && identity && out && rows > 0, VINCE_E_ARG, "vince_conv_expand_join: null pointer");
     VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_join: K=%d (64 or 128)", K);
@@ -576,6 +706,8 @@ extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, i
     p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
     p.cgroups = Co / XJ_CG;
     p.relu = relu;
+    p.w2 = w_next; p.y2 = y_next; p.stats2 = stats_next; p.w2_bytes = XJ_N2 * XJ_K2 * 2;
+    p.replicas2 = (replicas_next <= 0 || replicas_next > VINCE_STATS_REPLICAS) ? VINCE_STATS_REPLICAS : replicas_next;
     const int n_cu = xj_num_cu();
     static const int wg_per_cu = VINCE_MEASURE_KNOB("xj_wgs", 1);   // (measurement aid)
     long grid = (long)n_cu * wg_per_cu;
@@ -591,8 +723,15 @@ extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, i
         else if (mask_out) { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, 1); else VINCE_XJ_LAUNCH(KK, SS, false, 1); }    \
         else { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, 0); else VINCE_XJ_LAUNCH(KK, SS, false, 0); }                  \
     } while (0)
-    VinceProfScope prof(VINCE_TAG_XJOIN, (double)rows * 2 * (K + Co * (2 + (y_raw ? 1 : 0))) + (mask_out ? (double)rows * Co / 8 : 0), stream);
-    if (K == 64) VINCE_XJ_PICK(64, 3); else VINCE_XJ_PICK(128, 2);
+#define VINCE_XJ_LAUNCH_NEXT(AA, SV) \
+    hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, AA, SV, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p)
+    VinceProfScope prof(VINCE_TAG_XJOIN, (double)rows * 2 * (K + Co * (2 + (y_raw ? 1 : 0)) + (w_next ? XJ_N2 : 0)) + (mask_out ? (double)rows * Co / 8 : 0), stream);
+    if (w_next) {
+        if (y_raw) { if (id_scale) VINCE_XJ_LAUNCH_NEXT(true, 2); else VINCE_XJ_LAUNCH_NEXT(false, 2); }
+        else if (mask_out) { if (id_scale) VINCE_XJ_LAUNCH_NEXT(true, 1); else VINCE_XJ_LAUNCH_NEXT(false, 1); }
+        else { if (id_scale) VINCE_XJ_LAUNCH_NEXT(true, 0); else VINCE_XJ_LAUNCH_NEXT(false, 0); }
+    } else if (K == 64) VINCE_XJ_PICK(64, 3); else VINCE_XJ_PICK(128, 2);
+#undef VINCE_XJ_LAUNCH_NEXT
 #undef VINCE_XJ_PICK
 #undef VINCE_XJ_LAUNCH
     VINCE_CHECK_LAUNCH();

@@ -976,10 +976,16 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     if (gram_on && t->gram_bytes)
         RC(vince_zero_async(at(workspace, t->off_gram), t->gram_bytes, stream));
     size_t cur = t->off_p0;   // where the running block input lives (gram blocks update it in place, so b.x_in may be stale)
+    // `xjoin_next`: a layer1 join also runs the NEXT block's conv1 (256 -> 64) on the block output while it is in LDS
+    // (vince_conv_expand_join_next: the 411 MB re-read of that launch goes); 0 = every conv1 as its own launch (cross-check switch)
+    const bool next_env = vince_knob_live("xjoin_next", 1) != 0;
+    bool conv1_done = false;  // block bi's conv1 (output + statistics) came out of block bi-1's join
     for (size_t bi = 0; bi < t->blocks.size(); ++bi) {
         const Blk& b = t->blocks[bi];
         const size_t x_in = cur;
         size_t in = x_in;
+        const bool skip_conv1 = conv1_done;
+        conv1_done = false;
         const bool xj_ok = xjoin_env && c.dtype == VINCE_BF16 && b.nconv == 3 && (b.c[2].Ci == 64 || b.c[2].Ci == 128) &&
                            b.c[2].Co % 256 == 0 &&
                            (unsigned long long)t->cfg.N * b.c[2].Hi * b.c[2].Wi * b.c[2].Ci * 2 < 0x7ff00000ull;   // 31-bit descriptor offsets
@@ -995,7 +1001,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
         const int nplain = gram_blk ? b.nconv - 1 : b.nconv;   // convs that run with their own statistics epilogue
         bool gram_done = false;
         for (int ci = 0; ci < nplain; ++ci) {
-            RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, false));
+            if (!(ci == 0 && skip_conv1)) RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, false));
             if (ci < b.nconv - 1) {
                 // (the pass that writes conv3's input also sums it per channel when the Gram path follows -- and, for the bf16
                 // K = 64 / 128 blocks, multiplies what it writes into the Gram matrix itself: csrc/bn_gram.hip, `gram_fused=0` restores the
@@ -1044,7 +1050,17 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             if (save) out = b.z;               // backward reads the identity tensors again: nothing in place
             // bf16 at K = 64 / 128: the persistent streaming kernel (csrc/conv_xjoin.hip); otherwise the implicit-GEMM kernel's join
             // epilogue (fp32, or VINCE_XJOIN=0 as a cross-check; no-grad forwards only)
-            if (xj_ok) {
+            const Blk* nb = bi + 1 < t->blocks.size() ? &t->blocks[bi + 1] : nullptr;
+            const bool fuse_next = next_env && xj_ok && train_bn && cv.Ci == 64 && cv.Co == 256 && nb && nb->nconv == 3 && !nb->has_ds &&
+                                   nb->c[0].k == 1 && nb->c[0].stride == 1 && nb->c[0].Ci == 256 && nb->c[0].Co == 64;
+            if (fuse_next) {
+                RC(vince_conv_expand_join_next(c.dtype, at(workspace, in), at((void*)wcache, cv.wk), rows, cv.Ci, cv.Co, e.out_scale, e.bias,
+                                               at(workspace, idn), e.id_scale, e.id_shift, at(workspace, out),
+                                               (save && !(alg_fwd && alg_block(t, bi))) ? at(workspace, b.y[L]) : nullptr,
+                                               save ? zmask : nullptr, 1, at((void*)wcache, nb->c[0].wk), nb->c[0].Co,
+                                               at(workspace, nb->y[0]), c.stats(nb->b[0]), nb->b[0].R, stream));
+                conv1_done = true;
+            } else if (xj_ok) {
                 RC(vince_conv_expand_join(c.dtype, at(workspace, in), at((void*)wcache, cv.wk), rows, cv.Ci, cv.Co, e.out_scale, e.bias,
                                           at(workspace, idn), e.id_scale, e.id_shift, at(workspace, out),
                                           (save && !(alg_fwd && alg_block(t, bi))) ? at(workspace, b.y[L]) : nullptr,

@@ -164,6 +164,21 @@ def conv_expand_join(x, w, out_scale, out_shift, identity, out=None, id_scale=No
     return out
 
 
+def conv_expand_join_next(x, w, out_scale, out_shift, identity, w_next, y_next, out=None, id_scale=None, id_shift=None, relu=True,
+                          y_raw=None, mask_out=None, stats_next=None, replicas_next=0):
+    """conv_expand_join plus the next bottleneck's conv1 on the block output while it is on chip (vince_conv_expand_join_next):
+    y_next [rows, 64] = out @ w_next.T as vince_conv_igemm stores it, its BatchNorm statistics into stats_next (float64
+    [replicas, 64, 2], zeroed by the caller).  K = 64, Co = 256."""
+    require_gpu(x, w, out_scale, out_shift, identity, out, id_scale, id_shift, y_raw, mask_out, w_next, y_next, stats_next)
+    out = identity if out is None else out
+    rows, K = x.numel() // x.shape[-1], x.shape[-1]
+    check(lib().vince_conv_expand_join_next(dtype_code(x), _ptr(x), _ptr(w), rows, K, w.shape[0], _ptr(out_scale), _ptr(out_shift),
+                                            _ptr(identity), _ptr(id_scale), _ptr(id_shift), _ptr(out), _ptr(y_raw), _ptr(mask_out),
+                                            int(relu), _ptr(w_next), w_next.shape[0], _ptr(y_next), _ptr(stats_next), int(replicas_next),
+                                            stream_ptr()))
+    return out, y_next
+
+
 def conv_expand_stats(x, w, out, stats=None, replicas=0):
     """out = x @ w.T (bf16, K = 64 / 128, Co multiple of 256) through the streaming kernel, BatchNorm statistics of the stored
     values into stats (double[R][Co][2], zeroed by the caller)."""
