@@ -186,13 +186,15 @@ int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows
 /* vince_conv_expand_join plus the FIRST convolution of the bottleneck that follows (resnet.py:117 of the next block: 1x1, stride 1,
  * Co -> Co_next) on the block output while it is still on chip:
  *   y_next[p][c] = sum_k w_next[c][k] out[p][k]      (bf16, what vince_conv_igemm stores for that layer, bit for bit)
- * with the BatchNorm statistics of the stored y_next in stats_next (double[replicas_next][Co_next][2], zeroed by the caller; optional).
+ * with the BatchNorm statistics of the stored y_next in stats_next (double[replicas_next][Co_next][2], zeroed by the caller; optional);
+ * or, for a folded inference trunk (bias_next non-NULL), y_next = [relu_next]( y_next + bias_next[c] ) with vince_conv_igemm's roundings.
  * The block output is 4x wider than anything else in a bottleneck; this launch saves its re-read (411 MB per layer1 block boundary at
  * 256 frames).  K = 64, Co = 256, Co_next = 64 (layer1's identity blocks); everything else as vince_conv_expand_join. */
 int vince_conv_expand_join_next(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                                 const float* out_scale, const float* out_shift, const void* identity, const float* id_scale,
                                 const float* id_shift, void* out, void* y_raw, uint8_t* mask_out, int relu, const void* w_next,
-                                int32_t Co_next, void* y_next, double* stats_next, int32_t replicas_next, void* stream);
+                                int32_t Co_next, void* y_next, double* stats_next, int32_t replicas_next, const float* bias_next,
+                                int relu_next, void* stream);
 
 /* The same streaming structure for an expand convolution on its own: out[p][co] = sum_k w[co][k] x[p][k] (bf16, K = 64 / 128,
  * Co multiple of 256, stride 1) with the BatchNorm statistics of the STORED values accumulated into stats

@@ -866,6 +866,15 @@ def test_conv_expand_join_next_block_conv1_fused(rows, ds, save):
     y_c = torch.empty(rows, C2, device=DEV).bfloat16()
     ops.conv_expand_join_next(xg, wg, sc.to(DEV), sh.to(DEV), z, w2g, y_c, **kw)
     assert torch.equal(z, out_a) and torch.equal(y_c, y_a.view(rows, C2))
+    # the folded-inference epilogue: y_next = relu(conv + bias) with the implicit-GEMM kernel's roundings
+    from vince_amd._lib import EPI_RELU
+    b2 = (rnd(C2, seed=9) * 0.5).to(DEV)
+    y_d = torch.empty(1, rows, 1, C2, device=DEV).bfloat16()
+    ops.conv_igemm(ops.conv_desc(1, rows, 1, Co, C2, 1, 1, 0), out_a.view(1, rows, 1, Co), w2g.view(C2, 1, Co), y_d, bias=b2, flags=EPI_RELU)
+    z = idn.to(DEV).bfloat16().contiguous()
+    y_e = torch.empty(rows, C2, device=DEV).bfloat16()
+    ops.conv_expand_join_next(xg, wg, sc.to(DEV), sh.to(DEV), z, w2g, y_e, bias_next=b2, relu_next=True, **kw)
+    assert torch.equal(z, out_a) and torch.equal(y_e, y_d.view(rows, C2))
 
 
 def test_similarity_cross_entropy_unequal_positives_use_float():

@@ -61,7 +61,7 @@ PROTOTYPES = {
     "vince_conv_expand_join": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vince_conv_expand_join_next": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int, c_void_p]),
     "vince_conv3x3_strip": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_conv3x3_strip_bias": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "vince_conv3x3_strip_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, P(BnReduce), c_int32, c_void_p]),

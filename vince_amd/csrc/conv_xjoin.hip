@@ -52,6 +52,8 @@ struct XjParams {
     const void* w2;       // [64][256] bf16
     void* y2;             // [rows][64] bf16: the next conv1's raw output
     double* stats2;       // double[replicas2][64][2]: (sum, sum of squares) of the stored y2
+    const float* bias2;   // optional (folded inference): y2 = [relu]( bf16(conv) + bias2[c] ), as vince_conv_igemm's bias epilogue rounds
+    int relu2;
     uint32_t w2_bytes;
     int replicas2;
     uint32_t rows, Co, x_bytes, w_bytes;
@@ -278,6 +280,14 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             const uint32_t pix = pix0 + (uint32_t)prow;
             if (pix < p.rows) {
                 const size_t off = (size_t)pix * p.Co + (size_t)(c0 + wc * 64 + (NPASS == 1 ? 0 : pass * 32) + c * 8);
+#if defined(VINCE_XJ_OUT_NT)
+                if constexpr ((VINCE_XJ_OUT_NT == 1 && NEXT) || (VINCE_XJ_OUT_NT == 2 && !PLAIN && !DGRAD)) {
+                    typedef __attribute__((ext_vector_type(4))) float f4;
+                    f4 tv;
+                    __builtin_memcpy(&tv, &val, 16);
+                    __builtin_nontemporal_store(tv, (f4*)(dst + off));
+                } else
+#endif
                 *(uint4*)(dst + off) = val;
                 if constexpr (PLAIN) {
                     float f[8];
@@ -471,6 +481,17 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         // C[pixel][channel]: lane = channel column, register r = pixel row (r & 3) + 8 (r >> 2) + 4 khalf: 32 lanes store 64 consecutive bytes
         const uint32_t pix0 = (uint32_t)(first + t * step) * XJ_PX + (uint32_t)(wp * 64 + i * 32);
         bf16_t* __restrict__ y2 = (bf16_t*)p.y2 + (size_t)((wc & 1) * 32 + (lane & 31));
+        if (p.bias2) {                                      // (uniform) the implicit-GEMM epilogue's order: round, add the bias, ReLU, round
+            const float b2 = p.bias2[(wc & 1) * 32 + (lane & 31)];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t u0 = pack_bf16x2(c2[r], c2[r + 1]);
+                float f0 = __uint_as_float(u0 << 16) + b2, f1 = __uint_as_float(u0 & 0xffff0000u) + b2;
+                if (p.relu2) { f0 = fmaxf(f0, 0.f); f1 = fmaxf(f1, 0.f); }
+                c2[r] = f0;
+                c2[r + 1] = f1;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const uint32_t u = pack_bf16x2(c2[r], c2[r + 1]);
@@ -659,33 +680,35 @@ static int expand_dgrad_common(int dtype, const void* dy, const void* wt, int64_
 static int expand_join_common(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                               const float* out_scale, const float* out_shift, const void* identity,
                               const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
-                              int relu, const void* w_next, void* y_next, double* stats_next, int32_t replicas_next, void* stream);
+                              int relu, const void* w_next, void* y_next, double* stats_next, int32_t replicas_next, const float* bias_next,
+                              int relu_next, void* stream);
 
 extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                                       const float* out_scale, const float* out_shift, const void* identity,
                                       const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
                                       int relu, void* stream) {
     return expand_join_common(dtype, x, w, rows, K, Co, out_scale, out_shift, identity, id_scale, id_shift, out, y_raw, mask_out, relu,
-                              nullptr, nullptr, nullptr, 0, stream);
+                              nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
 }
 
 extern "C" int vince_conv_expand_join_next(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                                            const float* out_scale, const float* out_shift, const void* identity,
                                            const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
                                            int relu, const void* w_next, int32_t Co_next, void* y_next, double* stats_next,
-                                           int32_t replicas_next, void* stream) {
+                                           int32_t replicas_next, const float* bias_next, int relu_next, void* stream) {
     VINCE_CHECK_ARG(w_next && y_next, VINCE_E_ARG, "vince_conv_expand_join_next: null pointer");
     VINCE_CHECK_ARG(K == 64 && Co == XJ_K2 && Co_next == XJ_N2, VINCE_E_UNSUPPORTED,
                     "vince_conv_expand_join_next: K=%d Co=%d Co_next=%d (64, 256, 64: layer1)", K, Co, Co_next);
     VINCE_CHECK_ARG((((uintptr_t)w_next | (uintptr_t)y_next) & 15) == 0, VINCE_E_ALIGN, "vince_conv_expand_join_next: pointers must be 16-byte aligned");
     return expand_join_common(dtype, x, w, rows, K, Co, out_scale, out_shift, identity, id_scale, id_shift, out, y_raw, mask_out, relu,
-                              w_next, y_next, stats_next, replicas_next, stream);
+                              w_next, y_next, stats_next, replicas_next, bias_next, relu_next, stream);
 }
 
 static int expand_join_common(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                               const float* out_scale, const float* out_shift, const void* identity,
                               const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
-                              int relu, const void* w_next, void* y_next, double* stats_next, int32_t replicas_next, void* stream) {
+                              int relu, const void* w_next, void* y_next, double* stats_next, int32_t replicas_next, const float* bias_next,
+                              int relu_next, void* stream) {
     VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_expand_join: bf16 only (fp32 runs vince_conv_igemm's join epilogue)");
     VINCE_CHECK_ARG(x && w && out_scale && out_shift && identity && out && rows > 0, VINCE_E_ARG, "vince_conv_expand_join: null pointer");
     VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_join: K=%d (64 or 128)", K);
@@ -706,7 +729,7 @@ static int expand_join_common(int dtype, const void* x, const void* w, int64_t r
     p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
     p.cgroups = Co / XJ_CG;
     p.relu = relu;
-    p.w2 = w_next; p.y2 = y_next; p.stats2 = stats_next; p.w2_bytes = XJ_N2 * XJ_K2 * 2;
+    p.w2 = w_next; p.y2 = y_next; p.stats2 = stats_next; p.w2_bytes = XJ_N2 * XJ_K2 * 2; p.bias2 = bias_next; p.relu2 = relu_next;
     p.replicas2 = (replicas_next <= 0 || replicas_next > VINCE_STATS_REPLICAS) ? VINCE_STATS_REPLICAS : replicas_next;
     const int n_cu = xj_num_cu();
     static const int wg_per_cu = VINCE_MEASURE_KNOB("xj_wgs", 1);   // (measurement aid)

@@ -860,11 +860,19 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
     RC(vince_stem_pool_fwd(dtype, at(workspace, t->off_ystem), ones, ones + 64, at(workspace, t->off_p0),
                            (uint8_t*)at(workspace, t->off_amax), N, t->sH, t->sW, 64, stream));
     void* cur = at(workspace, t->off_p0);   // the running block output; identity blocks update it in place
+    static const bool next_folded = vince_knob("xjoin_next", 1) != 0;
+    bool conv1_done = false;   // block bi's conv1 (+ bias + ReLU) came out of block bi-1's join launch (vince_conv_expand_join_next)
     for (size_t bi = 0; bi < t->blocks.size(); ++bi) {
         const Blk& b = t->blocks[bi];
         const void* in = cur;
+        const bool skip_conv1 = conv1_done;
+        conv1_done = false;
         for (int ci = 0; ci < b.nconv - 1; ++ci) {
             const ConvL& cv = b.c[ci];
+            if (ci == 0 && skip_conv1) {
+                in = at(workspace, b.a[0]);
+                continue;
+            }
             // layer1's 3x3 (64 -> 64 at 56 x 56, bf16): the image-strip kernel with the bias + ReLU epilogue (bit-identical output)
             static const bool strip3x3 = (vince_knob("strip3x3", 1) != 0) && (vince_knob("xjoin_folded", 1) != 0);
             if (strip3x3 && dtype == VINCE_BF16 && t->cf == VINCE_BF16 && cv.k == 3 && cv.stride == 1 && cv.Ci == 64 && cv.Co == 64 &&
@@ -887,7 +895,17 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
             VINCE_CHECK_HIP(hipMemcpyAsync(out, cur, (size_t)N * b.c[L].Ho * b.c[L].Wo * b.c[L].Co * t->esize,
                                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
         }
-        if (folded_xjoin_block(t, b)) {
+        const Blk* nb = bi + 1 < t->blocks.size() ? &t->blocks[bi + 1] : nullptr;
+        if (folded_xjoin_block(t, b) && next_folded && b.c[L].Ci == 64 && b.c[L].Co == 256 && nb && nb->nconv == 3 && !nb->has_ds &&
+            nb->c[0].k == 1 && nb->c[0].stride == 1 && nb->c[0].Ci == 256 && nb->c[0].Co == 64) {
+            // ... and the next block's conv1 + bias + ReLU on the block output while it is in LDS
+            const ConvL& cv = b.c[L];
+            RC(vince_conv_expand_join_next(dtype, in, at((void*)wcache, cv.wk), (int64_t)N * cv.Ho * cv.Wo, cv.Ci, cv.Co,
+                                           fold_scale(t, (void*)wcache) + b.b[L].consts / 4, bias + b.b[L].consts / 4, out, nullptr, nullptr, out,
+                                           nullptr, nullptr, 1, at((void*)wcache, nb->c[0].wk), nb->c[0].Co, at(workspace, nb->a[0]), nullptr, 0,
+                                           bias + nb->b[0].consts / 4, 1, stream));
+            conv1_done = true;
+        } else if (folded_xjoin_block(t, b)) {
             const ConvL& cv = b.c[L];
             RC(vince_conv_expand_join(dtype, in, at((void*)wcache, cv.wk), (int64_t)N * cv.Ho * cv.Wo, cv.Ci, cv.Co,
                                       fold_scale(t, (void*)wcache) + b.b[L].consts / 4, bias + b.b[L].consts / 4, out, nullptr, nullptr, out,
@@ -1058,7 +1076,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
                                                at(workspace, idn), e.id_scale, e.id_shift, at(workspace, out),
                                                (save && !(alg_fwd && alg_block(t, bi))) ? at(workspace, b.y[L]) : nullptr,
                                                save ? zmask : nullptr, 1, at((void*)wcache, nb->c[0].wk), nb->c[0].Co,
-                                               at(workspace, nb->y[0]), c.stats(nb->b[0]), nb->b[0].R, stream));
+                                               at(workspace, nb->y[0]), c.stats(nb->b[0]), nb->b[0].R, nullptr, 0, stream));
                 conv1_done = true;
             } else if (xj_ok) {
                 RC(vince_conv_expand_join(c.dtype, at(workspace, in), at((void*)wcache, cv.wk), rows, cv.Ci, cv.Co, e.out_scale, e.bias,

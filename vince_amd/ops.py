@@ -165,17 +165,17 @@ def conv_expand_join(x, w, out_scale, out_shift, identity, out=None, id_scale=No
 
 
 def conv_expand_join_next(x, w, out_scale, out_shift, identity, w_next, y_next, out=None, id_scale=None, id_shift=None, relu=True,
-                          y_raw=None, mask_out=None, stats_next=None, replicas_next=0):
+                          y_raw=None, mask_out=None, stats_next=None, replicas_next=0, bias_next=None, relu_next=False):
     """conv_expand_join plus the next bottleneck's conv1 on the block output while it is on chip (vince_conv_expand_join_next):
     y_next [rows, 64] = out @ w_next.T as vince_conv_igemm stores it, its BatchNorm statistics into stats_next (float64
-    [replicas, 64, 2], zeroed by the caller).  K = 64, Co = 256."""
-    require_gpu(x, w, out_scale, out_shift, identity, out, id_scale, id_shift, y_raw, mask_out, w_next, y_next, stats_next)
+    [replicas, 64, 2], zeroed by the caller); bias_next / relu_next: the folded-inference epilogue instead.  K = 64, Co = 256."""
+    require_gpu(x, w, out_scale, out_shift, identity, out, id_scale, id_shift, y_raw, mask_out, w_next, y_next, stats_next, bias_next)
     out = identity if out is None else out
     rows, K = x.numel() // x.shape[-1], x.shape[-1]
     check(lib().vince_conv_expand_join_next(dtype_code(x), _ptr(x), _ptr(w), rows, K, w.shape[0], _ptr(out_scale), _ptr(out_shift),
                                             _ptr(identity), _ptr(id_scale), _ptr(id_shift), _ptr(out), _ptr(y_raw), _ptr(mask_out),
                                             int(relu), _ptr(w_next), w_next.shape[0], _ptr(y_next), _ptr(stats_next), int(replicas_next),
-                                            stream_ptr()))
+                                            _ptr(bias_next), int(relu_next), stream_ptr()))
     return out, y_next
 
 
