@@ -280,14 +280,6 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             const uint32_t pix = pix0 + (uint32_t)prow;
             if (pix < p.rows) {
                 const size_t off = (size_t)pix * p.Co + (size_t)(c0 + wc * 64 + (NPASS == 1 ? 0 : pass * 32) + c * 8);
-#if defined(VINCE_XJ_OUT_NT)
-                if constexpr ((VINCE_XJ_OUT_NT == 1 && NEXT) || (VINCE_XJ_OUT_NT == 2 && !PLAIN && !DGRAD)) {
-                    typedef __attribute__((ext_vector_type(4))) float f4;
-                    f4 tv;
-                    __builtin_memcpy(&tv, &val, 16);
-                    __builtin_nontemporal_store(tv, (f4*)(dst + off));
-                } else
-#endif
                 *(uint4*)(dst + off) = val;
                 if constexpr (PLAIN) {
                     float f[8];
