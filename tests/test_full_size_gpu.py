@@ -342,7 +342,9 @@ def test_full_size_backward_serialised_vs_overlapped_streams(tmp_path, dtype):
     assert list(a["grad_names"]) == list(b["grad_names"])
     worst = float(np.abs(a["grad_checksums"][:, 2] / b["grad_checksums"][:, 2] - 1).max())
     print("serialised vs overlapped (%s): worst sum|g| ratio error %.2e" % (dtype, worst))
-    np.testing.assert_allclose(a["grad_checksums"][:, 2], b["grad_checksums"][:, 2], rtol=2e-4 if dtype != "bf16" else 2e-2)
+    # bf16: nine runs on MI355X measured 8e-3 ... 1.8e-2 for the worst tensor (run-to-run: the order of the fp32 atomics decides bf16 rounding
+    # flips, the same noise between two runs of ONE arrangement), so 2e-2 failed one run in ten; a race moves a tensor by O(1)
+    np.testing.assert_allclose(a["grad_checksums"][:, 2], b["grad_checksums"][:, 2], rtol=2e-4 if dtype != "bf16" else 4e-2)
     for n in sampled:
         assert _rel(a["grad_" + n], b["grad_" + n]) < (2e-3 if dtype != "bf16" else 5e-2), n
 
