@@ -21,7 +21,7 @@ M=$(find $O/pmc_mfma -name '*.db' | head -1); timeout 60 python tools/pmc_mfma.p
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_mfma
 head -2 $O/pmc_summary.txt
 timeout 300 python tools/step_phases.py 20 bf16 2>/dev/null | tail -1 > $O/step_phases.txt
-timeout 1500 python tools/ab.py 4 40 "BASE" "VINCE_DEFER_STEM=1" "VINCE_DEFER_STEM=0" "VINCE_EARLY_PREP=0" "VINCE_HEAD_X3=0" "VINCE_KNOBS=gram_max_k=128" > $O/ab.txt 2>&1
+timeout 1500 python tools/ab.py 4 40 "BASE" "VINCE_DEFER_STEM=1" "VINCE_KNOBS=xjoin_next=0" "VINCE_KNOBS=bn_nt=0" "VINCE_KNOBS=xjoin_next=0,bn_nt=0" > $O/ab.txt 2>&1
 cat $O/ab.txt
 cp $O/pmc_conv_igemm.json profiles/pmc_conv_igemm.json
 VINCE_PROFILE_DUMP=$O/layers.csv timeout 600 python bench.py > $O/bench.json 2> $O/bench.err

@@ -49,7 +49,7 @@ timeout 1500 python -m pytest tests/test_full_size_gpu.py -q -s -k "g9 or g12" 2
 timeout 300 python tools/step_phases.py 20 bf16 2>/dev/null | tail -1 > $O/step_phases.txt
 timeout 300 python tools/step_phases.py 10 x3 2>/dev/null | tail -1 >> $O/step_phases.txt
 timeout 400 python tools/group_bound.py 256 10 2>/dev/null | tail -2 > $O/group_bound.txt
-timeout 1500 python tools/ab.py 3 40 "BASE" "VINCE_DEFER_STEM=1" "VINCE_DEFER_STEM=0" "VINCE_EARLY_PREP=0" "VINCE_HEAD_X3=0" "VINCE_KNOBS=gram_max_k=128" > $O/ab.txt 2>&1
+timeout 1500 python tools/ab.py 3 40 "BASE" "VINCE_DEFER_STEM=1" "VINCE_KNOBS=xjoin_next=0" "VINCE_KNOBS=bn_nt=0" "VINCE_KNOBS=xjoin_next=0,bn_nt=0" "VINCE_DEFER_STEM=0" "VINCE_HEAD_X3=0" > $O/ab.txt 2>&1
 export VINCE_GIT_HEAD=${VINCE_GIT_HEAD:-unknown}
 # the bench line once more, now that profiles/pmc_conv_igemm.json of THIS build exists (traffic_stale false)
 cp $O/pmc_conv_igemm.json profiles/pmc_conv_igemm.json
