@@ -189,7 +189,8 @@ int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows
  * with the BatchNorm statistics of the stored y_next in stats_next (double[replicas_next][Co_next][2], zeroed by the caller; optional);
  * or, for a folded inference trunk (bias_next non-NULL), y_next = [relu_next]( y_next + bias_next[c] ) with vince_conv_igemm's roundings.
  * The block output is 4x wider than anything else in a bottleneck; this launch saves its re-read (411 MB per layer1 block boundary at
- * 256 frames).  K = 64, Co = 256, Co_next = 64 (layer1's identity blocks); everything else as vince_conv_expand_join. */
+ * 256 frames).  K = 64, Co = 256; Co_next = 64 (layer1's identity blocks) or, with a plain identity (id_scale NULL), 128 (the first
+ * block of layer2 behind layer1's last); everything else as vince_conv_expand_join. */
 int vince_conv_expand_join_next(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                                 const float* out_scale, const float* out_shift, const void* identity, const float* id_scale,
                                 const float* id_shift, void* out, void* y_raw, uint8_t* mask_out, int relu, const void* w_next,

@@ -812,14 +812,16 @@ def test_conv_expand_join_streaming_kernel(rows, K, Co, ds):
     assert torch.equal(bits, out2 > 0) or float((bits != (out2 > 0)).float().mean()) < 1e-3   # mask == (relu output > 0) up to -0 / tiny
 
 
-@pytest.mark.parametrize("rows,ds,save", [(4 * 56 * 56, False, 0), (128 * 37 + 5, True, 0), (3 * 56 * 56 + 17, False, 2), (1000, True, 1), (37, False, 2)])
-def test_conv_expand_join_next_block_conv1_fused(rows, ds, save):
+@pytest.mark.parametrize("rows,ds,save,C2", [(4 * 56 * 56, False, 0, 64), (128 * 37 + 5, True, 0, 64), (3 * 56 * 56 + 17, False, 2, 64), (1000, True, 1, 64),
+                                             (37, False, 2, 64), (4 * 56 * 56, False, 0, 128), (128 * 37 + 5, False, 1, 128), (3 * 56 * 56 + 17, False, 2, 128),
+                                             (37, False, 0, 128)])
+def test_conv_expand_join_next_block_conv1_fused(rows, ds, save, C2):
     """vince_conv_expand_join_next (csrc/conv_xjoin.hip, NEXT): the join of a layer1 bottleneck + the following block's conv1
-    (resnet.py:117: 1x1, 256 -> 64) on the block output while it is in LDS.  Everything the join alone writes is unchanged, bit for
+    (resnet.py:117: 1x1, 256 -> 64; or layer2's first block behind layer1's last, 256 -> 128) on the block output while it is in LDS.  Everything the join alone writes is unchanged, bit for
     bit; y_next equals vince_conv_igemm's output for that layer on the stored block output, bit for bit (same MFMA steps in the same
     order); its BatchNorm statistics equal the sums of the stored values; ragged row counts, the affine identity, all three save modes."""
     ops = _ops()
-    K, Co, C2 = 64, 256, 64
+    K, Co = 64, 256
     x = rnd(rows, K, seed=1).clamp_(min=0)
     w = rnd(Co, K, seed=2) * (2.0 / Co) ** 0.5
     w2 = rnd(C2, Co, seed=8) * (2.0 / C2) ** 0.5

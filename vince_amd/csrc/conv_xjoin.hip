@@ -60,15 +60,17 @@ struct XjParams {
     int ptiles, cgroups, relu, replicas;
 };
 
-constexpr int XJ_N2 = 64;           // NEXT mode: output channels of the fused second convolution (layer1's conv1: 256 -> 64)
-constexpr int XJ_K2 = 256;          // ... and its reduction length = this launch's Co
+constexpr int XJ_K2 = 256;          // NEXT mode: reduction length of the fused second convolution = this launch's Co
 
-template <int K, int STAGES, bool NEXT = false>
+// NEXT = output channels of the fused second convolution: 0 (none), 64 (layer1's conv1: 256 -> 64) or 128 (layer2.0's conv1: 256 -> 128)
+template <int K, int STAGES, int NEXT = 0>
 struct XjSmem {
     static constexpr int NKT = K / 32;                      // 64-byte K blocks per row
     static constexpr int WB = NKT * XJ_CG * 64;             // resident weights
     static constexpr int XB = NKT * XJ_PX * 64;             // one input tile
-    static constexpr int TAB = 4 * XJ_CG * 4;               // scale, shift, id_scale, id_shift of this channel group
+    // scale, shift, id_scale, id_shift of this channel group.  NEXT = 128 has no room for it (32 KB conv3 weights + 2 x 16 KB ring + 32 KB
+    // stripes + 64 KB of next-conv weights = the 160 KB of a CU exactly): that instantiation reads scale / shift from memory.
+    static constexpr int TAB = NEXT == 128 ? 0 : 4 * XJ_CG * 4;
     // per-consumer transposition buffer for the stores: 32 pixels x CHW channels.  A 16-byte store per lane with lane = pixel
     // reaches memory as 32-byte pieces of 32 different rows, and partial-line WRITES are what this chip's L2 charges for
     // (measured: ~18 us per million 32-byte write requests, reads nearly free); through the buffer 8 (4) consecutive lanes write
@@ -81,8 +83,9 @@ struct XjSmem {
     // from there as before, and two of them then read whole rows as the MFMA operand of the second convolution.  Same 32 KB.
     static constexpr int ABUF = 32 * XJ_K2 * 2;
     static constexpr int OFF_W2 = OFF_T + XJ_CONSUMERS * TBUF;
-    static constexpr int BYTES = OFF_W2 + (NEXT ? XJ_N2 * XJ_K2 * 2 : 0);
+    static constexpr int BYTES = OFF_W2 + NEXT * XJ_K2 * 2;
     static_assert(!NEXT || (K == 64 && 2 * ABUF == XJ_CONSUMERS * TBUF), "NEXT: K = 64 only");
+    static_assert(BYTES <= 163840, "LDS");
 };
 
 // PLAIN: the same streaming structure for an expand convolution on its own (resnet.py:123 without the join: grad-enabled
@@ -103,10 +106,13 @@ struct XjSmem {
 // launch, so y2 is BIT-IDENTICAL to it), store y2 as 64-byte row pieces straight from the accumulators (lane = channel) and keep
 // that channel's (sum, sum of squares) in two registers for the whole launch.  Four barriers per tile instead of one (the loader
 // counts along): stripes of unit 0 complete / read / stripes of unit 1 complete / (next tile's) read.
-template <int K, int STAGES, bool ID_AFFINE, int SAVE, bool PLAIN = false, bool DGRAD = false, bool NEXT = false>
+// NEXT = 128 (the layer1 -> layer2 transition, 256 -> 128): all four consumers of a half multiply (one 32-channel tile each); two ring stages.
+template <int K, int STAGES, bool ID_AFFINE, int SAVE, bool PLAIN = false, bool DGRAD = false, int NEXT = 0>
 __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p) {
     using S = XjSmem<K, STAGES, NEXT>;
     static_assert(!NEXT || (!PLAIN && !DGRAD), "NEXT rides on the join");
+    static_assert(NEXT != 128 || !ID_AFFINE, "NEXT = 128 keeps no constant table");
+    constexpr bool TABLE = S::TAB != 0;
     constexpr int NKT = S::NKT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[S::BYTES];
     unsigned char* const wsm = smem;
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         if constexpr (NEXT) {
             // w2 rows of 512 bytes; one DMA instruction = 2 rows; lane -> (row, physical slot), logical chunk = slot ^ (row & 15)
             const v4i_t rsrc_w2 = make_rsrc(p.w2, p.w2_bytes);
-            for (int pc = wave; pc < XJ_N2 / 2; pc += XJ_CONSUMERS + 1) {
+            for (int pc = wave; pc < NEXT / 2; pc += XJ_CONSUMERS + 1) {
                 const int r = pc * 2 + (lane >> 5), slot = lane & 31;
                 const uint32_t off = (uint32_t)(r * XJ_K2 + ((slot ^ (r & 15)) * 8)) * 2u;
                 lds_dma16(__builtin_amdgcn_readfirstlane(smem_base + S::OFF_W2 + pc * 1024), off, rsrc_w2);
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             tab[i] = ok ? p.br_mean[c] : 0.f;
             tab[XJ_CG + i] = ok ? p.br_invstd[c] : 0.f;
         }
-        for (int i = tid; !PLAIN && !DGRAD && i < XJ_CG; i += XJ_THREADS) {
+        for (int i = tid; TABLE && !PLAIN && !DGRAD && i < XJ_CG; i += XJ_THREADS) {
             const int c = c0 + i;
             const bool ok = (uint32_t)c < p.Co;
             tab[i] = ok ? p.out_scale[c] : 0.f;
@@ -419,7 +425,14 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                 Chunk<bf16_t>::unpack(ids[j][gp], idf);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const float4 a = *(const float4*)(tab + tb + 4 * h), b = *(const float4*)(tab + XJ_CG + tb + 4 * h);
+                    float4 a, b;
+                    if constexpr (TABLE) {
+                        a = *(const float4*)(tab + tb + 4 * h);
+                        b = *(const float4*)(tab + XJ_CG + tb + 4 * h);
+                    } else {                                // (one channel group, Co = 256: every channel of the table exists)
+                        a = *(const float4*)(p.out_scale + c0 + tb + 4 * h);
+                        b = *(const float4*)(p.out_shift + c0 + tb + 4 * h);
+                    }
                     float4 c = make_float4(1.f, 1.f, 1.f, 1.f), d = make_float4(0.f, 0.f, 0.f, 0.f);
                     if constexpr (ID_AFFINE) {
                         c = *(const float4*)(tab + 2 * XJ_CG + tb + 4 * h);
@@ -452,12 +465,14 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             }
         }
     };
-    // NEXT: the second convolution of unit (t, i) for this pixel half, channel tile (wc & 1) -- run by the consumers with (wc >> 1) == i
+    // NEXT: the second convolution of unit (t, i) for this pixel half, channel tile c1t -- NEXT = 64: tile (wc & 1), run by the consumers
+    // with (wc >> 1) == i; NEXT = 128: tile wc, every consumer
+    const int c1t = NEXT == 128 ? wc : (wc & 1);
     float s2 = 0.f, q2 = 0.f;                               // statistics of channel (wc & 1) * 32 + (lane & 31), this lane's pixel rows
     auto gemm2 = [&](int t, int i) {
         const int sz = lane & 15;                           // (row & 15) of both operands' rows: lane & 31 within a 32-row tile
         const unsigned char* const arow = tbuf + (lane & 31) * (XJ_K2 * 2);
-        const unsigned char* const brow = smem + S::OFF_W2 + ((wc & 1) * 32 + (lane & 31)) * (XJ_K2 * 2);
+        const unsigned char* const brow = smem + S::OFF_W2 + (c1t * 32 + (lane & 31)) * (XJ_K2 * 2);
         f32x16_t c2;
 #pragma unroll
         for (int e = 0; e < 16; ++e) c2[e] = 0.f;
@@ -472,9 +487,9 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         }
         // C[pixel][channel]: lane = channel column, register r = pixel row (r & 3) + 8 (r >> 2) + 4 khalf: 32 lanes store 64 consecutive bytes
         const uint32_t pix0 = (uint32_t)(first + t * step) * XJ_PX + (uint32_t)(wp * 64 + i * 32);
-        bf16_t* __restrict__ y2 = (bf16_t*)p.y2 + (size_t)((wc & 1) * 32 + (lane & 31));
+        bf16_t* __restrict__ y2 = (bf16_t*)p.y2 + (size_t)(c1t * 32 + (lane & 31));
         if (p.bias2) {                                      // (uniform) the implicit-GEMM epilogue's order: round, add the bias, ReLU, round
-            const float b2 = p.bias2[(wc & 1) * 32 + (lane & 31)];
+            const float b2 = p.bias2[c1t * 32 + (lane & 31)];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const uint32_t u0 = pack_bf16x2(c2[r], c2[r + 1]);
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
                 const uint32_t pix = pix0 + (uint32_t)(((r + h) & 3) + 8 * ((r + h) >> 2) + 4 * khalf);
                 if (pix < p.rows) {
                     const uint32_t b16 = h ? (u >> 16) : (u & 0xffffu);
-                    y2[(size_t)pix * XJ_N2] = (bf16_t)b16;
+                    y2[(size_t)pix * NEXT] = (bf16_t)b16;
                     const float f = __uint_as_float(b16 << 16);
                     s2 += f;
                     q2 += f * f;
@@ -516,13 +531,13 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             if constexpr (NEXT) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();               // every stripe of unit 0 is in the shared buffers
-                if ((wc >> 1) == 0) gemm2(t, 0);
+                if (NEXT == 128 || (wc >> 1) == 0) gemm2(t, 0);
             }
             run_unit(oB, t, 1);
             if constexpr (NEXT) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();               // ... of unit 1 (B(t + 1) keeps the next tile's stripes behind these reads)
-                if ((wc >> 1) == 1) gemm2(t, 1);
+                if (NEXT == 128 || (wc >> 1) == 1) gemm2(t, 1);
             }
         }
     }
@@ -531,7 +546,7 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
             s2 += __shfl_xor(s2, 32, 64);
             q2 += __shfl_xor(q2, 32, 64);
             if (lane < 32) {
-                double* dst = p.stats2 + ((size_t)(blockIdx.x % (unsigned)p.replicas2) * XJ_N2 + (size_t)((wc & 1) * 32 + lane)) * 2;
+                double* dst = p.stats2 + ((size_t)(blockIdx.x % (unsigned)p.replicas2) * NEXT + (size_t)(c1t * 32 + lane)) * 2;
                 unsafeAtomicAdd(dst, (double)s2);
                 unsafeAtomicAdd(dst + 1, (double)q2);
             }
@@ -672,15 +687,15 @@ static int expand_dgrad_common(int dtype, const void* dy, const void* wt, int64_
 static int expand_join_common(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                               const float* out_scale, const float* out_shift, const void* identity,
                               const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
-                              int relu, const void* w_next, void* y_next, double* stats_next, int32_t replicas_next, const float* bias_next,
-                              int relu_next, void* stream);
+                              int relu, const void* w_next, int32_t co_next, void* y_next, double* stats_next, int32_t replicas_next,
+                              const float* bias_next, int relu_next, void* stream);
 
 extern "C" int vince_conv_expand_join(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                                       const float* out_scale, const float* out_shift, const void* identity,
                                       const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
                                       int relu, void* stream) {
     return expand_join_common(dtype, x, w, rows, K, Co, out_scale, out_shift, identity, id_scale, id_shift, out, y_raw, mask_out, relu,
-                              nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+                              nullptr, 0, nullptr, nullptr, 0, nullptr, 0, stream);
 }
 
 extern "C" int vince_conv_expand_join_next(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
@@ -689,18 +704,18 @@ extern "C" int vince_conv_expand_join_next(int dtype, const void* x, const void*
                                            int relu, const void* w_next, int32_t Co_next, void* y_next, double* stats_next,
                                            int32_t replicas_next, const float* bias_next, int relu_next, void* stream) {
     VINCE_CHECK_ARG(w_next && y_next, VINCE_E_ARG, "vince_conv_expand_join_next: null pointer");
-    VINCE_CHECK_ARG(K == 64 && Co == XJ_K2 && Co_next == XJ_N2, VINCE_E_UNSUPPORTED,
-                    "vince_conv_expand_join_next: K=%d Co=%d Co_next=%d (64, 256, 64: layer1)", K, Co, Co_next);
+    VINCE_CHECK_ARG(K == 64 && Co == XJ_K2 && (Co_next == 64 || (Co_next == 128 && !id_scale)), VINCE_E_UNSUPPORTED,
+                    "vince_conv_expand_join_next: K=%d Co=%d Co_next=%d (64, 256, 64 or -- plain identity only -- 128: layer1)", K, Co, Co_next);
     VINCE_CHECK_ARG((((uintptr_t)w_next | (uintptr_t)y_next) & 15) == 0, VINCE_E_ALIGN, "vince_conv_expand_join_next: pointers must be 16-byte aligned");
     return expand_join_common(dtype, x, w, rows, K, Co, out_scale, out_shift, identity, id_scale, id_shift, out, y_raw, mask_out, relu,
-                              w_next, y_next, stats_next, replicas_next, bias_next, relu_next, stream);
+                              w_next, Co_next, y_next, stats_next, replicas_next, bias_next, relu_next, stream);
 }
 
 static int expand_join_common(int dtype, const void* x, const void* w, int64_t rows, int32_t K, int32_t Co,
                               const float* out_scale, const float* out_shift, const void* identity,
                               const float* id_scale, const float* id_shift, void* out, void* y_raw, uint8_t* mask_out,
-                              int relu, const void* w_next, void* y_next, double* stats_next, int32_t replicas_next, const float* bias_next,
-                              int relu_next, void* stream) {
+                              int relu, const void* w_next, int32_t co_next, void* y_next, double* stats_next, int32_t replicas_next,
+                              const float* bias_next, int relu_next, void* stream) {
     VINCE_CHECK_ARG(dtype == VINCE_BF16, VINCE_E_DTYPE, "vince_conv_expand_join: bf16 only (fp32 runs vince_conv_igemm's join epilogue)");
     VINCE_CHECK_ARG(x && w && out_scale && out_shift && identity && out && rows > 0, VINCE_E_ARG, "vince_conv_expand_join: null pointer");
     VINCE_CHECK_ARG(K == 64 || K == 128, VINCE_E_UNSUPPORTED, "vince_conv_expand_join: K=%d (64 or 128)", K);
@@ -721,7 +736,7 @@ static int expand_join_common(int dtype, const void* x, const void* w, int64_t r
     p.ptiles = (int)((rows + XJ_PX - 1) / XJ_PX);
     p.cgroups = Co / XJ_CG;
     p.relu = relu;
-    p.w2 = w_next; p.y2 = y_next; p.stats2 = stats_next; p.w2_bytes = XJ_N2 * XJ_K2 * 2; p.bias2 = bias_next; p.relu2 = relu_next;
+    p.w2 = w_next; p.y2 = y_next; p.stats2 = stats_next; p.w2_bytes = (uint32_t)co_next * XJ_K2 * 2; p.bias2 = bias_next; p.relu2 = relu_next;
     p.replicas2 = (replicas_next <= 0 || replicas_next > VINCE_STATS_REPLICAS) ? VINCE_STATS_REPLICAS : replicas_next;
     const int n_cu = xj_num_cu();
     static const int wg_per_cu = VINCE_MEASURE_KNOB("xj_wgs", 1);   // (measurement aid)
@@ -739,14 +754,19 @@ static int expand_join_common(int dtype, const void* x, const void* w, int64_t r
         else { if (id_scale) VINCE_XJ_LAUNCH(KK, SS, true, 0); else VINCE_XJ_LAUNCH(KK, SS, false, 0); }                  \
     } while (0)
 #define VINCE_XJ_LAUNCH_NEXT(AA, SV) \
-    hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, AA, SV, false, false, true>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p)
-    VinceProfScope prof(VINCE_TAG_XJOIN, (double)rows * 2 * (K + Co * (2 + (y_raw ? 1 : 0)) + (w_next ? XJ_N2 : 0)) + (mask_out ? (double)rows * Co / 8 : 0), stream);
-    if (w_next) {
+    hipLaunchKernelGGL((conv_xjoin_kernel<64, 3, AA, SV, false, false, 64>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p)
+#define VINCE_XJ_LAUNCH_NEXT128(SV) \
+    hipLaunchKernelGGL((conv_xjoin_kernel<64, 2, false, SV, false, false, 128>), dim3((unsigned)grid), dim3(XJ_THREADS), 0, (hipStream_t)stream, p)
+    VinceProfScope prof(VINCE_TAG_XJOIN, (double)rows * 2 * (K + Co * (2 + (y_raw ? 1 : 0)) + co_next) + (mask_out ? (double)rows * Co / 8 : 0), stream);
+    if (w_next && co_next == 128) {
+        if (y_raw) VINCE_XJ_LAUNCH_NEXT128(2); else if (mask_out) VINCE_XJ_LAUNCH_NEXT128(1); else VINCE_XJ_LAUNCH_NEXT128(0);
+    } else if (w_next) {
         if (y_raw) { if (id_scale) VINCE_XJ_LAUNCH_NEXT(true, 2); else VINCE_XJ_LAUNCH_NEXT(false, 2); }
         else if (mask_out) { if (id_scale) VINCE_XJ_LAUNCH_NEXT(true, 1); else VINCE_XJ_LAUNCH_NEXT(false, 1); }
         else { if (id_scale) VINCE_XJ_LAUNCH_NEXT(true, 0); else VINCE_XJ_LAUNCH_NEXT(false, 0); }
     } else if (K == 64) VINCE_XJ_PICK(64, 3); else VINCE_XJ_PICK(128, 2);
 #undef VINCE_XJ_LAUNCH_NEXT
+#undef VINCE_XJ_LAUNCH_NEXT128
 #undef VINCE_XJ_PICK
 #undef VINCE_XJ_LAUNCH
     VINCE_CHECK_LAUNCH();

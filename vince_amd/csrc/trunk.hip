@@ -725,6 +725,10 @@ namespace {
 // Folded inference forward: a bottleneck's conv3 + bias + identity + ReLU through the persistent streaming kernel (csrc/conv_xjoin.hip)
 // where it applies -- bf16, K = 64 / 128, Co multiple of 256: layer1 / layer2 -- with bn3's scale as the kernel's out_scale instead of
 // folded into the weights (round 5: 4.4-5.2 TB/s against the implicit-GEMM join epilogue's 3.4).  `xjoin=0`: the epilogue everywhere.
+// `xjoin_next128=0`: the layer1 -> layer2 transition keeps its own conv1 launch (cross-check / A-B switch)
+bool next_env128() {
+    return vince_knob_live("xjoin_next128", 1) != 0;
+}
 bool folded_xjoin_block(const vince_trunk* t, const Blk& b) {
     static const bool on = (vince_knob("xjoin", 1) != 0) && (vince_knob("xjoin_folded", 1) != 0);
     return on && t->sdtype == VINCE_BF16 && t->cf == VINCE_BF16 && b.nconv == 3 && (b.c[2].Ci == 64 || b.c[2].Ci == 128) &&
@@ -896,8 +900,9 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
                                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
         }
         const Blk* nb = bi + 1 < t->blocks.size() ? &t->blocks[bi + 1] : nullptr;
-        if (folded_xjoin_block(t, b) && next_folded && b.c[L].Ci == 64 && b.c[L].Co == 256 && nb && nb->nconv == 3 && !nb->has_ds &&
-            nb->c[0].k == 1 && nb->c[0].stride == 1 && nb->c[0].Ci == 256 && nb->c[0].Co == 64) {
+        if (folded_xjoin_block(t, b) && next_folded && b.c[L].Ci == 64 && b.c[L].Co == 256 && nb && nb->nconv == 3 &&
+            nb->c[0].k == 1 && nb->c[0].stride == 1 && nb->c[0].Ci == 256 &&
+            ((nb->c[0].Co == 64 && !nb->has_ds) || (nb->c[0].Co == 128 && next_env128()))) {
             // ... and the next block's conv1 + bias + ReLU on the block output while it is in LDS
             const ConvL& cv = b.c[L];
             RC(vince_conv_expand_join_next(dtype, in, at((void*)wcache, cv.wk), (int64_t)N * cv.Ho * cv.Wo, cv.Ci, cv.Co,
@@ -1069,8 +1074,10 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             // bf16 at K = 64 / 128: the persistent streaming kernel (csrc/conv_xjoin.hip); otherwise the implicit-GEMM kernel's join
             // epilogue (fp32, or VINCE_XJOIN=0 as a cross-check; no-grad forwards only)
             const Blk* nb = bi + 1 < t->blocks.size() ? &t->blocks[bi + 1] : nullptr;
-            const bool fuse_next = next_env && xj_ok && train_bn && cv.Ci == 64 && cv.Co == 256 && nb && nb->nconv == 3 && !nb->has_ds &&
-                                   nb->c[0].k == 1 && nb->c[0].stride == 1 && nb->c[0].Ci == 256 && nb->c[0].Co == 64;
+            // (256 -> 64: layer1's identity blocks; 256 -> 128: the first block of layer2 behind a layer1 block with a plain identity)
+            const bool fuse_next = next_env && xj_ok && train_bn && cv.Ci == 64 && cv.Co == 256 && nb && nb->nconv == 3 &&
+                                   nb->c[0].k == 1 && nb->c[0].stride == 1 && nb->c[0].Ci == 256 &&
+                                   ((nb->c[0].Co == 64 && !nb->has_ds) || (nb->c[0].Co == 128 && !e.id_scale && next_env128()));
             if (fuse_next) {
                 RC(vince_conv_expand_join_next(c.dtype, at(workspace, in), at((void*)wcache, cv.wk), rows, cv.Ci, cv.Co, e.out_scale, e.bias,
                                                at(workspace, idn), e.id_scale, e.id_shift, at(workspace, out),
