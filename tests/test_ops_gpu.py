@@ -879,6 +879,39 @@ def test_conv_expand_join_next_block_conv1_fused(rows, ds, save, C2):
     assert torch.equal(z, out_a) and torch.equal(y_e, y_d.view(rows, C2))
 
 
+@pytest.mark.parametrize("C2", [64, 128])
+def test_conv_expand_join_next_is_stable_beside_a_busy_stream(C2):
+    """The fused join keeps a pixel half's stripes in a SHARED LDS buffer between four barriers per tile: a missing barrier would show as
+    a run-to-run difference under load.  Twenty repetitions at layer1's size (64 frames) beside a stream that keeps the machine busy:
+    outputs equal the separate launches bit for bit every time, the statistics are bitwise identical run to run
+    (tools/stress_xjoin_next.py: 150 repetitions at 256 frames)."""
+    ops = _ops()
+    rows, K, Co = 64 * 56 * 56, 64, 256
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(rows, K, device=DEV, generator=g).clamp_(min=0).bfloat16()
+    w = (torch.randn(Co, K, device=DEV, generator=g) * 0.1).bfloat16().contiguous()
+    w2 = (torch.randn(C2, Co, device=DEV, generator=g) * 0.1).bfloat16().contiguous()
+    idn = torch.randn(rows, Co, device=DEV, generator=g).bfloat16()
+    sc, sh = torch.rand(Co, device=DEV, generator=g) + 0.5, torch.randn(Co, device=DEV, generator=g) * 0.3
+    out_a = torch.empty(rows, Co, device=DEV).bfloat16()
+    ops.conv_expand_join(x, w, sc, sh, idn, out=out_a)
+    y_a = torch.empty(1, rows, 1, C2, device=DEV).bfloat16()
+    ops.conv_igemm(ops.conv_desc(1, rows, 1, Co, C2, 1, 1, 0), out_a.view(1, rows, 1, Co), w2.view(C2, 1, Co), y_a)
+    side, junk, first = torch.cuda.Stream(), torch.randn(32 * 1024 * 1024, device=DEV), None
+    for it in range(20):
+        with torch.cuda.stream(side):
+            junk.mul_(1.0001)
+        out_b = torch.empty(rows, Co, device=DEV).bfloat16()
+        y_b = torch.empty(rows, C2, device=DEV).bfloat16()
+        st_b = torch.zeros(ops.STATS_REPLICAS, C2, 2, device=DEV, dtype=torch.float64)
+        mask = torch.zeros(rows * Co // 8, device=DEV, dtype=torch.uint8) if it % 2 else None
+        ops.conv_expand_join_next(x, w, sc, sh, idn, w2, y_b, out=out_b, stats_next=st_b, mask_out=mask)
+        assert torch.equal(out_b, out_a) and torch.equal(y_b, y_a.view(rows, C2)), it
+        first = st_b.sum(0) if first is None else first
+        assert torch.equal(st_b.sum(0), first), it
+    torch.cuda.synchronize()
+
+
 def test_similarity_cross_entropy_unequal_positives_use_float():
     """utils/loss_util.py:25-36,46-48 on the HIP row kernel, against the reference's own numbers (tests/golden/g2u_loss_unequal.npz)
     incl. the process-wide cached decision (App. D item 2) and the failure the reference has when an equal-count mask came
