@@ -134,7 +134,9 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     // cross-check of the parity tests), VINCE_M8_MIN_K moves the threshold.
     static const int m8_on = vince_knob("m8", 1);
     static const int m8_min_k = vince_knob("m8_min_k", 1024);
-    static const int m8_min_tiles = vince_knob("m8_min_tiles", 128);
+    // (96 since late round 5: layer4's 3x3 and 2048 -> 512 -- 98 tiles of 256 x 256 -- moved here from the 128-pixel tiles; with
+    // big_min_k 512 / s3_min_k 1024 in conv_igemm_impl.h -0.2 ms per step in two same-box sweeps, profiles/r05_knob_sweep.txt)
+    static const int m8_min_tiles = vince_knob("m8_min_tiles", 96);
     rc = VINCE_M8_NOT_ELIGIBLE;
     if (m8_on && !e.in2 && dtype == VINCE_BF16 && d.Co % 256 == 0 && T * d.Ci >= m8_min_k &&
         (long)((p.M + 255) / 256) * (d.Co / 256) >= m8_min_tiles)

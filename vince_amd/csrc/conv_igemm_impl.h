@@ -541,7 +541,9 @@ int launch(ConvParams& p, hipStream_t stream) {
     const int k_elems = p.total_chunks * (16 / (int)sizeof(T));
     // VINCE_DLDS_CFG=4 forces the 128-pixel tile everywhere (measurement aid); the default (5) adds the 256-pixel tile
     static int dlds_cfg = VINCE_MEASURE_KNOB("dlds_cfg", 5);
-    static int big_min_k = vince_knob("big_min_k", 1024);
+    // (16-bit tensors: 1024 until late round 5, profiles/r05_knob_sweep.txt; the fp32 trunk -- the parity mode -- keeps the arrangement its
+    // full-size fixtures were measured with)
+    static int big_min_k = vince_knob("big_min_k", sizeof(T) == 2 ? 512 : 1024);
     static int big_min_tiles = vince_knob("big_min_tiles", 256);
     static long narrow256 = vince_knob("narrow256_min_tiles", 2048);   // 0 = off
     // rotated main loop (fragment reads one MFMA phase ahead, across the tile barrier): bit 0 the 256x128 tile, 1 the 256x64
@@ -626,7 +628,7 @@ int launch(ConvParams& p, hipStream_t stream) {
                 // reductions at least VINCE_S3_MIN_K long take a 3-stage ring (two K tiles in flight, 3 workgroups per CU) instead
                 // of 2 stages / 4 workgroups
                 // default 2048: layer4's 3x3 (K = 4608) 92.6 -> 85 us, 2048 -> 512 50 -> 44 us; shorter reductions lose
-                static const int s3_min_k = vince_knob("s3_min_k", 2048);
+                static const int s3_min_k = vince_knob("s3_min_k", sizeof(T) == 2 ? 1024 : 2048);    // (16-bit: 2048 until late round 5, measured layer by layer alone; 1024 is better inside the step)
                 if (s3_min_k > 0 && k_elems >= s3_min_k) {
                     if (rot & 8)
                         hipLaunchKernelGGL((conv_igemm_dlds_kernel<T, CT, 4, 3, 3, PT, MODE, true>), dim3(p.ptiles * p.ctiles), dim3(256), 0, stream, p);
