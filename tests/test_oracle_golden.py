@@ -286,3 +286,30 @@ def test_g12_fixture_is_the_centred_head_state_at_config3_size():
     np.testing.assert_allclose(pair, float(g["pairwise_cosine"]), atol=1e-5)
     assert pair < 0.3 and 0.5 < float(g["m_nce_accuracy_mean"]) <= 1.0
     assert len(g["grad_names"]) == 163 == len(g["grad_checksums"])
+
+
+def test_g14_config2_full_size_iteration():
+    """G14 (oracle/make_golden_g14.py): ONE iteration of the imported reference at BASELINE config 2's OWN size -- ResNet-18 (BasicBlock
+    trunk, models/building_blocks/resnet.py:53-92,269), 224 x 224, batch 256, K=4096, D=64, T=0.07, fp32 -- from the centred-head state.
+    Cheap enough (half a minute of CPU) for the oracle to replay it here; the GPU tests hold the HIP path against the same fixture."""
+    g = load("g14_config2.npz")
+    c = vo.G14
+    assert g["embeddings"].shape == (c["B"], c["embed"]) and g["shift"].shape == (c["embed"],) and len(g["grad_names"]) == 64
+    assert float(g["pairwise_cosine"]) < 0.3
+    tr = vo.OracleTrainer(c["arch"], c["embed"], c["K"], c["B"], c["T"], c["lr"], seed=c["seed"], queue_init=vo.g14_queue().numpy())
+    with torch.no_grad():
+        tr.q["embedding.2.bias"] += torch.from_numpy(g["shift"])
+        tr.k["embedding.2.bias"] += torch.from_numpy(g["shift"])
+    r = tr.step(*vo.g14_inputs())
+    np.testing.assert_allclose(r["nce_loss"], float(g["loss"]), rtol=1e-4)
+    np.testing.assert_allclose([r[k] for k in ("nce_accuracy_mean", "cosine_sim", "cosine_sim_neg_max")],
+                               [float(g["m_" + k]) for k in ("nce_accuracy_mean", "cosine_sim", "cosine_sim_neg_max")], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(r["embeddings"].numpy(), g["embeddings"], atol=2e-4)
+    np.testing.assert_allclose(r["queue_embeddings"].numpy(), g["queue_embeddings"], atol=2e-4)
+    names = list(g["grad_names"])
+    for n in ("embedding.2.weight", "embedding.0.bias", "feature_extractor.model.layer4.1.conv2.weight",
+              "feature_extractor.model.layer2.0.downsample.0.weight", "feature_extractor.model.conv1.weight"):
+        want = g["grad_checksums"][names.index(n)]
+        got = vo.tensor_checksum(r["grads"][n])
+        assert abs(got[2] - want[2]) <= 2e-2 * abs(want[2]), (n, got, want)     # sum |g|
+    np.testing.assert_allclose(r["grads"]["embedding.2.weight"][:16].numpy(), g["grad_embedding.2.weight"], rtol=5e-2, atol=1e-5)
