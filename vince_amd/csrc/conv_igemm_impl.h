@@ -438,8 +438,13 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
                     wl[j] = *(const uint4*)(ws + j * 32 * KB + slot1);
                 }
 #pragma unroll
-                for (int i = 0; i < PI; ++i)
+                for (int i = 0; i < PI; ++i) {
+                    if (IG_ABL(256)) {   // (measurement build: the activation operand taken as stored half pairs -- timing only)
+                        xh[i] = *(const uint4*)(xs + i * 32 * KB + slot0);
+                        xl[i] = *(const uint4*)(xs + i * 32 * KB + slot1);
+                    } else
                     x3_split<T, false>(*(const uint4*)(xs + i * 32 * KB + slot0), *(const uint4*)(xs + i * 32 * KB + slot1), xh[i], xl[i]);
+                }
                 mfma_prio<1>();
 #pragma unroll
                 for (int j = 0; j < CJ; ++j)
