@@ -51,7 +51,7 @@ const char* vince_last_error(void);
 /* Bumped whenever an exported signature, a struct layout or a dtype code changes.  vince_abi_version() returns the value the library
  * was BUILT with; a binding compares it at load (vince_amd/_lib.py: a stale .so behind VINCE_HIP_LIB would otherwise be called with
  * shifted arguments). */
-#define VINCE_ABI_VERSION 10
+#define VINCE_ABI_VERSION 11
 int vince_abi_version(void);
 
 /* Measurement aid (bench.py): while enabled, every conv_igemm / conv_wgrad launch is bracketed by a hipEvent pair on
@@ -504,14 +504,19 @@ size_t vince_infonce_workspace_bytes(const vince_infonce_desc* d);
 /* outputs: pos[B][P] raw cosines of the positives (P = frames), row_max[B], neg_sum[B] (sum of exp(s - row_max)
  * over negatives), dists[B][P], softmax_weights[B][P], scalars[8] = {loss mean, softmax_weight mean,
  * accuracy mean, mean positive cosine, mean row-max negative cosine, 0,0,0}. */
-/* logits: optional float[B][Bk + K] -- the raw cosines, in-batch columns first (what the reference materialises as
+/* PRECONDITION: q, inb and queue hold UNIT vectors (the reference L2-normalises both sides, vince_model.py:180): the logits are formed
+ * from IEEE-half hi / lo halves of the operands scaled by 2^8, so an entry with |x| >= 255.9 turns its row into NaN by design (loud, not
+ * saturated) -- this is not a general-purpose similarity kernel.
+ * logits: optional float[B][Bk + K] -- the raw cosines, in-batch columns first (what the reference materialises as
  * `vince_similarities`, vince_model.py:207-242); a training forward stores them so that vince_infonce_bwd reads them back instead of
  * recomputing them.  NULL: not written. */
 int vince_infonce_fwd(const vince_infonce_desc* d, const float* q, const float* inb, const float* queue,
                       float* pos, float* row_max, float* neg_sum, float* dists, float* softmax_weights,
                       float* scalars, float* logits, void* workspace, void* stream);
 /* dq[B][D] += dloss/dq (atomic fp32; zero it first).  grad_scale: device pointer to the upstream scalar gradient.
- * logits: the matrix vince_infonce_fwd stored for the same operands, or NULL (recomputed with exact fp32 products).
+ * logits: the matrix vince_infonce_fwd stored for the same operands, or NULL (recomputed with exact fp32 products: they differ from the
+ * forward's split-half logits by fp32 rounding, ~2e-7 per logit, while row_max / neg_sum are the forward's -- the training path always
+ * passes the stored matrix, so its gradients are those of the logits the loss was computed from).
  * wmat: optional float[B][Bk] receiving dloss/dlogit for the in-batch columns (self-similarity column-side grad). */
 int vince_infonce_bwd(const vince_infonce_desc* d, const float* q, const float* inb, const float* queue,
                       const float* pos, const float* row_max, const float* neg_sum, const float* grad_scale,
@@ -609,8 +614,15 @@ int vince_trunk_set_bucket_callback(vince_trunk_t t, void (*cb)(int32_t, void*),
  * EXCEPT conv1's (resnet.py:170; the last launch of backward, ~200 us alone on the machine at ResNet-50 / B = 256) and records the
  * event behind that launch instead: the gradient of params[0] is final only after the event; everything else as before.  The caller
  * steps every other parameter while the stem's weight gradient runs (optim.FlatSGD.step(defer_stem=True)).  NULL (default): the
- * stream waits for all of them. */
+ * stream waits for all of them.
+ * Workspace lifetime: that launch keeps READING the stem input, a gradient ring slot and the scratch area of `workspace` until the event
+ * has passed.  The next vince_trunk_forward / _forward_folded / _backward on this handle makes its own stream wait for the event before it
+ * touches the workspace; a caller that writes the staged input itself (vince_trunk_input_ptr) or frees / reuses the workspace for anything
+ * else must wait for the event first.  Replacing or clearing the event while such a launch is pending drains it on the host. */
 int vince_trunk_set_stem_event(vince_trunk_t t, void* event);
+/* Makes `stream` wait for a deferred stem weight gradient still in flight on this handle (no-op otherwise): for callers that write the
+ * staged input themselves.  (ABI 11) */
+int vince_trunk_stem_join(vince_trunk_t t, void* stream);
 /* grads: float pointers parallel to params (accumulated into; zero them first).  dpooled: float[N][C].
  * Gradient buckets for data parallelism: after the backward of residual block event_blocks[e] (blocks are numbered in
  * forward order; backward visits them last to first) has been enqueued, hipEvent_t events[e] is recorded on `stream`;

@@ -333,20 +333,28 @@ def test_full_size_backward_serialised_vs_overlapped_streams(tmp_path, dtype):
     # "bf16-nogram" keeps the old leg (gram_join=0: no Gram route, no algebra) as the cross-check.
     common = "gram_join=0," if dtype == "bf16-nogram" else ""
     dtype = "bf16" if dtype == "bf16-nogram" else dtype
+    # bf16: EVERY weight gradient of both runs through the fixed-order reduction (wgrad_det=2: per-split slabs summed in split order,
+    # vince_conv_wgrad_det) -- the order of the fp32 atomics decided bf16 rounding flips downstream and with them 8e-3 ... 2e-2 of
+    # run-to-run noise on the worst tensor, the same between two runs of ONE arrangement; with it gone the two arrangements differ by
+    # the stage-entry add order alone, and the bound is back where a race that moves one tensor by 3 % fails (VERDICT r5 / ADVICE r5)
+    if dtype == "bf16":
+        common += "wgrad_det=2,"
     a = _dump(tmp_path, "ser", dtype, dict(VINCE_KNOBS=common + "wgrad_stream=0,ds_stream=0", VINCE_OVERLAP_KEY="0"), sampled)
     b = _dump(tmp_path, "ovl", dtype, {"VINCE_KNOBS": common} if common else {}, sampled)
-    # (fp32 atomics of the weight-gradient kernel also feed the Gram statistics: run-to-run 1e-7 on bn3's constants, which a
-    # bf16 trunk turns into rounding flips)
     assert float(a["loss"]) == pytest.approx(float(b["loss"]), rel=1e-6)
     np.testing.assert_allclose(a["embeddings"], b["embeddings"], rtol=0, atol=1e-6)
     assert list(a["grad_names"]) == list(b["grad_names"])
-    worst = float(np.abs(a["grad_checksums"][:, 2] / b["grad_checksums"][:, 2] - 1).max())
-    print("serialised vs overlapped (%s): worst sum|g| ratio error %.2e" % (dtype, worst))
-    # bf16: nine runs on MI355X measured 8e-3 ... 1.8e-2 for the worst tensor (run-to-run: the order of the fp32 atomics decides bf16 rounding
-    # flips, the same noise between two runs of ONE arrangement), so 2e-2 failed one run in ten; a race moves a tensor by O(1)
-    np.testing.assert_allclose(a["grad_checksums"][:, 2], b["grad_checksums"][:, 2], rtol=2e-4 if dtype != "bf16" else 4e-2)
+    err = np.abs(a["grad_checksums"][:, 2] / b["grad_checksums"][:, 2] - 1)
+    worst, median = float(err.max()), float(np.median(err))
+    rows = {n: _rel(a["grad_" + n], b["grad_" + n]) for n in sampled}
+    print("serialised vs overlapped (%s): sum|g| ratio error worst %.2e (%s) median %.2e; sampled tensors worst %.2e"
+          % (dtype, worst, a["grad_names"][int(err.argmax())], median, max(rows.values())))
+    # a race moves a tensor by O(1)
+    np.testing.assert_allclose(a["grad_checksums"][:, 2], b["grad_checksums"][:, 2], rtol=2e-4 if dtype != "bf16" else 2e-2)
+    if dtype == "bf16":
+        assert median < 5e-3, median
     for n in sampled:
-        assert _rel(a["grad_" + n], b["grad_" + n]) < (2e-3 if dtype != "bf16" else 5e-2), n
+        assert rows[n] < (2e-3 if dtype != "bf16" else 5e-2), n
 
 
 # G12: config 3 at its real size from the CENTRED-HEAD state (oracle/make_golden_g12.py): the 256 embeddings are spread over the sphere

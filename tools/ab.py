@@ -1,6 +1,7 @@
 """Same-box A/B of the training step: runs bench.py --no-extras for each configuration in turn, REPS rounds (A B C A B C ...), and prints
 every ms_per_step with the median per configuration.  A configuration is a string of NAME=VALUE environment settings; the word BASE
 (alone or first) runs the tree under ab_base/ (a checkout of an earlier commit with its own built library) instead.
+AB_ARGS (environment): extra bench.py arguments for every configuration, e.g. AB_ARGS="--dtype x3".
 Usage: python tools/ab.py REPS STEPS "CONFIG A" "CONFIG B" ..."""
 import json
 import os
@@ -22,7 +23,7 @@ for r in range(reps):
         for w in words:
             k, v = w.split("=", 1)
             env[k] = v
-        out = subprocess.run([sys.executable, "bench.py", "--steps", str(steps), "--warmup", "8", "--no-extras"], cwd=cwd, env=env,
+        out = subprocess.run([sys.executable, "bench.py", "--steps", str(steps), "--warmup", "8", "--no-extras"] + os.environ.get("AB_ARGS", "").split(), cwd=cwd, env=env,
                              capture_output=True, text=True, timeout=600)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not lines:

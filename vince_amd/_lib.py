@@ -159,6 +159,7 @@ PROTOTYPES = {
                                            c_void_p]),
     "vince_trunk_set_bucket_callback": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vince_trunk_set_stem_event": (c_int, [c_void_p, c_void_p]),
+    "vince_trunk_stem_join": (c_int, [c_void_p, c_void_p]),
     "vince_trunk_prepare_weights_part": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_trunk_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                      c_void_p]),
@@ -169,7 +170,7 @@ _LIB = None
 
 
 # include/vince_hip.h VINCE_ABI_VERSION (tests/test_abi_cpu.py holds the two together)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 def lib():

@@ -107,6 +107,9 @@ struct vince_trunk {
     // vince_trunk_set_stem_event: the caller's stream leaves backward WITHOUT waiting for the stem's weight gradient (the last launch of
     // the step, alone on the machine); this event is recorded behind it instead
     hipEvent_t stem_event = nullptr;
+    // ... and while that launch may still be running it READS the stem input (off_x0), its dY ring slot and the weight-gradient scratch
+    // of the workspace: every entry point that rewrites the workspace makes its stream wait for stem_event first (stem_join)
+    bool stem_inflight = false;
 };
 
 namespace {
@@ -439,8 +442,25 @@ extern "C" int vince_trunk_set_bucket_callback(vince_trunk_t t, void (*cb)(int32
     t->bucket_cb_user = user;
     return VINCE_OK;
 }
+// Deferred stem join, the engine's own protection: the stem's weight gradient of the previous backward may still be reading the
+// workspace (the stem input, a dY slot, the scratch).  Whoever rewrites the workspace next waits for it on ITS stream -- a no-op when the
+// caller has already joined (FlatSGD / VinceQueueModel wait for the same event), so a C-ABI caller that re-runs forward or backward right
+// after a deferred backward cannot race with it.
+static int stem_join(vince_trunk* t, void* stream) {
+    if (t->stem_inflight && t->stem_event) VINCE_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, t->stem_event, 0));
+    t->stem_inflight = false;
+    return VINCE_OK;
+}
+
+extern "C" int vince_trunk_stem_join(vince_trunk_t t, void* stream) {
+    VINCE_CHECK_ARG(t, VINCE_E_ARG, "vince_trunk_stem_join: null handle");
+    return stem_join(t, stream);
+}
 extern "C" int vince_trunk_set_stem_event(vince_trunk_t t, void* event) {
     VINCE_CHECK_ARG(t, VINCE_E_ARG, "vince_trunk_set_stem_event: null handle");
+    if (t->stem_inflight && t->stem_event && (hipEvent_t)event != t->stem_event)
+        VINCE_CHECK_HIP(hipEventSynchronize(t->stem_event));     // (the event is being replaced or cleared under a running launch: drain it)
+    if ((hipEvent_t)event != t->stem_event) t->stem_inflight = false;
     t->stem_event = (hipEvent_t)event;
     return VINCE_OK;
 }
@@ -729,11 +749,19 @@ namespace {
 bool next_env128() {
     return vince_knob_live("xjoin_next128", 1) != 0;
 }
+// Inference cache: which blocks keep conv3's weights UNFOLDED (bn3's scale goes in as the join's out_scale).  A property of the
+// ARCHITECTURE and the dtype only -- one inference cache serves every trunk of a model (VinceModel._wcache_folded), whatever its batch --
+// so it must not depend on cfg.N; whether the streaming kernel can take the launch (31-bit descriptor offsets) is asked separately and a
+// launch past the limit runs the implicit-GEMM join epilogue with the same out_scale.
 bool folded_xjoin_block(const vince_trunk* t, const Blk& b) {
     static const bool on = (vince_knob("xjoin", 1) != 0) && (vince_knob("xjoin_folded", 1) != 0);
     return on && t->sdtype == VINCE_BF16 && t->cf == VINCE_BF16 && b.nconv == 3 && (b.c[2].Ci == 64 || b.c[2].Ci == 128) &&
-           b.c[2].Co % 256 == 0 && b.c[2].k == 1 && b.c[2].stride == 1 &&
-           (unsigned long long)t->cfg.N * b.c[2].Hi * b.c[2].Wi * b.c[2].Ci * 2 < 0x7ff00000ull;
+           b.c[2].Co % 256 == 0 && b.c[2].k == 1 && b.c[2].stride == 1;
+}
+bool folded_xjoin_fits(const vince_trunk* t, const Blk& b) {
+    // (`xjoin_folded_max_bytes`: cross-check switch of the tests -- the fallback is otherwise reached only by batches of thousands of frames)
+    const unsigned long long limit = (unsigned long long)vince_knob_live("xjoin_folded_max_bytes", 0x7ff00000L);
+    return (unsigned long long)t->cfg.N * b.c[2].Hi * b.c[2].Wi * b.c[2].Ci * 2 < limit;
 }
 
 // Batched weight prep shared by the training cache (scale == nullptr) and the BatchNorm-folded inference cache
@@ -834,6 +862,7 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
     VINCE_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, VINCE_E_ALIGN,
                     "vince_trunk_forward_folded: workspace / weight cache must be 256-byte aligned");
     const int N = t->cfg.N, dtype = t->sdtype;
+    RC(stem_join(t, stream));
     const float* bias = fold_bias(t, (void*)wcache);
     const float* ones = fold_ones(t, (void*)wcache);
     if (!input) {   // staged input, see vince_trunk_forward
@@ -900,7 +929,7 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
                                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
         }
         const Blk* nb = bi + 1 < t->blocks.size() ? &t->blocks[bi + 1] : nullptr;
-        if (folded_xjoin_block(t, b) && next_folded && b.c[L].Ci == 64 && b.c[L].Co == 256 && nb && nb->nconv == 3 &&
+        if (folded_xjoin_block(t, b) && folded_xjoin_fits(t, b) && next_folded && b.c[L].Ci == 64 && b.c[L].Co == 256 && nb && nb->nconv == 3 &&
             nb->c[0].k == 1 && nb->c[0].stride == 1 && nb->c[0].Ci == 256 &&
             ((nb->c[0].Co == 64 && !nb->has_ds) || (nb->c[0].Co == 128 && next_env128()))) {
             // ... and the next block's conv1 + bias + ReLU on the block output while it is in LDS
@@ -910,11 +939,21 @@ extern "C" int vince_trunk_forward_folded(vince_trunk_t t, const void* wcache, c
                                            nullptr, nullptr, 1, at((void*)wcache, nb->c[0].wk), nb->c[0].Co, at(workspace, nb->a[0]), nullptr, 0,
                                            bias + nb->b[0].consts / 4, 1, stream));
             conv1_done = true;
-        } else if (folded_xjoin_block(t, b)) {
+        } else if (folded_xjoin_block(t, b) && folded_xjoin_fits(t, b)) {
             const ConvL& cv = b.c[L];
             RC(vince_conv_expand_join(dtype, in, at((void*)wcache, cv.wk), (int64_t)N * cv.Ho * cv.Wo, cv.Ci, cv.Co,
                                       fold_scale(t, (void*)wcache) + b.b[L].consts / 4, bias + b.b[L].consts / 4, out, nullptr, nullptr, out,
                                       nullptr, nullptr, 1, stream));
+        } else if (folded_xjoin_block(t, b)) {
+            // the cache holds conv3 UNFOLDED for this block, the tensor is past the streaming kernel's 31-bit offsets: the implicit-GEMM
+            // join epilogue with bn3's scale as out_scale (out = relu(conv * scale + bias + out))
+            vince_conv_epi e;
+            memset(&e, 0, sizeof(e));
+            e.flags = VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU;
+            e.out_scale = fold_scale(t, (void*)wcache) + b.b[L].consts / 4;
+            e.bias = bias + b.b[L].consts / 4;
+            const vince_conv_desc d3 = fwd_desc(t, b.c[L]);
+            RC(vince_conv_igemm(&d3, t->cf, in, at((void*)wcache, b.c[L].wk), out, &e, stream));
         } else {
             RC(conv(fwd_desc(t, b.c[L]), b.c[L], b.b[L], in, out, VINCE_EPI_ACCUMULATE | VINCE_EPI_RELU));
         }
@@ -934,6 +973,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
                     "vince_trunk_forward: workspace / weight cache must be 256-byte aligned");
     Ctx c{t, params, wcache, workspace, stream, t->sdtype};
     const int N = t->cfg.N;
+    RC(stem_join(t, stream));
     if (train_bn)
         RC(vince_zero_async(at(workspace, t->off_stats), t->n_stats_doubles * sizeof(double), stream));
     if (!input) {
@@ -1118,6 +1158,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
     VINCE_CHECK_ARG(t && params && wcache && workspace && dpooled && grads, VINCE_E_ARG, "vince_trunk_backward: null pointer");
     Ctx c{t, params, wcache, workspace, stream, t->sdtype};
     const int N = t->cfg.N;
+    RC(stem_join(t, stream));
     RC(vince_zero_async(at(workspace, t->off_sums), t->n_stats_doubles * sizeof(double), stream));
     if (t->fwd_alg && t->algR_bytes) RC(vince_zero_async(at(workspace, t->off_algR), t->algR_bytes, stream));
     // Weight gradients run on a side stream: wgrad(layer) only needs dY(layer) and the saved activation, and nothing but
@@ -1406,12 +1447,14 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
         // Deferred stem join (vince_trunk_set_stem_event): the caller's stream waits for every weight gradient BUT the stem's -- whatever
         // it enqueues next (the optimiser over every other parameter, the key encoder's EMA) runs beside that launch, which is
         // otherwise alone on the machine at the very end of the step (~200 us at ResNet-50, B = 256) -- and the stem's gradient is
-        // final once stem_event has passed.  Its dY slot stays marked pending, so the next backward still waits before reusing it.
+        // final once stem_event has passed.  The launch keeps reading the stem input, its dY slot and the scratch after this function
+        // has returned: `stem_inflight` makes the next forward / backward / folded forward on this handle wait for the event (stem_join).
         VINCE_CHECK_HIP(hipEventRecord(t->ev_join, t->side));
         VINCE_CHECK_HIP(hipStreamWaitEvent(main_s, t->ev_join, 0));
         for (int i = 0; i < t->ndy; ++i) t->wg_pending[i] = false;
         RC(wgrad_async(stem_desc(t), at(workspace, t->off_x0), grads[t->stem.param], 3));
         VINCE_CHECK_HIP(hipEventRecord(t->stem_event, t->side));
+        t->stem_inflight = true;
         return VINCE_OK;
     }
     RC(wgrad_async(stem_desc(t), at(workspace, t->off_x0), grads[t->stem.param], 3));

@@ -104,6 +104,7 @@ class Trunk:
             raise ValueError("stage_u8: expected contiguous uint8 [%d, Hs, Ws, 3] frames, got %s %s"
                              % (self.N, frames_u8.dtype, tuple(frames_u8.shape)))
         wp, left = ctypes.c_int32(), ctypes.c_int32()
+        check(lib().vince_trunk_stem_join(self._h, ops.stream_ptr()))     # a deferred stem weight gradient may still be reading x0
         x0 = lib().vince_trunk_input_ptr(self._h, ctypes.c_void_p(workspace.data_ptr()), ctypes.byref(wp), ctypes.byref(left))
         mean = (ctypes.c_float * 3)(*[float(v) for v in mean255])
         std = (ctypes.c_float * 3)(*[float(v) for v in std255])
@@ -120,6 +121,7 @@ class Trunk:
             raise ValueError("stage_blur: expected contiguous uint8 [%d, %d, %d, 3] frames, got %s %s"
                              % (self.N, self.H, self.W, img_u8.dtype, tuple(img_u8.shape)))
         wp, left = ctypes.c_int32(), ctypes.c_int32()
+        check(lib().vince_trunk_stem_join(self._h, ops.stream_ptr()))
         x0 = lib().vince_trunk_input_ptr(self._h, ctypes.c_void_p(workspace.data_ptr()), ctypes.byref(wp), ctypes.byref(left))
         if wp.value != ops.stem_row_width(w) or left.value != ops.STEM_LEFT:
             raise RuntimeError("stage_blur: stem layout mismatch")

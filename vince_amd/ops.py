@@ -604,6 +604,8 @@ class InfoNCEResult:
 
 def infonce_fwd(q, inb, queue, temperature, frames=1, offdiag_neg=False, save_logits=False):
     """Fused similarity + loss + metrics.  q:[B,D] inb:[B,D] queue:[K,D] or None (all float32).
+    PRECONDITION: the rows are UNIT vectors (the reference normalises both sides, vince_model.py:180).  The logits are products of
+    IEEE-half hi / lo halves scaled by 2^8: an entry with |x| >= 255.9 makes its row NaN by design (include/vince_hip.h).
     save_logits: also store the B x (Bk + K) raw cosines (r.logits) for infonce_bwd to read back instead of recomputing them."""
     require_gpu(q, inb, queue)
     B, D = q.shape
