@@ -46,7 +46,9 @@ FWD_GFLOP_PER_FRAME = {"ResNet50": 8.2000, "ResNet18": 3.6282}
 TRUNK_GFLOP_PER_FRAME = {"ResNet50": 8.1743, "ResNet18": 3.6271}      # conv MACs x 2 per image
 # MI355X_MICROARCH.md dense MFMA peaks; "x3" = fp32 tensors multiplied as hi*hi + hi*lo + lo*hi on the half-precision pipe:
 # three MFMAs per algorithmic product, so the roof for ALGORITHMIC FLOPs is a third of the 16-bit peak
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "x3": 2500.0 / 3.0}
+# "x3f" = the x3 forward with single bfloat16 products in every gradient convolution: of the step's algorithmic FLOPs the two forwards
+# (half) cost three MFMAs per product and the backward (half) one -> two on average.  (Its forward + InfoNCE leg is priced as x3's.)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "x3": 2500.0 / 3.0, "x3f": 2500.0 / 2.0}
 # One tag per kernel family, in the library's order (csrc/common.h VINCE_TAG_*).  bound "mfma": the profiler's `work` is algorithmic
 # FLOPs and the roof is the dense MFMA peak of the dtype; bound "hbm": `work` is algorithmic BYTES and the roof is 8 TB/s.
 KERNEL_TAGS = [("conv_igemm<%s,%s,%s>" % (t, shape, e), "mfma", t) for t in ("f32", "bf16")
@@ -77,6 +79,22 @@ class PooledFrames:
         item = self.items[self.i % len(self.items)]
         self.i += 1
         return dict(item)
+
+
+class stdout_to_stderr:
+    """RCCL prints a version banner on the C-level stdout when a communicator is created: keep fd 1 clean for the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
 
 
 def physical_cores():
@@ -232,7 +250,10 @@ def measure_copy_ceiling(L, device, nbytes=1 << 30):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 100: five blocks of 20, each block timed by device events -- `blocks` -- so that a 1 %% change "
+                         "shows through the +-3 %% box-to-box spread; an explicit K is timed as exactly K steps, and a 5 x 20 `steady_state` "
+                         "leg follows among the extras when K < 100)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--backbone", default="ResNet50")
     ap.add_argument("--batch", type=int, default=256)
@@ -240,7 +261,7 @@ def main():
     ap.add_argument("--queue", type=int, default=65536)
     ap.add_argument("--embed", type=int, default=128)
     ap.add_argument("--temperature", type=float, default=0.2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "x3", "x3f"])
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline and cpu_baseline legs")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -257,6 +278,8 @@ def main():
                          "through the GPU input stage (MoCo-v2 recipe: resized crop, grayscale, colour jitter, flip, blur) "
                          "inside the timed step")
     opt = ap.parse_args()
+    if opt.steps is None:
+        opt.steps = 100
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -268,6 +291,10 @@ def main():
     if one_gpu:
         local = 0
     torch.cuda.set_device(local)
+    fd_guard = None
+    if world > 1 or os.environ.get("VINCE_FORCE_DP"):
+        fd_guard = stdout_to_stderr()
+        fd_guard.__enter__()       # until rank 0 prints its line: communicators are created lazily, at the first collective
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo" if one_gpu else "nccl")
@@ -323,16 +350,35 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def run_blocks(s_, nblocks, per_block):
+        """nblocks x per_block steps back to back; block boundaries are device events on the step's stream (no host synchronisation
+        inside: the host keeps running ahead exactly as in a plain loop).  Returns (last step's output, per-block ms per step)."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nblocks + 1)]
+        last_ = None
+        evs[0].record()
+        for b_ in range(nblocks):
+            for _ in range(per_block):
+                last_ = s_.run_train_iteration()
+            evs[b_ + 1].record()
+        return last_, evs
+
+    def block_stats(evs, per_block):
+        ms_ = [evs[i].elapsed_time(evs[i + 1]) / per_block for i in range(len(evs) - 1)]
+        return {"steps_per_block": per_block, "ms_per_step": [round(v, 3) for v in ms_], "min": round(min(ms_), 3),
+                "median": round(float(np.median(ms_)), 3), "max": round(max(ms_), 3),
+                "how": "device events at the block boundaries on the step's stream; the loop never synchronises the host"}
+
     for _ in range(opt.warmup):
         solver.run_train_iteration()
+    nblocks = 5 if (opt.steps >= 25 and opt.steps % 5 == 0) else 1
+    launches0 = lib().vince_launch_count()
     barrier()
     t0 = time.perf_counter()
-    last = None
-    for _ in range(opt.steps):
-        last = solver.run_train_iteration()
+    last, block_events = run_blocks(solver, nblocks, opt.steps // nblocks)
     t_enqueued = time.perf_counter() - t0      # the host has ENQUEUED every step (nothing in the loop synchronises); the GPU is still running
     barrier()
     dt = time.perf_counter() - t0
+    launches_per_step = (lib().vince_launch_count() - launches0) / float(opt.steps)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -360,7 +406,13 @@ def main():
         "host_enqueue_frac": round(t_enqueued / dt, 4),
         "step_mfma_frac": round(whole_step_tflops / PEAK_TFLOPS[opt.dtype], 4),
         "step_tflops_per_gpu": round(whole_step_tflops, 2),
+        # launch budget: kernel launches of the HIP library per step, counted by the library itself over the timed loop
+        # (csrc/common.h: every launch site); torch's own element-wise launches and runtime copies / fills come on top (~45 per step in
+        # the kernel trace, profiles/r06_kernel_stats.txt)
+        "launches_per_step": {"library": round(launches_per_step, 1), "counted_by": "vince_launch_count() over the timed loop"},
     }
+    if nblocks > 1:
+        out["blocks"] = block_stats(block_events, opt.steps // nblocks)
 
     if not opt.no_extras and world == 1:
         # ---- key-encoder overlap A/B, untraced (VERDICT r4 weak #6a): the same step with the key encoder inline on the main stream
@@ -391,6 +443,14 @@ def main():
             solver.run_train_iteration()
         out["host_enqueue_idle_ms"] = round(1000.0 * (time.perf_counter() - th) / 3, 3)
         torch.cuda.synchronize()
+        if nblocks == 1:
+            # an explicit short --steps (the driver's 20): the same loop once more as 5 blocks of 20, so that the line carries a
+            # min / median over 100 steps whatever K was
+            barrier()
+            _, evs = run_blocks(solver, 5, 20)
+            barrier()
+            out["steady_state"] = dict(block_stats(evs, 20), steps=100)
+            out["steady_state"]["frames_per_s_at_median"] = round(2.0 * opt.batch / (out["steady_state"]["median"] * 1e-3), 1)
 
     if not opt.no_extras:
         # ---- forward + InfoNCE only (the quantity the north-star roofline target is stated on): query-encoder forward in
@@ -640,14 +700,79 @@ def main():
                 barrier()
                 t3 = (time.perf_counter() - t3) / max(3, steps)
                 ftf = FWD_GFLOP_PER_FRAME.get(gflop_backbone, 0.0) * bsz / 1000.0 / t3
-                leg["fwd_infonce"] = {"ms": round(t3 * 1000, 3), "tflops": round(ftf, 1), "mfma_frac": round(ftf / PEAK_TFLOPS[dt_name], 4),
-                                      "roof_tflops": round(PEAK_TFLOPS[dt_name], 1)}
+                froof = PEAK_TFLOPS["x3" if dt_name == "x3f" else dt_name]     # (x3f's forward IS x3's)
+                leg["fwd_infonce"] = {"ms": round(t3 * 1000, 3), "tflops": round(ftf, 1), "mfma_frac": round(ftf / froof, 4),
+                                      "roof_tflops": round(froof, 1)}
             del s2
             torch.cuda.empty_cache()
             return leg
 
+        def dp_leg(side_streams, steps=10):
+            """Data-parallel machinery without peers: the headline step with VINCE_FORCE_DP=1 -- a single-rank RCCL
+            group, bucket events from the engine's backward, the all-reduce slots on the communication stream (a device copy of each
+            bucket stands in for the collective RCCL elides at world size 1: VINCE_DP_TRACE_PROXY), key all-gather, the last bucket
+            behind the stem event -- and one traced step's bucket slot offsets relative to backward."""
+            nonlocal solver
+            import torch.distributed as dist
+            solver = None
+            torch.cuda.empty_cache()
+            own_group = not dist.is_initialized()
+            env_keys = ("VINCE_FORCE_DP", "VINCE_DP_TRACE_PROXY", "VINCE_DP_SIDE_STREAMS")
+            saved_env = {k_: os.environ.get(k_) for k_ in env_keys}
+            os.environ.update({"VINCE_FORCE_DP": "1", "VINCE_DP_TRACE_PROXY": "1", "VINCE_DP_SIDE_STREAMS": str(side_streams)})
+            guard = stdout_to_stderr()
+            guard.__enter__()
+            try:
+                if own_group:
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", "29578")
+                    dist.init_process_group("nccl", rank=0, world_size=1)
+                base = {k_: getattr(args, k_) for k_ in vars(args)}
+                base["batch_source"] = PooledFrames(opt.batch, opt.size, opt.size, 1, device, pool=2, rank=rank, world=world)
+                with contextlib.redirect_stdout(sys.stderr):
+                    s2 = VinceSolver(make_args(**base))
+                    s2.reset_epoch()
+                assert s2.reducer is not None
+                for _ in range(3):
+                    s2.run_train_iteration()
+                barrier()
+                t2 = time.perf_counter()
+                for _ in range(steps):
+                    s2.run_train_iteration()
+                barrier()
+                t2 = (time.perf_counter() - t2) / steps
+                s2.reducer.enable_trace()
+                s2.run_train_iteration()
+                rep = s2.reducer.trace_report()
+                s2.reducer.enable_trace(False)
+                leg = {"ms_per_step": round(t2 * 1000, 3), "steps": steps, "engine_side_streams": side_streams, "trace": rep}
+                del s2
+                return leg
+            finally:
+                if own_group and dist.is_initialized():
+                    dist.destroy_process_group()
+                for k_, v_ in saved_env.items():
+                    if v_ is None:
+                        os.environ.pop(k_, None)
+                    else:
+                        os.environ[k_] = v_
+                lib().vince_set_side_streams(2)      # the data-parallel solver lowered the engine's stream budget process-wide
+                torch.cuda.empty_cache()
+                guard.__exit__()
+
         is_c3 = opt.mode == "moco" and opt.input == "float"
-        if opt.fp32_steps > 0 and opt.dtype != "x3" and is_c3:
+        if is_c3 and opt.config_steps > 0:
+            try:
+                out["dp_forced_single_rank"] = {
+                    "what": "the headline step through the data-parallel path on ONE GPU (single-rank RCCL group; a device copy of each "
+                            "gradient bucket stands in for the elided collective): ms per step against `ms_per_step`, for the engine keeping "
+                            "1 side stream (the data-parallel default: weight gradients only) and 2 (+ the downsample branch); `trace` = one "
+                            "step's bucket communication slots relative to the start of backward",
+                    "plain_ms_per_step": out["ms_per_step"],
+                    "side_streams_1": dp_leg(1), "side_streams_2": dp_leg(2)}
+            except Exception as e:
+                out["dp_forced_single_rank"] = {"error": repr(e)}
+        if opt.fp32_steps > 0 and opt.dtype not in ("x3", "x3f") and is_c3:
             try:
                 out["x3_step"] = dict(step_leg(opt.fp32_steps, gflop_backbone=opt.backbone, fwd_too=True, compute_dtype="x3"),
                                       what="fp32 tensors, convolutions as split-half products (f16 hi/lo forward, bf16 hi/lo gradients): the "
@@ -655,6 +780,15 @@ def main():
                                            "G11c, G12); mfma_frac against 2.5 PF / 3")
             except Exception as e:
                 out["x3_step"] = {"error": repr(e)}
+        if opt.fp32_steps > 0 and opt.dtype not in ("x3", "x3f") and is_c3:
+            try:
+                out["x3f_step"] = dict(step_leg(opt.fp32_steps, gflop_backbone=opt.backbone, compute_dtype="x3f"),
+                                       what="the x3 forward (embeddings, keys and loss at the reference's 1e-3 bar: the same forward kernels) with "
+                                            "every gradient convolution as SINGLE bfloat16 products on the fp32 tensors -- a mixed-precision "
+                                            "backward (what the reference's --use-apex would run) behind an fp32-grade forward; gradients "
+                                            "at bf16-product precision, measured against the reference in test_x3f_*; mfma_frac against 2.5 PF / 2")
+            except Exception as e:
+                out["x3f_step"] = {"error": repr(e)}
         if opt.fp32_steps > 0 and opt.dtype != "fp32":
             try:
                 out["fp32_step"] = step_leg(opt.fp32_steps, gflop_backbone=opt.backbone, fwd_too=is_c3, compute_dtype="fp32")
@@ -678,8 +812,10 @@ def main():
                 out["c2_x3_step"] = {"error": repr(e)}
             try:
                 random.seed(1234 + rank)
-                out["c5_step"] = dict(step_leg(opt.config_steps, frames=4, num_frames=4, inter_batch_comparison=True,
+                out["c5_step"] = dict(step_leg(opt.config_steps, frames=4, gflop_backbone=opt.backbone, num_frames=4, inter_batch_comparison=True,
                                                self_batch_comparison=True, jigsaw=True, vince_self_temperature=0.03),
+                                      flops_note="tflops / mfma_frac count the plain step's trunk + head + similarity FLOPs per frame: the jigsawed "
+                                                 "side's nine 75 x 75 tiles are 50 625 pixels against 50 176, its head GEMMs (2048 x 18432) add 0.3 %",
                                       workload="BASELINE config 5 per-GPU work: %s %dx%d, B=%d frames = %d clips x 4 frames, K=%d, inter-batch + "
                                                "self-batch comparison, jigsaw side by a seeded coin, %s trunk"
                                                % (opt.backbone, opt.size, opt.size, opt.batch, opt.batch // 4, opt.queue, opt.dtype))
@@ -702,9 +838,13 @@ def main():
         except Exception as e:   # the baseline leg must never take the measurement down
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
 
+    if fd_guard is not None:
+        fd_guard.__exit__()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        sys.stdout.flush()
+        os.dup2(2, 1)              # (whatever the teardown prints)
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -46,6 +46,14 @@ extern "C" {
 #define VINCE_F32X3H 2
 #define VINCE_F32X3B 3
 #define VINCE_F32X3 VINCE_F32X3H
+/* fp32 tensors, SINGLE bfloat16 products (the hi halves only: one MFMA per block, 2^-9 per operand) -- gradient launches of the mixed mode
+ * below; accepted by vince_conv_igemm and vince_conv_wgrad(_det) with the VINCE_F32X3B weight layout (the lo halves are not read).
+ * VINCE_F32X3F (vince_trunk_cfg.dtype only): forward as VINCE_F32X3 -- split-half products, embeddings and loss at the fp32 reference's
+ * 1e-3 bar -- and every GRADIENT convolution (input and weight gradients) as VINCE_F32X1B: the arithmetic of a bf16 mixed-precision
+ * backward (what the reference's --use-apex would run) behind an fp32-grade forward.  Gram matrices (they feed forward statistics) stay
+ * on VINCE_F32X3B.  (ABI 11) */
+#define VINCE_F32X1B 4
+#define VINCE_F32X3F 5
 
 const char* vince_last_error(void);
 /* Bumped whenever an exported signature, a struct layout or a dtype code changes.  vince_abi_version() returns the value the library
@@ -66,6 +74,9 @@ int vince_profile_enable(int on);
  * the data-parallel solver sets 1.  Process-wide; call before the first backward. */
 int vince_set_side_streams(int32_t n);
 int vince_profile_collect(int32_t ntags, double* ms, double* flops, int64_t* count);
+/* Kernel launches this library has enqueued since it was loaded (every launch site counts itself; memsets / copies issued through the
+ * HIP runtime and the caller's own kernels are not included).  bench.py differences it over a step: `launches_per_step`.  (ABI 11) */
+int64_t vince_launch_count(void);
 /* Calibration aid (bench.py `roofline.hbm_achievable`, tools/ceilings.py): copies `bytes` (multiple of 16) with a plain
  * 16-byte-per-lane grid-stride kernel of `blocks` workgroups (<= 0: 2048) -- the HBM streaming rate this box gives an
  * element-wise pass, measured with the library's own code instead of a framework copy.  nontemporal: bit 0 = `nt` loads and stores;

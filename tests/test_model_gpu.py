@@ -419,7 +419,7 @@ def test_g11_centred_head_vs_reference_golden(dtype):
 
 # ------------------------------------------------------------------------------------------ G13: config 5 at its own size
 @pytest.mark.parametrize("coin", ["k", "q"])
-@pytest.mark.parametrize("dtype", ["fp32", "x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "x3", "x3f", "bf16"])
 def test_g13_config5_multiframe_jigsaw_vs_reference_golden(dtype, coin):
     """G13 (oracle/make_golden_g13.py): BASELINE config 5's per-GPU work at ITS OWN size against the imported
     reference -- ResNet-50, 224 x 224, 4 frames per clip (8 clips), inter-batch + self-batch comparison, D=128, T=0.2 / self-T 0.03,

@@ -139,3 +139,36 @@ def test_x3_stem_packed_rows(hw):
     dw = torch.zeros(64, 49, 3, device=DEV)
     ops.conv_wgrad(d, xin, to_nhwc(dy, torch.float32), dw, ci_dw=3, x3="b")
     assert _err(dw, w.grad.permute(0, 2, 3, 1).reshape(64, 49, 3)) < 1e-4
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_x1b_single_product_gradients_vs_fp64(cfg):
+    """VINCE_F32X1B (the gradient launches of compute_dtype "x3f"): fp32 tensors, ONE bfloat16 MFMA per block -- both operands rounded
+    to 8 significand bits, fp32 accumulation.  Input and weight gradients against fp64 autograd: rounding errors of 2^-9 per operand
+    average out over the reduction; held at 6e-3 of the largest entry (measured 1e-3 ... 3e-3), and -- the point of the mode -- the
+    SAME launches with three products (x3b) are three orders tighter on the same operands."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, p = cfg
+    x = rnd(N, Ci, H, W, seed=6).double().requires_grad_(True)
+    w = rnd(Co, Ci, k, k, seed=7, scale=(2.0 / (Ci * k * k)) ** 0.5).double().requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = rnd(*y.shape, seed=8) * 1e-6
+    y.backward(dy.double())
+    _, wt = weights_krsc(w.detach().float(), torch.float32, x3=True)     # the bfloat16-pair layout; the lo halves are not read
+    dyg = to_nhwc(dy, torch.float32)
+    res = {}
+    for tag in ("1", "b"):
+        dx = torch.full((N, H, W, Ci), float("nan"), device=DEV)
+        descs = ops.dgrad_descs(N, H, W, Ci, Co, k, s, p)
+        if len(descs) < s * s:
+            dx.zero_()
+        for d in descs:
+            ops.conv_igemm(d, dyg, wt, dx, x3=tag)
+        fd = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
+        dw = torch.zeros(Co, k * k, Ci, device=DEV)
+        ops.conv_wgrad(fd, to_nhwc(x.detach().float(), torch.float32), dyg, dw, x3=tag)
+        res[tag] = (_err(from_nhwc(dx), x.grad), _err(dw, w.grad.permute(0, 2, 3, 1).reshape(Co, k * k, Ci)))
+    print("x1b %s: dgrad %.2e wgrad %.2e (x3b on the same operands: %.2e / %.2e)" % ((cfg,) + res["1"] + res["b"]))
+    assert res["1"][0] < 6e-3 and res["1"][1] < 6e-3
+    assert res["b"][0] < 1e-4 and res["b"][1] < 1e-4
+    assert res["1"][0] > 10 * res["b"][0]        # (the single-product launches really are a different arithmetic)

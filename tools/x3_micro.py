@@ -1,5 +1,6 @@
 """The convolutions of ResNet-50 at the benchmark batch (N = 256), timed alone: forward, input gradient (stride-1 layers) and weight
-gradient as split-half products (x3: fp32 tensors, f16 hi/lo forward, bf16 hi/lo gradients) beside the bf16 and exact-fp32 kernels.
+gradient as split-half products (x3: fp32 tensors, f16 hi/lo forward, bf16 hi/lo gradients; x1: the gradient launches of x3f -- single
+bfloat16 products on the same fp32 tensors, forward as x3) beside the bf16 and exact-fp32 kernels.
 Usage: python tools/x3_micro.py [label]   (X3_SHAPES=0,3 restricts the list; X3_MODES=x3,bf16,fp32; X3_OPS=fwd,dgrad,wgrad)"""
 import os
 import sys
@@ -40,10 +41,10 @@ for hw, ci, co, k in SHAPES:
         cells = []
         for mode in MODES:
             dt = torch.bfloat16 if mode == "bf16" else torch.float32
-            x3f, x3b = ("h", "b") if mode == "x3" else (None, None)
+            x3f, x3b = ("h", "b") if mode == "x3" else ("h", "1") if mode == "x1" else (None, None)
             x = torch.randn(N, hw, hw, ci, device="cuda").to(dt)
             w = (torch.randn(co, k * k, ci, device="cuda") * (2.0 / (ci * k * k)) ** 0.5)
-            wk, wt = ops.prepare_weight(w, dt, want_transposed=True, x3=(mode == "x3"))
+            wk, wt = ops.prepare_weight(w, dt, want_transposed=True, x3=(mode in ("x3", "x1")))
             y = torch.empty(N, hw, hw, co, device="cuda", dtype=dt)
             d = ops.conv_desc(N, hw, hw, ci, co, k, 1, k // 2)
             if op == "fwd":

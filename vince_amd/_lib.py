@@ -10,6 +10,8 @@ VINCE_F32, VINCE_BF16 = 0, 1
 # B = bfloat16 halves (gradients); VINCE_F32X3 is what vince_trunk_cfg.dtype takes
 VINCE_F32X3H, VINCE_F32X3B = 2, 3
 VINCE_F32X3 = VINCE_F32X3H
+# fp32 tensors, single bfloat16 products (op level: gradient launches); trunk cfg: x3 forward + single-product gradients ("x3f")
+VINCE_F32X1B, VINCE_F32X3F = 4, 5
 EPI_ACCUMULATE, EPI_RELU = 1, 2
 
 c_void_p, c_int, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,
@@ -160,6 +162,7 @@ PROTOTYPES = {
     "vince_trunk_set_bucket_callback": (c_int, [c_void_p, c_void_p, c_void_p]),
     "vince_trunk_set_stem_event": (c_int, [c_void_p, c_void_p]),
     "vince_trunk_stem_join": (c_int, [c_void_p, c_void_p]),
+    "vince_launch_count": (ctypes.c_int64, []),
     "vince_trunk_prepare_weights_part": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_trunk_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                      c_void_p]),

@@ -53,7 +53,7 @@ def build_parser():
     p.add_argument("--vince-self-temperature", type=float, default=0.03)
     p.add_argument("--no-multi-frame", dest="multi_frame", action="store_false")
     p.add_argument("--use-apex", action="store_true", help="accepted for script compatibility; use --compute-dtype bf16")
-    p.add_argument("--compute-dtype", default="bf16", choices=["bf16", "fp32", "x3"],
+    p.add_argument("--compute-dtype", default="bf16", choices=["bf16", "fp32", "x3", "x3f"],
                    help="trunk arithmetic (head, similarity and loss are always fp32)")
     p.add_argument("--epochs", default=200, type=int)
     p.add_argument("--lr-decay-type", default="cos", choices=["cos", "step"])

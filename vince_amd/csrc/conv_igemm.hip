@@ -38,7 +38,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
                     "vince_conv_igemm: out_scale / id_scale need VINCE_EPI_ACCUMULATE and exclude acc_mask, bnred and stats");
     VINCE_CHECK_ARG(!e.bnred.mask_scale == !e.bnred.mask_shift, VINCE_E_ARG,
                     "vince_conv_igemm: bnred mask_scale and mask_shift come together");
-    VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16 || dtype == VINCE_F32X3H || dtype == VINCE_F32X3B, VINCE_E_DTYPE,
+    VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16 || dtype == VINCE_F32X3H || dtype == VINCE_F32X3B || dtype == VINCE_F32X1B, VINCE_E_DTYPE,
                     "vince_conv_igemm: bad dtype %d", dtype);
     const bool f32_store = dtype != VINCE_BF16;    // the split-half types are fp32 tensors
     VINCE_CHECK_ARG(!e.in2 || (dd->TA * dd->TB >= 2 && dd->Cs == 0 && e.in2_channels > 0 && e.in2_channels <= dd->Ci &&
@@ -148,7 +148,7 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
         }
         return rc;
     }
-    if (dtype == VINCE_F32X3H || dtype == VINCE_F32X3B) {
+    if (dtype == VINCE_F32X3H || dtype == VINCE_F32X3B || dtype == VINCE_F32X1B) {
         rc = vince_conv_igemm_x3_launch(p, dtype, join ? 2 : (bwd ? 1 : 0), narrow, s);
     } else if (dtype == VINCE_F32) {
         if (join) rc = narrow ? launch<float, 64, 2>(p, s) : launch<float, 128, 2>(p, s);

@@ -10,6 +10,11 @@ int vince_conv_igemm_x3_launch(vince_conv::ConvParams& p, int dtype, int mode, b
         if (mode == 1) return narrow ? launch_x3<x3h_t, 64, 1>(p, s) : launch_x3<x3h_t, 128, 1>(p, s);
         return narrow ? launch_x3<x3h_t, 64, 0>(p, s) : launch_x3<x3h_t, 128, 0>(p, s);
     }
+    if (dtype == VINCE_F32X1B) {   // the bfloat16 hi halves only (the gradient launches of VINCE_F32X3F): one MFMA per block
+        if (mode == 2) return narrow ? launch_x3<x1b_t, 64, 2>(p, s) : launch_x3<x1b_t, 128, 2>(p, s);
+        if (mode == 1) return narrow ? launch_x3<x1b_t, 64, 1>(p, s) : launch_x3<x1b_t, 128, 1>(p, s);
+        return narrow ? launch_x3<x1b_t, 64, 0>(p, s) : launch_x3<x1b_t, 128, 0>(p, s);
+    }
     if (mode == 2) return narrow ? launch_x3<x3b_t, 64, 2>(p, s) : launch_x3<x3b_t, 128, 2>(p, s);
     if (mode == 1) return narrow ? launch_x3<x3b_t, 64, 1>(p, s) : launch_x3<x3b_t, 128, 1>(p, s);
     return narrow ? launch_x3<x3b_t, 64, 0>(p, s) : launch_x3<x3b_t, 128, 0>(p, s);

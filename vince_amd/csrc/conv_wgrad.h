@@ -31,7 +31,7 @@ int wgrad_tr_launch(const WgradParams& p, int ct, int nt, int splits, hipStream_
 
 // conv_wgrad_x3.hip: the split-half (VINCE_F32X3B) weight gradient with conv_wgrad_tr's addressing; same contract as the pair above
 void wgrad_x3_tile(const WgradParams& p, int* ct, int* nt);
-int wgrad_x3_launch(const WgradParams& p, int ct, int nt, int splits, hipStream_t stream);
+int wgrad_x3_launch(const WgradParams& p, int ct, int nt, int splits, bool single, hipStream_t stream);   // single: VINCE_F32X1B (hi halves only)
 
 // dst[i] += slab[0][i] + slab[1][i] + ... (n4 float4 columns, `stride` floats between slabs) in a fixed order: run-to-run identical
 int slab_reduce(const float* slab, int splits, size_t stride, float* dst, size_t n4, hipStream_t stream);

@@ -84,6 +84,7 @@ template <> struct FragT<float> {
 // split-half products (bfloat16 halves: gradients need fp32's exponent range): the fp32 tiles and fetches, two fetches (8 pixels per
 // lane and column) split into hi / lo halves in registers feed three v_mfma_f32_32x32x16_bf16 per block
 template <> struct FragT<x3b_t> : FragT<float> {};
+template <> struct FragT<x1b_t> : FragT<float> {};
 
 template <typename T, int CT, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
@@ -298,6 +299,7 @@ template <int ROWBYTES> struct FragD<float, ROWBYTES> {
 };
 
 template <int ROWBYTES> struct FragD<x3b_t, ROWBYTES> : FragD<float, ROWBYTES> {};
+template <int ROWBYTES> struct FragD<x1b_t, ROWBYTES> : FragD<float, ROWBYTES> {};
 
 // NW wavefronts as 2 (channel halves) x NW/2 (reduction-side column groups): 4 = the 128 x 128 tile of 2 x 2 MFMA tiles per wavefront,
 // 8 = the 256 x 256 tile of the long multi-tap layers (4 x 2 MFMA tiles per wavefront: half the operand bytes per FLOP through L2 -> LDS)
@@ -574,7 +576,7 @@ int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t
     // split-half products: the kernel of conv_wgrad_x3.hip (the addressing of conv_wgrad_tr on fp32 tiles) whenever the layer qualifies
     // (`wgrad_x3=0`: the LDS-DMA kernel of this file instantiated for x3b_t, cross-check switch)
     bool x3k = false;
-    if (std::is_same<T, x3b_t>::value && vince_knob_live("wgrad_x3", 1)) {
+    if (X3<T>::on && vince_knob_live("wgrad_x3", 1)) {
         vince_wgrad::wgrad_x3_tile(p, &tr_ct, &tr_nt);
         x3k = tr_ct > 0;
     }
@@ -639,7 +641,7 @@ int dispatch(WgradParams& p, hipStream_t stream, void* scratch = nullptr, size_t
         }
     }
     int rc;
-    if (x3k) rc = vince_wgrad::wgrad_x3_launch(p, CT, NT, splits, stream);
+    if (x3k) rc = vince_wgrad::wgrad_x3_launch(p, CT, NT, splits, X3<T>::single, stream);
     else if (tr) rc = vince_wgrad::wgrad_tr_launch(p, CT, NT, splits, stream);
     else     if (CT == 64 && NT == 64) rc = launch<T, 64, 64>(p, splits, stream);
     else if (CT == 64) rc = launch<T, 64, 128>(p, splits, stream);
@@ -689,7 +691,7 @@ static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, co
     }
 #endif
     if (dtype == VINCE_F32X3H) dtype = VINCE_F32X3B;   // weight gradients always split into bfloat16 halves (the operand dy spans many decades)
-    VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16 || dtype == VINCE_F32X3B, VINCE_E_DTYPE, "vince_conv_wgrad: bad dtype %d", dtype);
+    VINCE_CHECK_ARG(dtype == VINCE_F32 || dtype == VINCE_BF16 || dtype == VINCE_F32X3B || dtype == VINCE_F32X1B, VINCE_E_DTYPE, "vince_conv_wgrad: bad dtype %d", dtype);
     const vince_conv_desc& d = *dd;
     const bool f32_store = dtype != VINCE_BF16;
     const int CH = f32_store ? 4 : 8;
@@ -758,6 +760,7 @@ static int wgrad_common(const vince_conv_desc* dd, int dtype, const void* in, co
     }
     const int rc = dtype == VINCE_F32 ? dispatch<float>(p, s, scratch, scratch_bytes, need_out)
                  : dtype == VINCE_F32X3B ? dispatch<x3b_t>(p, s, scratch, scratch_bytes, need_out)
+                 : dtype == VINCE_F32X1B ? dispatch<x1b_t>(p, s, scratch, scratch_bytes, need_out)
                                          : dispatch<bf16_t>(p, s, scratch, scratch_bytes, need_out);
     if (tok) vince_profile_end_launch(tok, stream);
     return rc;

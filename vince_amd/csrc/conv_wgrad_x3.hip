@@ -37,7 +37,8 @@ static __device__ __forceinline__ uint32_t fdiv(uint32_t n, uint32_t mul, uint32
 // 4 wavefronts as 2 (dy channel halves) x 2 (x column halves); wavefront tile CT/2 x NT/2 = (CT/64) x (NT/64) MFMA blocks.
 // RUN = 0: 1x1, stride 1, no padding -- the input pixel is the output pixel.  RUN > 0: consecutive x sub-tiles that share a tap
 // (min(NT, Ci) / 32).
-template <int CT, int NT, int STAGES, int RUN>
+// XT: x3b_t (three MFMAs per block) or x1b_t (VINCE_F32X1B: the hi halves only, one MFMA per block)
+template <typename XT, int CT, int NT, int STAGES, int RUN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams p) {
     constexpr bool LINEAR = RUN == 0;
     constexpr int YS = CT / 32, XS = NT / 32;                 // sub-tiles per operand
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
     auto frag = [&](const unsigned char* base, uint4& hi, uint4& lo) {
         const uint4 f0 = make_uint4(*(const uint32_t*)base, *(const uint32_t*)(base + 128), *(const uint32_t*)(base + 256), *(const uint32_t*)(base + 384));
         const uint4 f1 = make_uint4(*(const uint32_t*)(base + 512), *(const uint32_t*)(base + 640), *(const uint32_t*)(base + 768), *(const uint32_t*)(base + 896));
-        x3_split<x3b_t, false>(f0, f1, hi, lo);
+        x3_split<XT, false>(f0, f1, hi, lo);
     };
 
     f32x16_t acc[CJ][NJ];
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
 #pragma unroll
                 for (int j = 0; j < CJ; ++j)
 #pragma unroll
-                    for (int i = 0; i < NJ; ++i) x3_mma<x3b_t>(ah[j], al[j], bh[i], bl[i], acc[j][i]);
+                    for (int i = 0; i < NJ; ++i) x3_mma<XT>(ah[j], al[j], bh[i], bl[i], acc[j][i]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             wait_vmcnt<(STAGES - 2) * PER>();                     // this thread's share of the NEXT slice has landed
@@ -206,19 +207,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradParams
     }
 }
 
-template <int CT, int NT, int STAGES>
+template <typename XT, int CT, int NT, int STAGES>
 int launch_x3(const WgradParams& p, int splits, hipStream_t stream) {
     const dim3 grid(p.ctiles * p.ntiles, splits), block(256);
     constexpr int XS = NT / 32;
     const int run = p.linear_x ? 0 : (p.d.Ci / 32 < XS ? p.d.Ci / 32 : XS);
-    if (run == 0) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CT, NT, STAGES, 0>), grid, block, 0, stream, p);
-    else if (run == 2) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CT, NT, STAGES, 2>), grid, block, 0, stream, p);
+    if (run == 0) hipLaunchKernelGGL((conv_wgrad_x3_kernel<XT, CT, NT, STAGES, 0>), grid, block, 0, stream, p);
+    else if (run == 2) hipLaunchKernelGGL((conv_wgrad_x3_kernel<XT, CT, NT, STAGES, 2>), grid, block, 0, stream, p);
     else if constexpr (XS >= 4) {
-        if (run == 4) hipLaunchKernelGGL((conv_wgrad_x3_kernel<CT, NT, STAGES, 4>), grid, block, 0, stream, p);
+        if (run == 4) hipLaunchKernelGGL((conv_wgrad_x3_kernel<XT, CT, NT, STAGES, 4>), grid, block, 0, stream, p);
         else return VINCE_E_SHAPE;
     } else return VINCE_E_SHAPE;
     VINCE_CHECK_LAUNCH();
     return VINCE_OK;
+}
+
+template <typename XT>
+int launch_x3_tile(const WgradParams& p, int ct, int nt, int splits, hipStream_t stream) {
+    // 128 x 128: 32 KB per slice, two stages (64 KB: two workgroups per CU); the narrower tiles take three
+    if (ct == 128 && nt == 128) return launch_x3<XT, 128, 128, 2>(p, splits, stream);
+    if (ct == 128 && nt == 64) return launch_x3<XT, 128, 64, 3>(p, splits, stream);
+    if (ct == 64 && nt == 128) return launch_x3<XT, 64, 128, 3>(p, splits, stream);
+    if (ct == 64 && nt == 64) return launch_x3<XT, 64, 64, 3>(p, splits, stream);
+    vince_set_error("wgrad_x3_launch: no %d x %d tile", ct, nt);
+    return VINCE_E_SHAPE;
 }
 
 }  // namespace
@@ -244,14 +256,8 @@ void wgrad_x3_tile(const WgradParams& p, int* ct, int* nt) {
     *nt = ntot % 128 ? 64 : 128;
 }
 
-int wgrad_x3_launch(const WgradParams& p, int ct, int nt, int splits, hipStream_t stream) {
-    // 128 x 128: 32 KB per slice, two stages (64 KB: two workgroups per CU); the narrower tiles take three
-    if (ct == 128 && nt == 128) return launch_x3<128, 128, 2>(p, splits, stream);
-    if (ct == 128 && nt == 64) return launch_x3<128, 64, 3>(p, splits, stream);
-    if (ct == 64 && nt == 128) return launch_x3<64, 128, 3>(p, splits, stream);
-    if (ct == 64 && nt == 64) return launch_x3<64, 64, 3>(p, splits, stream);
-    vince_set_error("wgrad_x3_launch: no %d x %d tile", ct, nt);
-    return VINCE_E_SHAPE;
+int wgrad_x3_launch(const WgradParams& p, int ct, int nt, int splits, bool single, hipStream_t stream) {
+    return single ? launch_x3_tile<x1b_t>(p, ct, nt, splits, stream) : launch_x3_tile<x3b_t>(p, ct, nt, splits, stream);
 }
 
 }  // namespace vince_wgrad

@@ -80,6 +80,11 @@ void vince_profile_end_launch(void* token, void* stream) {
     hipEventRecord(g_prof[idx].b, (hipStream_t)stream);
 }
 
+#include <atomic>
+static std::atomic<long long> g_launches{0};
+void vince_note_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" int64_t vince_launch_count(void) { return (int64_t)g_launches.load(std::memory_order_relaxed); }
+
 static int g_side_streams = 2;
 int vince_side_stream_budget() { return g_side_streams; }
 

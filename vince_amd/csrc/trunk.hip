@@ -253,15 +253,18 @@ inline unsigned char* at(void* ws, size_t off) { return (unsigned char*)ws + off
 extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out) {
     VINCE_CHECK_ARG(cfg && out, VINCE_E_ARG, "vince_trunk_create: null pointer");
     VINCE_CHECK_ARG(cfg->arch == 18 || cfg->arch == 50, VINCE_E_UNSUPPORTED, "vince_trunk_create: arch %d (18 or 50)", cfg->arch);
-    VINCE_CHECK_ARG(cfg->dtype == VINCE_F32 || cfg->dtype == VINCE_BF16 || cfg->dtype == VINCE_F32X3, VINCE_E_DTYPE, "vince_trunk_create: bad dtype");
+    VINCE_CHECK_ARG(cfg->dtype == VINCE_F32 || cfg->dtype == VINCE_BF16 || cfg->dtype == VINCE_F32X3 || cfg->dtype == VINCE_F32X3F, VINCE_E_DTYPE,
+                    "vince_trunk_create: bad dtype");
     VINCE_CHECK_ARG(cfg->N > 0 && cfg->H >= 8 && cfg->W >= 8, VINCE_E_SHAPE, "vince_trunk_create: bad input shape");
     vince_trunk* t = new vince_trunk();
     t->cfg = *cfg;
     // VINCE_F32X3: fp32 tensors everywhere; only the convolution launches differ (split-half products: IEEE half halves forward,
     // bfloat16 halves for the gradients)
     t->sdtype = cfg->dtype == VINCE_BF16 ? VINCE_BF16 : VINCE_F32;
-    t->cf = cfg->dtype == VINCE_F32X3 ? VINCE_F32X3H : t->sdtype;
-    t->cb = cfg->dtype == VINCE_F32X3 ? VINCE_F32X3B : t->sdtype;
+    // VINCE_F32X3F: the same forward; gradient launches as single bfloat16 products (VINCE_F32X1B), Gram matrices excepted (wgrad_launch)
+    const bool x3any = cfg->dtype == VINCE_F32X3 || cfg->dtype == VINCE_F32X3F;
+    t->cf = x3any ? VINCE_F32X3H : t->sdtype;
+    t->cb = cfg->dtype == VINCE_F32X3 ? VINCE_F32X3B : cfg->dtype == VINCE_F32X3F ? VINCE_F32X1B : t->sdtype;
     t->esize = t->sdtype == VINCE_F32 ? 4 : 2;
     t->CH = t->sdtype == VINCE_F32 ? 4 : 8;
     t->Cp = t->CH;
@@ -700,6 +703,7 @@ int wgrad_launch(vince_trunk* t, void* ws, int dtype, const vince_conv_desc& d, 
                  int which, void* stream) {
     static const int det = (int)vince_knob("wgrad_det", 1);
     const bool gram = in == dy;
+    if (gram && dtype == VINCE_F32X1B) dtype = VINCE_F32X3B;     // Gram matrices feed FORWARD statistics: split-half products in every x3 mode
     if (!(det >= 2 || (det == 1 && gram)) || !t->wg_scratch_bytes) return vince_conv_wgrad(&d, dtype, in, dy, dw, ci_dw, 0, stream);
     return vince_conv_wgrad_det(&d, dtype, in, dy, dw, ci_dw, at(ws, t->off_wg_scratch[which]), t->wg_scratch_bytes, stream);
 }

@@ -81,6 +81,36 @@ class GradientReducer:
             # elides at world size 1 -- so a kernel trace shows WHEN each bucket's communication slot runs relative to backward
             self._proxy = (torch.empty_like(model._flat_grad) if os.environ.get("VINCE_DP_TRACE_PROXY") == "1" and world()[0] == 1
                            else None)
+        self._trace = None       # enable_trace(): timing events around every bucket's communication slot (bench.py `dp_forced_single_rank`)
+
+    def enable_trace(self, on=True):
+        """Measurement aid: from the next begin_step() on, every bucket's communication slot is bracketed by timing events on the
+        communication stream and backward by events on the compute stream; trace_report() reads them (after a synchronise)."""
+        self._trace = {} if (on and self.on_gpu) else None
+
+    def _slot(self, e, a, b, inside):
+        if self._trace is None or "t0" not in self._trace:
+            return self._reduce_bucket(a, b)
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record(self.comm_stream)
+        self._reduce_bucket(a, b)
+        s1.record(self.comm_stream)
+        self._trace["buckets"][e] = (s0, s1, (b - a) * 4, inside)
+
+    def trace_report(self):
+        """[{bucket, first block, MB, start_ms, ms, launched}] relative to begin_step() + where backward ended, from the last traced step."""
+        t = self._trace
+        if not t or "t0" not in t or "tail" not in t:
+            return None
+        torch.cuda.synchronize()
+        rows = []
+        for e in sorted(t["buckets"]):
+            s0, s1, nbytes, inside = t["buckets"][e]
+            rows.append({"bucket": e, "first_block": self.plan[e][0], "MB": round(nbytes / 1e6, 1),
+                         "start_ms": round(t["t0"].elapsed_time(s0), 3), "ms": round(s0.elapsed_time(s1), 3),
+                         "launched": "inside backward (engine callback)" if inside else "after backward returned"})
+        return {"backward_ms": round(t["t0"].elapsed_time(t["tail"]), 3), "all_reduced_ms": round(t["t0"].elapsed_time(t["done"]), 3),
+                "buckets": rows}
 
     def _reduce_bucket(self, a, b):
         grad = self.model._flat_grad
@@ -99,7 +129,7 @@ class GradientReducer:
             blk, a, b = self.plan[e]
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(self.events[e])
-                self._reduce_bucket(a, b)
+                self._slot(e, a, b, True)
             self._launched.add(e)
         except BaseException as exc:        # a ctypes callback cannot propagate: reduce_after_backward re-raises
             self._hook_error = exc
@@ -157,6 +187,9 @@ class GradientReducer:
         cur = torch.cuda.current_stream()
         tail_event = torch.cuda.Event()
         tail_event.record(cur)
+        if self._trace is not None and "t0" in self._trace:
+            self._trace["tail"] = torch.cuda.Event(enable_timing=True)
+            self._trace["tail"].record(cur)
         # Deferred stem join (round 5; models/vince_model.py defer_stem_join): backward has returned with conv1's weight gradient still
         # in flight behind model._stem_event.  Only the LAST bucket (flat range [0, layer2): stem + layer1) contains it: that bucket's
         # all-reduce waits for the event, and the compute stream is made to wait for every OTHER bucket only (done_most) -- the
@@ -173,8 +206,11 @@ class GradientReducer:
                     self.comm_stream.wait_event(tail_event)
                     if deferred and a == 0:
                         self.comm_stream.wait_event(self.model._stem_event)
-                    self._reduce_bucket(a, b)
+                    self._slot(e, a, b, False)
                 self.done.record(self.comm_stream)
+                if self._trace is not None and "t0" in self._trace:
+                    self._trace["done"] = torch.cuda.Event(enable_timing=True)
+                    self._trace["done"].record(self.comm_stream)
         finally:
             launched_last = last in self._launched
             self._launched.clear()
@@ -192,6 +228,10 @@ class GradientReducer:
         if self.on_gpu:
             self._launched.clear()
             self._hook_error = None
+            if self._trace is not None:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record()
+                self._trace = {"t0": t0, "buckets": {}}
 
 
 # ------------------------------------------------------------------------------------------------ keys

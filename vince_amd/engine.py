@@ -4,7 +4,7 @@ import ctypes
 import torch
 
 from . import ops
-from ._lib import TrunkCfg, VINCE_BF16, VINCE_F32, VINCE_F32X3, check, lib
+from ._lib import TrunkCfg, VINCE_BF16, VINCE_F32, VINCE_F32X3, VINCE_F32X3F, check, lib
 
 ARCH_CODE = {"ResNet18": 18, "ResNet50": 50}
 
@@ -58,7 +58,8 @@ class Trunk:
         if self.x3 and dtype != torch.float32:
             raise ValueError("Trunk: split-half products (x3) keep float32 tensors")
         self._h = ctypes.c_void_p()
-        code = (VINCE_F32X3 if self.x3 else VINCE_F32) if dtype == torch.float32 else VINCE_BF16
+        # x3 == "f": the mixed mode VINCE_F32X3F (split-half forward, single bfloat16 products in every gradient convolution)
+        code = ((VINCE_F32X3F if x3 == "f" else VINCE_F32X3) if self.x3 else VINCE_F32) if dtype == torch.float32 else VINCE_BF16
         check(L.vince_trunk_create(ctypes.byref(TrunkCfg(arch=ARCH_CODE[arch], N=N, H=H, W=W, dtype=code)),
                                    ctypes.byref(self._h)))
         self.ws_bytes = L.vince_trunk_workspace_bytes(self._h)

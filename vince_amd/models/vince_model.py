@@ -110,6 +110,9 @@ _ALIGN = 64  # floats; every tensor in the flat buffers starts on a 256-byte bou
 
 
 X3_NAMES = ("x3", "fp32x3", "f32x3")
+# "x3f": the x3 forward (embeddings and loss at the reference's 1e-3 bar) with every GRADIENT convolution as single bfloat16 products --
+# the arithmetic of a mixed-precision backward (what the reference's --use-apex would run) behind an fp32-grade forward
+X3F_NAMES = ("x3f",)
 
 
 def _compute_dtype(args):
@@ -119,9 +122,9 @@ def _compute_dtype(args):
     name = str(getattr(args, "compute_dtype", "fp32")).lower()
     if name in ("bf16", "bfloat16"):
         return torch.bfloat16
-    if name in ("fp32", "float32", "f32") + X3_NAMES:
+    if name in ("fp32", "float32", "f32") + X3_NAMES + X3F_NAMES:
         return torch.float32
-    raise ValueError("compute_dtype must be bf16, fp32 or x3, got %r" % name)
+    raise ValueError("compute_dtype must be bf16, fp32, x3 or x3f, got %r" % name)
 
 
 class _TransposedHeads(dict):
@@ -259,7 +262,8 @@ class VinceModel(BaseModel):
         super().__init__(args)
         self.args, self.num_frames = args, args.num_frames
         self.compute_dtype = _compute_dtype(args)
-        self.conv_x3 = str(getattr(args, "compute_dtype", "fp32")).lower() in X3_NAMES
+        self.conv_x3 = str(getattr(args, "compute_dtype", "fp32")).lower() in X3_NAMES + X3F_NAMES
+        self.conv_x3f = str(getattr(args, "compute_dtype", "fp32")).lower() in X3F_NAMES
 
         # Modules (vince_model.py:25-49).  Attribute names and nesting ARE the state-dict layout of the reference's checkpoints:
         # feature_extractor.*, embedding.{0,2}.*, jigsaw_linear.*, jigsaw_embedding.{0,2}.*, imagenet_decoders.{0,1.0,1.2}.*
@@ -424,7 +428,7 @@ class VinceModel(BaseModel):
         key = (n, h, w)
         t = self._trunks.get(key)
         if t is None:
-            t = Trunk(self.feature_extractor.arch, n, h, w, self.compute_dtype, x3=self.conv_x3)
+            t = Trunk(self.feature_extractor.arch, n, h, w, self.compute_dtype, x3=("f" if self.conv_x3f else self.conv_x3))
             self._trunks[key] = t
         return t
 

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BnReduce, BnTrain, ConvDesc, ConvEpi, InfoNCEDesc, VINCE_BF16, VINCE_F32, VINCE_F32X3B, VINCE_F32X3H, check, lib
+from ._lib import BnReduce, BnTrain, ConvDesc, ConvEpi, InfoNCEDesc, VINCE_BF16, VINCE_F32, VINCE_F32X1B, VINCE_F32X3B, VINCE_F32X3H, check, lib
 
 EPI_ACCUMULATE, EPI_RELU = _lib.EPI_ACCUMULATE, _lib.EPI_RELU
 STATS_REPLICAS = 16   # VINCE_STATS_REPLICAS in include/vince_hip.h
@@ -115,7 +115,7 @@ def bn_reduce_arg(y, mean, invstd, sums, mask_bits=None, mask_scale=None, mask_s
     return r
 
 
-X3_CODE = {None: None, "h": VINCE_F32X3H, "b": VINCE_F32X3B}
+X3_CODE = {None: None, "h": VINCE_F32X3H, "b": VINCE_F32X3B, "1": VINCE_F32X1B}    # "1": single bfloat16 products (gradient launches of x3f)
 
 
 def _conv_dtype(x, x3):

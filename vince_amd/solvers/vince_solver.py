@@ -111,9 +111,12 @@ class VinceSolver(BaseSolver):
             comm = None
             if self.model.device.type == "cuda":
                 # stream budget (include/vince_hip.h vince_set_side_streams): main, key encoder (= gradient all-reduce during
-                # backward), weight gradients, RCCL's own -- the downsample-branch stream gives its hardware queue away
+                # backward), weight gradients, downsample branch
                 from .._lib import lib
-                lib().vince_set_side_streams(int(os.environ.get("VINCE_DP_SIDE_STREAMS", "1")))   # (2: measurement, keeps the downsample stream)
+                # (round 6: decided by bench.py's `dp_forced_single_rank` leg -- single-rank RCCL group, one MI355X: 22.14 ms with the
+                # downsample stream kept against 22.40 without, 21.94 for the plain step; RCCL enqueues its kernels on the stream it is
+                # handed (the key-encoder stream here), so the process stays at four active streams.  1 = give the downsample stream up)
+                lib().vince_set_side_streams(int(os.environ.get("VINCE_DP_SIDE_STREAMS", "2")))
                 if self.overlap_key_encoder:
                     self._key_stream = _shared_key_stream(self.model.device)
                     comm = self._key_stream
