@@ -174,6 +174,10 @@ typedef struct vince_conv_epi {
      * launch (the input gradient of the BatchNorm-backward algebra: da = wd g + nq a, csrc/bn_algebra.hip).  Direct-to-LDS kernels only. */
     const void* in2;
     int32_t in2_channels;
+    /* Forward epilogue of fp32-store launches only (VINCE_F32 / VINCE_F32X3H, no split reduction): a bfloat16 SHADOW of `out` -- the
+     * same NHWC element offsets, every stored value also written rounded to bfloat16 (8 bytes per 16-byte chunk).  What the mixed mode
+     * "x3f" saves for its bf16 backward (vince_trunk_set_shadow).  NULL = none.  (ABI 11) */
+    void* out2;
 } vince_conv_epi;
 
 /* in/w/out have element type `dtype`.  epi may be NULL (plain store). */
@@ -297,6 +301,17 @@ typedef struct vince_bn_train {
                                    * this launch STORES (after ReLU, rounded to dtype), atomically accumulated -- the column sums
                                    * vince_bn_gram_finalize needs beside the Gram matrix of the same tensor */
     int32_t out_sum_replicas;
+    /* fp32 launches only: a bfloat16 shadow of `out` (same element offsets) and, instead of mask_out's fp32 format (one byte per 4
+     * channels), a mask in the BF16 format -- one byte per 8 channels, bit e = channel e of the chunk -- at mask_bf16.  Either may be
+     * NULL.  (vince_trunk_set_shadow; ABI 11) */
+    void* out_bf16;
+    uint8_t* mask_bf16;
+    /* ... and a bfloat16 shadow of the INPUT y, CENTRED: y - mean[c], rounded to bfloat16 (same element offsets), with the constants a
+     * backward over that shadow needs in shadow_consts = float[4][C]: scale, beta (= shift + mean * scale), 0 (the mean of the centred
+     * tensor), invstd.  A bf16 copy of the raw y would lose (y - mean) to cancellation wherever |mean| >> std; the centred one keeps
+     * 8 significand bits of the deviation itself.  Both NULL or both set. */
+    void* y_centred_bf16;
+    float* shadow_consts;
 } vince_bn_train;
 int vince_bn_train_apply(int dtype, const void* y, const vince_bn_train* bt, const void* identity, const float* id_scale,
                          const float* id_shift, void* out, uint8_t* mask_out, int64_t rows, int32_t C, int relu,
@@ -631,6 +646,15 @@ int vince_trunk_set_bucket_callback(vince_trunk_t t, void (*cb)(int32_t, void*),
  * touches the workspace; a caller that writes the staged input itself (vince_trunk_input_ptr) or frees / reuses the workspace for anything
  * else must wait for the event first.  Replacing or clearing the event while such a launch is pending drains it on the host. */
 int vince_trunk_set_stem_event(vince_trunk_t t, void* event);
+/* The mixed mode "x3f": an fp32-tensor trunk (VINCE_F32 / VINCE_F32X3 / VINCE_F32X3F) whose grad-enabled forwards ALSO leave everything a
+ * backward reads -- stem input, every convolution's raw output, every activation, block outputs, ReLU masks, pool argmax bytes,
+ * BatchNorm constants -- as bfloat16 in the workspace of a TWIN handle created with VINCE_BF16 for the same architecture and input
+ * shape (shadow_workspace: vince_trunk_workspace_bytes(shadow) bytes).  vince_trunk_backward is then called on the TWIN with its own
+ * bf16 weight cache: the forward keeps fp32-grade embeddings and loss, the backward runs the bf16 kernels on half the bytes -- the
+ * arithmetic of a mixed-precision (AMP) backward.  Costs the forward one extra 2-byte write per saved element.  NULL clears.  (ABI 11) */
+int vince_trunk_set_shadow(vince_trunk_t t, vince_trunk_t shadow, void* shadow_workspace);
+/* n floats -> n bfloat16 (round to nearest even); n multiple of 8, both pointers 16-byte aligned.  (ABI 11) */
+int vince_cast_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);
 /* Makes `stream` wait for a deferred stem weight gradient still in flight on this handle (no-op otherwise): for callers that write the
  * staged input themselves.  (ABI 11) */
 int vince_trunk_stem_join(vince_trunk_t t, void* stream);

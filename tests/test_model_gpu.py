@@ -479,6 +479,9 @@ def test_g13_config5_multiframe_jigsaw_vs_reference_golden(dtype, coin):
         return
     assert e_terms < 1e-3 and max(errs.values()) < 1e-3, (e_terms, errs)
     np.testing.assert_allclose([float(met[k]) for k in sorted(met)], g[p + "metrics"], rtol=2e-3, atol=2e-4)
+    if dtype == "x3f":    # the forward is x3's; the mixed-precision (bf16 twin engine) backward: sums of |g| at its own, AMP-grade bound
+        assert max(ratios.values()) < 4e-2, (max(ratios, key=ratios.get), max(ratios.values()))
+        return
     head = "jigsaw_embedding.2.weight" if coin == "q" else "embedding.2.weight"
     assert rel(named[head].grad[:8].cpu(), g[p + "grad_" + head]) < 5e-3
     early = ("feature_extractor.model.conv1", "feature_extractor.model.bn1", "feature_extractor.model.layer1")
@@ -1468,3 +1471,49 @@ def test_fill_queue_with_distinct_batches():
     # the key encoder is a hard copy of the encoder after the fill (param_update(model, 0))
     n = solver.model._n_ema
     assert torch.equal(solver.queue_model.queue_network._flat[:n], solver.model._flat[:n])
+
+
+def test_x3f_mixed_mode_forward_is_x3s_and_backward_runs_on_the_bf16_twin(monkeypatch):
+    """compute_dtype "x3f" (round 6): the forward IS x3's -- same kernels, bit-identical trunk features (the head's split-K GEMMs use fp32
+    atomics, so embeddings repeat to rounding only) -- and also leaves bfloat16 copies of what
+    backward reads in the workspace of a bf16 twin engine (engine.Trunk.set_shadow), which then runs the backward: gradients agree with
+    x3's in direction (cosine) and size at bf16 grade.  With VINCE_X3F_HYBRID=0 the backward stays on the fp32 tensors as single bfloat16
+    products; a second forward + backward reuses the twin."""
+    x = vo.structured_frames(8, 96, 96, seed=31).to(DEV)
+
+    def run(dtype, train=True, steps=1):
+        _, model = build("ResNet50", 128, dtype, 12)
+        model.train(train)
+        for _ in range(steps):
+            model.zero_grad()
+            o = model.get_embeddings({"data": x})
+            (o["embeddings"] * torch.linspace(-1, 1, 128, device=DEV)).sum().backward()
+        torch.cuda.synchronize()
+        return model, o["extracted_features"].detach().float().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()
+                                                               if p.grad is not None}
+
+    m3, e3, g3 = run("x3")
+    mf, ef, gf = run("x3f")
+    assert mf.x3f_hybrid and len(mf._twins) == 1 and mf._saved_ws_bf is not None and not m3._twins
+    assert torch.equal(e3, ef), "the x3f forward must be x3's to the bit"
+    assert sorted(g3) == sorted(gf)
+    worst = {}
+    for n in g3:
+        a, b = gf[n].double().flatten(), g3[n].double().flatten()
+        if float(b.abs().max()) == 0.0:      # (the unused fc)
+            assert float(a.abs().max()) == 0.0, n
+            continue
+        worst[n] = (float(a @ b / (a.norm() * b.norm())), abs(float(a.abs().sum() / b.abs().sum()) - 1.0))
+    lo = min(worst, key=lambda n: worst[n][0])
+    print("x3f vs x3 gradients (ResNet-50, 8 x 96 x 96): min cosine %.5f (%s), worst sum|g| ratio error %.2e" %
+          (worst[lo][0], lo, max(v[1] for v in worst.values())))
+    assert worst[lo][0] > 0.98 and max(v[1] for v in worst.values()) < 6e-2
+    # two steps: the twin and its workspace are reused, the stale-weight check of its bf16 cache sees the (unchanged) parameter version
+    mf2, ef2, gf2 = run("x3f", steps=2)
+    assert torch.equal(ef2, ef) and len(mf2._twins) == 1
+    # the switch: no twin, the fp32-tensor backward (single bfloat16 products) -- same forward, gradients at x3's bounds
+    n = "feature_extractor.model.layer3.2.conv2.weight"
+    monkeypatch.setenv("VINCE_X3F_HYBRID", "0")
+    mo, eo, go = run("x3f")
+    assert not mo.x3f_hybrid and not mo._twins and torch.equal(eo, e3)
+    assert rel(go[n], g3[n]) < 3e-2

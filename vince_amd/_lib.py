@@ -31,14 +31,15 @@ class BnReduce(ctypes.Structure):
 class ConvEpi(ctypes.Structure):
     _fields_ = [("flags", c_int32), ("bias", c_void_p), ("stats", c_void_p), ("acc_mask", c_void_p),
                 ("bnred", BnReduce), ("replicas", c_int32),
-                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p), ("out_mask", c_void_p), ("in2", c_void_p), ("in2_channels", c_int32)]
+                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p), ("out_mask", c_void_p), ("in2", c_void_p), ("in2_channels", c_int32), ("out2", c_void_p)]
 
 
 class BnTrain(ctypes.Structure):
     _fields_ = [("stats", c_void_p), ("replicas", c_int32), ("count", ctypes.c_int64), ("gamma", c_void_p), ("beta", c_void_p),
                 ("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p),
                 ("momentum", c_float), ("eps", c_float), ("scale", c_void_p), ("shift", c_void_p),
-                ("save_mean", c_void_p), ("save_invstd", c_void_p), ("out_sum", c_void_p), ("out_sum_replicas", c_int32)]
+                ("save_mean", c_void_p), ("save_invstd", c_void_p), ("out_sum", c_void_p), ("out_sum_replicas", c_int32),
+                ("out_bf16", c_void_p), ("mask_bf16", c_void_p), ("y_centred_bf16", c_void_p), ("shadow_consts", c_void_p)]
 
 
 class InfoNCEDesc(ctypes.Structure):
@@ -163,6 +164,8 @@ PROTOTYPES = {
     "vince_trunk_set_stem_event": (c_int, [c_void_p, c_void_p]),
     "vince_trunk_stem_join": (c_int, [c_void_p, c_void_p]),
     "vince_launch_count": (ctypes.c_int64, []),
+    "vince_trunk_set_shadow": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "vince_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "vince_trunk_prepare_weights_part": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "vince_trunk_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                      c_void_p]),

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                                                        T* __restrict__ out, uint8_t* __restrict__ mask_out, int64_t rows,
                                                        int C, int relu, RowWalk w, const vince_bn_train fin) {
     constexpr int CH = Elem<T>::CH;
-    __shared__ float cst[2][256 * CH];   // fused finalize: (scale, shift) of this block's channels
+    __shared__ float cst[sizeof(T) == 4 ? 3 : 2][256 * CH];   // fused finalize: (scale, shift[, mean: fp32 launches, for the centred shadow]) of this block's channels
     const int col = blockIdx.x * w.tpc + (threadIdx.x % w.tpc);
     if (fin.stats) {
         // train-mode finalize fused in (vince_bn_train_apply): every workgroup folds the statistic replicas of ITS channels
@@ -181,7 +181,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             const float shv = fin.beta[c] - mean * scv;
             cst[0][cl] = scv;
             cst[1][cl] = shv;
+            if constexpr (sizeof(T) == 4) cst[2][cl] = mean;
             if (blockIdx.y == 0) {
+                if constexpr (sizeof(T) == 4) {
+                    if (fin.shadow_consts) {   // what a backward over the CENTRED bf16 shadow of y needs (include/vince_hip.h)
+                        fin.shadow_consts[c] = scv;
+                        fin.shadow_consts[C + c] = fin.beta[c];
+                        fin.shadow_consts[2 * C + c] = 0.f;
+                        fin.shadow_consts[3 * C + c] = invstd;
+                    }
+                }
                 fin.scale[c] = scv;
                 fin.shift[c] = shv;
                 if (fin.save_mean) fin.save_mean[c] = mean;
@@ -199,12 +208,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     const bool want_sum = fin.out_sum != nullptr;   // uniform: per-channel sums of the stored values (vince_bn_gram_finalize)
     const bool active = col < w.cpr;
     if (!active && !want_sum) return;
-    float sc[CH], sh[CH], isc[CH], ish[CH], osum[CH];
+    float sc[CH], sh[CH], isc[CH], ish[CH], osum[CH], mu[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
         const int cl = (threadIdx.x % w.tpc) * CH + e;
         sc[e] = !active ? 0.f : (fin.stats ? cst[0][cl] : scale[col * CH + e]);
         sh[e] = !active ? 0.f : (fin.stats ? cst[1][cl] : shift[col * CH + e]);
+        if constexpr (sizeof(T) == 4) mu[e] = (active && fin.stats) ? cst[2][cl] : 0.f; else mu[e] = 0.f;
         isc[e] = (ids && active) ? ids[col * CH + e] : 1.f;
         ish[e] = (ids && active) ? idt[col * CH + e] : 0.f;
         osum[e] = 0.f;
@@ -231,6 +241,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             const size_t off = (size_t)r * C + (size_t)col * CH;
             float f[CH];
             Chunk<T>::unpack(yv[u], f);
+            if constexpr (sizeof(T) == 4) {
+                if (fin.y_centred_bf16)    // (uniform) y - mean, rounded to bfloat16: the backward's view of this BatchNorm's input
+                    *(uint2*)((bf16_t*)fin.y_centred_bf16 + off) = make_uint2(pack_bf16x2(f[0] - mu[0], f[1] - mu[1]), pack_bf16x2(f[2] - mu[2], f[3] - mu[3]));
+            }
 #pragma unroll
             for (int e = 0; e < CH; ++e) f[e] = f[e] * sc[e] + sh[e];
             if (idn) {
@@ -245,12 +259,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                 for (int e = 0; e < CH; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
                 mask_out[(size_t)r * w.cpr + col] = (uint8_t)b;
             }
+            if constexpr (sizeof(T) == 4) {
+                if (fin.mask_bf16) {   // (uniform) the same bits in the bf16 tensors' format: one byte per EIGHT channels -- two neighbouring chunks
+                    uint32_t b = 0;
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
+                    const uint32_t hi = __shfl_xor(b, 1, 64);        // (lanes col, col ^ 1 walk the same row: tpc is even, C % 8 == 0)
+                    if ((col & 1) == 0) fin.mask_bf16[(size_t)r * (w.cpr >> 1) + (col >> 1)] = (uint8_t)(b | (hi << 4));
+                }
+            }
             if (relu) {
 #pragma unroll
                 for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
             }
             const uint4 pv = Chunk<T>::pack(f);
             st16<(NT & 2) != 0>(out + off, pv);
+            if constexpr (sizeof(T) == 4) {
+                if (fin.out_bf16)      // (uniform) bfloat16 shadow of what was just stored
+                    *(uint2*)((bf16_t*)fin.out_bf16 + off) = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+            }
             if (want_sum) {   // sum what a reader of `out` will see (the rounded values)
                 float q[CH];
                 Chunk<T>::unpack(pv, q);
@@ -1021,6 +1048,10 @@ extern "C" int vince_bn_train_apply(int dtype, const void* y, const vince_bn_tra
                     "vince_bn_train_apply: stats, count, gamma, beta, scale and shift are required");
     VINCE_CHECK_ARG(!bt->running_mean == !bt->running_var, VINCE_E_ARG, "vince_bn_train_apply: running_mean and running_var come together");
     VINCE_CHECK_ARG(C % CH_OF(dtype) == 0, VINCE_E_SHAPE, "vince_bn_train_apply: C=%d not a multiple of %d", C, CH_OF(dtype));
+    VINCE_CHECK_ARG((!bt->out_bf16 && !bt->mask_bf16 && !bt->y_centred_bf16 && !bt->shadow_consts) ||
+                    (dtype == VINCE_F32 && C % 8 == 0 && ((uintptr_t)bt->out_bf16 & 15) == 0 && ((uintptr_t)bt->y_centred_bf16 & 15) == 0), VINCE_E_ARG,
+                    "vince_bn_train_apply: the bf16 shadows belong to an fp32 launch with C a multiple of 8");
+    VINCE_CHECK_ARG(!bt->y_centred_bf16 == !bt->shadow_consts, VINCE_E_ARG, "vince_bn_train_apply: y_centred_bf16 and shadow_consts come together");
     vince_bn_train fin = *bt;
     if (fin.replicas <= 0 || fin.replicas > VINCE_STATS_REPLICAS) fin.replicas = VINCE_STATS_REPLICAS;
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_target_blocks());

@@ -234,6 +234,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
                 }
                 v = Chunk<T>::pack(f);
             }
+            if constexpr (sizeof(T) == 4 && MODE == 0) {
+                if (p.e.out2) {   // (uniform) bfloat16 shadow of the stored value: what the mixed mode's bf16 backward reads
+                    *(uint2*)((bf16_t*)p.e.out2 + off[u]) =
+                        make_uint2(pack_bf16x2(__uint_as_float(v.x), __uint_as_float(v.y)), pack_bf16x2(__uint_as_float(v.z), __uint_as_float(v.w)));
+                }
+            }
             if constexpr (sizeof(T) == 4) {
                 if (p.kt_per_split > 0) {   // split-K partial: accumulate into the zeroed output
                     float f[CH];

@@ -34,6 +34,9 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     VINCE_CHECK_ARG(!e.out_mask || (!e.out_scale && !e.id_scale && !e.bnred.y), VINCE_E_ARG,
                     "vince_conv_igemm: out_mask belongs to the gradient epilogue and excludes bnred / the forward join");
     VINCE_CHECK_ARG(!e.id_scale == !e.id_shift, VINCE_E_ARG, "vince_conv_igemm: id_scale and id_shift come together");
+    VINCE_CHECK_ARG(!e.out2 || ((dtype == VINCE_F32 || dtype == VINCE_F32X3H) && !(e.flags & VINCE_EPI_ACCUMULATE) && !e.bnred.y && !e.out_mask &&
+                                !e.out_scale && !e.id_scale && ((uintptr_t)e.out2 & 15) == 0), VINCE_E_ARG,
+                    "vince_conv_igemm: out2 belongs to the forward epilogue of fp32-store launches");
     VINCE_CHECK_ARG((!e.out_scale && !e.id_scale) || ((e.flags & VINCE_EPI_ACCUMULATE) && !e.acc_mask && !e.bnred.y && !e.stats), VINCE_E_ARG,
                     "vince_conv_igemm: out_scale / id_scale need VINCE_EPI_ACCUMULATE and exclude acc_mask, bnred and stats");
     VINCE_CHECK_ARG(!e.bnred.mask_scale == !e.bnred.mask_shift, VINCE_E_ARG,

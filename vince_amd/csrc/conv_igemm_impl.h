@@ -612,7 +612,7 @@ int launch(ConvParams& p, hipStream_t stream) {
             int splits = 1;
             const long tiles = (long)p.ptiles * p.ctiles;
             static const bool splitk_env = (VINCE_MEASURE_KNOB("splitk", 1) != 0);
-            if (sizeof(T) == 4 && splitk_env && !BWD && !p.e.stats && tiles < 128 && p.nkt >= 16 &&
+            if (sizeof(T) == 4 && splitk_env && !BWD && !p.e.stats && !p.e.out2 && tiles < 128 && p.nkt >= 16 &&
                 p.d.osh == 1 && p.d.osw == 1 && p.d.OH == p.d.Ho && p.d.OW == p.d.Wo) {
                 static const long target = VINCE_MEASURE_KNOB("splitk_wgs", 256);   // (env: measurement aid) more splits cost more in atomics than they buy
                 splits = (int)min((long)(p.nkt / 8), (target + tiles - 1) / tiles);
@@ -711,7 +711,7 @@ int launch_x3(ConvParams& p, hipStream_t stream) {
             // products, 3 x 16-bit MFMAs per product against exact fp32 MFMAs at a sixteenth of that rate)
             const long tiles = (long)p.ptiles * p.ctiles;
             int splits = 1;
-            if (MODE == 0 && !p.e.stats && tiles < 128 && p.nkt >= 16 && p.d.osh == 1 && p.d.osw == 1 && p.d.OH == p.d.Ho && p.d.OW == p.d.Wo) {
+            if (MODE == 0 && !p.e.stats && !p.e.out2 && tiles < 128 && p.nkt >= 16 && p.d.osh == 1 && p.d.osw == 1 && p.d.OH == p.d.Ho && p.d.OW == p.d.Wo) {
                 splits = (int)min((long)(p.nkt / 8), (256 + tiles - 1) / tiles);
                 if (splits < 2) splits = 1;
             }

@@ -722,6 +722,32 @@ __global__ __launch_bounds__(256) void stream_copy_shape_kernel(const f32x4_t* _
 }
 }  // namespace
 
+namespace {
+// 8 floats -> 8 bfloat16 per thread and trip (two 16-byte loads, one 16-byte store), block-contiguous like the streaming copy
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n8) {
+    const size_t per = (n8 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n8 ? lo + per : n8;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint4 a = *(const uint4*)(src + i * 8), b = *(const uint4*)(src + i * 8 + 4);
+        *(uint4*)(dst + i * 8) = make_uint4(pack_bf16x2(__uint_as_float(a.x), __uint_as_float(a.y)), pack_bf16x2(__uint_as_float(a.z), __uint_as_float(a.w)),
+                                            pack_bf16x2(__uint_as_float(b.x), __uint_as_float(b.y)), pack_bf16x2(__uint_as_float(b.z), __uint_as_float(b.w)));
+    }
+}
+}  // namespace
+
+// The bf16 shadow of an fp32 tensor nobody's epilogue can write on the side (the staged stem input, the stem pool's output): the mixed
+// mode "x3f" (vince_trunk_set_shadow).
+extern "C" int vince_cast_f32_to_bf16(const float* src, void* dst, size_t n, void* stream) {
+    VINCE_CHECK_ARG(src && dst && n % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, VINCE_E_ARG,
+                    "vince_cast_f32_to_bf16: n multiple of 8, 16-byte aligned pointers");
+    if (!n) return VINCE_OK;
+    const size_t n8 = n / 8;
+    const unsigned blocks = (unsigned)(n8 < 2048 * 256 ? (n8 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n8);
+    VINCE_CHECK_LAUNCH();
+    return VINCE_OK;
+}
+
 extern "C" int vince_stream_copy(void* dst, const void* src, size_t bytes, int32_t blocks, int32_t nontemporal, void* stream) {
     VINCE_CHECK_ARG(dst && src && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0 && (bytes & 15) == 0, VINCE_E_ALIGN,
                     "vince_stream_copy: 16-byte granularity");

@@ -110,6 +110,9 @@ struct vince_trunk {
     // ... and while that launch may still be running it READS the stem input (off_x0), its dY ring slot and the weight-gradient scratch
     // of the workspace: every entry point that rewrites the workspace makes its stream wait for stem_event first (stem_join)
     bool stem_inflight = false;
+    // vince_trunk_set_shadow: the bf16 twin whose workspace this (fp32-tensor) handle's grad-enabled forwards also fill
+    vince_trunk* shadow = nullptr;
+    void* shadow_ws = nullptr;
 };
 
 namespace {
@@ -455,6 +458,19 @@ static int stem_join(vince_trunk* t, void* stream) {
     return VINCE_OK;
 }
 
+extern "C" int vince_trunk_set_shadow(vince_trunk_t t, vince_trunk_t sh, void* shadow_workspace) {
+    VINCE_CHECK_ARG(t, VINCE_E_ARG, "vince_trunk_set_shadow: null handle");
+    if (!sh) { t->shadow = nullptr; t->shadow_ws = nullptr; return VINCE_OK; }
+    VINCE_CHECK_ARG(shadow_workspace && ((uintptr_t)shadow_workspace & 255) == 0, VINCE_E_ALIGN, "vince_trunk_set_shadow: workspace must be 256-byte aligned");
+    VINCE_CHECK_ARG(t->sdtype == VINCE_F32 && sh->sdtype == VINCE_BF16 && sh->cf == VINCE_BF16, VINCE_E_DTYPE,
+                    "vince_trunk_set_shadow: an fp32-tensor handle shadows into a VINCE_BF16 twin");
+    VINCE_CHECK_ARG(sh->cfg.arch == t->cfg.arch && sh->cfg.N == t->cfg.N && sh->cfg.H == t->cfg.H && sh->cfg.W == t->cfg.W &&
+                    sh->blocks.size() == t->blocks.size() && sh->n_consts_floats == t->n_consts_floats, VINCE_E_SHAPE,
+                    "vince_trunk_set_shadow: the twin must be created for the same architecture and input shape");
+    t->shadow = sh;
+    t->shadow_ws = shadow_workspace;
+    return VINCE_OK;
+}
 extern "C" int vince_trunk_stem_join(vince_trunk_t t, void* stream) {
     VINCE_CHECK_ARG(t, VINCE_E_ARG, "vince_trunk_stem_join: null handle");
     return stem_join(t, stream);
@@ -525,16 +541,26 @@ struct Ctx {
 
 #define RC(expr) do { int _rc = (expr); if (_rc != VINCE_OK) return _rc; } while (0)
 
+// The twin's constants of one BatchNorm (float[4][C]: scale, shift, mean, invstd in ITS workspace), and a verbatim copy of this handle's
+// (the BatchNorms whose bf16 shadow is the RAW convolution output: the stem's and the downsample branches').
+float* twin_consts(vince_trunk* S, void* sw, const BnL& sbn) { return (float*)at(sw, S->off_consts) + sbn.consts; }
+int copy_consts(Ctx& c, const BnL& bn, vince_trunk* S, void* sw, const BnL& sbn) {
+    VINCE_CHECK_HIP(hipMemcpyAsync(twin_consts(S, sw, sbn), c.consts(bn, 0), (size_t)4 * bn.C * sizeof(float), hipMemcpyDeviceToDevice,
+                                   (hipStream_t)c.stream));
+    return VINCE_OK;
+}
+
 // conv (+ BatchNorm statistics in train mode).  finalize_now: also run the stand-alone finalize -- needed in eval mode and
 // where the consumer of scale / shift is not vince_bn_train_apply (the stem's pool, the downsample branch's identity
 // affine); everywhere else the finalize rides in the prologue of the apply pass (bn_apply_fwd below).
 int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_off, float* const* bn_running,
-                int64_t* const* bn_nbt, int train_bn, bool finalize_now, const vince_conv_desc* desc = nullptr) {
+                int64_t* const* bn_nbt, int train_bn, bool finalize_now, const vince_conv_desc* desc = nullptr, void* y2 = nullptr) {
     vince_conv_desc d = desc ? *desc : fwd_desc(c.t, cv);
     vince_conv_epi e;
     memset(&e, 0, sizeof(e));
     e.stats = train_bn ? c.stats(bn) : nullptr;
     e.replicas = bn.R;
+    e.out2 = y2;       // (fp32-tensor handles only: the bf16 twin's copy of this raw output, vince_trunk_set_shadow)
     // layer1's expand convolutions (64 -> 256, stride 1: conv3 of every block and the downsample conv) are pure HBM streams that
     // write 4x what they read: the persistent streaming kernel runs them at 4.2 TB/s (122 us) against the implicit-GEMM
     // kernel's 3.1 (166 us), statistics in registers for the whole launch.  At K = 128 (layer2) it does not win (half-line
@@ -569,7 +595,7 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
 // out = relu(bn(y) [+ identity affine]); in train mode the BatchNorm's finalize is fused into the same launch
 int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const void* idn, const float* ids, const float* idt,
                  void* out, uint8_t* mask_out, float* const* bn_running, int64_t* const* bn_nbt, int train_bn,
-                 double* out_sum = nullptr) {
+                 double* out_sum = nullptr, void* out2 = nullptr, uint8_t* mask2 = nullptr, void* y2c = nullptr, float* consts2 = nullptr) {
     const int64_t rows = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
     static const bool fuse_fin = (VINCE_MEASURE_KNOB("fuse_finalize", 1) != 0);
     if (!train_bn)
@@ -600,6 +626,10 @@ int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const voi
     bt.save_invstd = c.consts(bn, 3);
     bt.out_sum = out_sum;
     bt.out_sum_replicas = GRAM_R;
+    bt.out_bf16 = out2;
+    bt.mask_bf16 = mask2;
+    bt.y_centred_bf16 = y2c;
+    bt.shadow_consts = consts2;
     return vince_bn_train_apply(c.dtype, at(c.ws, y_off), &bt, idn, ids, idt, out, mask_out, rows, cv.Co, 1, c.stream);
 }
 
@@ -998,11 +1028,27 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
         RC(vince_input_nchw_to_rows(c.dtype, input, perm, at(workspace, t->off_x0), N, 3, t->cfg.H, t->cfg.W, t->sWp, STEM_LEFT,
                                     stream));
     }
+    // Mixed mode "x3f" (vince_trunk_set_shadow): a grad-enabled train-mode forward of this fp32-tensor handle also leaves everything the
+    // backward reads as bfloat16 in the twin's workspace -- raw convolution outputs and activations from the epilogues / passes that write
+    // them (one extra 2-byte store per element), the stem input and the pool output by a cast, ReLU masks and pool argmax bytes straight
+    // into the twin (this handle's own backward is not going to run), the BatchNorm constants by a copy at the end.
+    vince_trunk* const S = (save && t->shadow) ? t->shadow : nullptr;
+    void* const sw = t->shadow_ws;
+    if (S) {
+        RC(stem_join(S, stream));      // (the twin's deferred stem weight gradient may still be reading ITS workspace)
+        VINCE_CHECK_ARG(train_bn && stem_packed(), VINCE_E_UNSUPPORTED,
+                        "vince_trunk_forward: the bf16 shadow needs a train-mode forward and the packed stem layout");
+        RC(vince_cast_f32_to_bf16((const float*)at(workspace, t->off_x0), at(sw, S->off_x0), (size_t)N * t->cfg.H * t->sWp * STEM_CS, stream));
+    }
     const vince_conv_desc sd = stem_desc(t);
     // stem: conv 7x7/s2 -> BN -> ReLU -> maxpool 3x3/s2 (resnet.py:170-173); BN-apply + ReLU are fused into the pool
-    RC(conv_bn_fwd(c, t->stem, t->stem_bn, t->off_x0, t->off_ystem, bn_running, bn_nbt, train_bn, true, &sd));
+    RC(conv_bn_fwd(c, t->stem, t->stem_bn, t->off_x0, t->off_ystem, bn_running, bn_nbt, train_bn, true, &sd, S ? at(sw, S->off_ystem) : nullptr));
     RC(vince_stem_pool_fwd(c.dtype, at(workspace, t->off_ystem), c.consts(t->stem_bn, 0), c.consts(t->stem_bn, 1),
-                           at(workspace, t->off_p0), (uint8_t*)at(workspace, t->off_amax), N, t->sH, t->sW, 64, stream));
+                           at(workspace, t->off_p0), (uint8_t*)(S ? at(sw, S->off_amax) : at(workspace, t->off_amax)), N, t->sH, t->sW, 64, stream));
+    if (S) {
+        RC(vince_cast_f32_to_bf16((const float*)at(workspace, t->off_p0), at(sw, S->off_p0), (size_t)N * t->pH * t->pW * 64, stream));
+        RC(copy_consts(c, t->stem_bn, S, sw, S->stem_bn));
+    }
     // The forward downsample conv on its own stream is OPT-IN (VINCE_DS_STREAM_FWD=1): worth 0.1 ms when it happens to share a
     // hardware queue with another stream (GPU_MAX_HW_QUEUES=4, the default), but +4 ms when every stream gets its own queue
     // (two overlapped encoders x two streams each thrash) -- the mapping depends on stream creation order, so it is not relied on.
@@ -1011,7 +1057,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // mode 2: only a handle that already owns a downsample stream from an earlier backward (the query encoder's) uses it in
     // forward too -- no stream is created for it, the key encoder stays inline
     const bool ds_side = (ds_fwd_mode == 1 || (ds_fwd_mode == 2 && save && t->ds_stream)) && !vince_profile_enabled() &&
-                         vince_side_stream_budget() >= 2;
+                         vince_side_stream_budget() >= 2 && !(save && t->shadow);
     if (ds_side && !t->ds_stream) {
         RC(shared_stream(g_ds_stream, false, 0, &t->ds_stream));
         VINCE_CHECK_HIP(hipEventCreateWithFlags(&t->ev_ds_start, hipEventDisableTiming));
@@ -1049,6 +1095,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     bool conv1_done = false;  // block bi's conv1 (output + statistics) came out of block bi-1's join
     for (size_t bi = 0; bi < t->blocks.size(); ++bi) {
         const Blk& b = t->blocks[bi];
+        const Blk* const sb = S ? &S->blocks[bi] : nullptr;      // the twin's block: where the bf16 copies go
         const size_t x_in = cur;
         size_t in = x_in;
         const bool skip_conv1 = conv1_done;
@@ -1080,7 +1127,8 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
                     gram_done = true;
                 } else
                 RC(bn_apply_fwd(c, b.c[ci], b.b[ci], b.y[ci], nullptr, nullptr, nullptr, at(workspace, b.a[ci]), nullptr,
-                                bn_running, bn_nbt, train_bn, osum));
+                                bn_running, bn_nbt, train_bn, osum, sb ? at(sw, sb->a[ci]) : nullptr, nullptr,
+                                sb ? at(sw, sb->y[ci]) : nullptr, sb ? twin_consts(S, sw, sb->b[ci]) : nullptr));
                 in = b.a[ci];
             }
         }
@@ -1141,18 +1189,26 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             cur = out;
             continue;
         }
+        // (with a shadow the ReLU bits go to the twin alone, in ITS format -- one byte per 8 channels)
+        void* const z2 = sb ? at(sw, sb->z) : nullptr;
+        uint8_t* const zm2 = sb ? (uint8_t*)at(sw, sb->zmask) : nullptr;
+        uint8_t* const zm1 = sb ? nullptr : zmask;
+        void* const y2L = sb ? at(sw, sb->y[L]) : nullptr;       // the block's last BatchNorm: centred shadow of its input + the twin's constants
+        float* const c2L = sb ? twin_consts(S, sw, sb->b[L]) : nullptr;
         if (b.has_ds) {   // the downsample BatchNorm enters the join as an affine of its conv output: finalised on its own
             if (ds_side) VINCE_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, t->ev_ds_done, 0));
-            else RC(conv_bn_fwd(c, b.cd, b.bd, x_in, b.yd, bn_running, bn_nbt, train_bn, true));
+            else RC(conv_bn_fwd(c, b.cd, b.bd, x_in, b.yd, bn_running, bn_nbt, train_bn, true, nullptr, sb ? at(sw, sb->yd) : nullptr));
+            if (sb) RC(copy_consts(c, b.bd, S, sw, sb->bd));     // (the downsample BatchNorm: raw bf16 shadow from its epilogue, constants as they are)
             RC(bn_apply_fwd(c, b.c[L], b.b[L], b.y[L], at(workspace, b.yd), c.consts(b.bd, 0), c.consts(b.bd, 1),
-                            at(workspace, b.z), zmask, bn_running, bn_nbt, train_bn));
+                            at(workspace, b.z), zm1, bn_running, bn_nbt, train_bn, nullptr, z2, zm2, y2L, c2L));
         } else {
-            RC(bn_apply_fwd(c, b.c[L], b.b[L], b.y[L], at(workspace, x_in), nullptr, nullptr, at(workspace, b.z), zmask,
-                            bn_running, bn_nbt, train_bn));
+            RC(bn_apply_fwd(c, b.c[L], b.b[L], b.y[L], at(workspace, x_in), nullptr, nullptr, at(workspace, b.z), zm1,
+                            bn_running, bn_nbt, train_bn, nullptr, z2, zm2, y2L, c2L));
         }
         cur = b.z;
     }
     RC(vince_avgpool_fwd(c.dtype, at(workspace, t->blocks.back().z), pooled, N, t->outH * t->outW, t->outC, stream));
+    if (S) S->fwd_alg = false;     // its backward takes the separate BatchNorm-backward passes: conv3's (centred) raw outputs are all there
     return VINCE_OK;
 }
 

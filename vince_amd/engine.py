@@ -154,6 +154,15 @@ class Trunk:
                                          ctypes.c_void_p(workspace.data_ptr()), ctypes.c_void_p(dpooled.data_ptr()),
                                          grad_ptrs, blocks, events, n, ops.stream_ptr()))
 
+    def set_shadow(self, twin, workspace):
+        """The mixed mode "x3f": grad-enabled train-mode forwards of this fp32-tensor trunk also fill `workspace` (twin.ws_bytes) of the
+        bf16 `twin` (same arch / N / H / W) with everything a backward reads; twin.backward(...) then runs the bf16 kernels
+        (include/vince_hip.h vince_trunk_set_shadow).  twin None: off."""
+        if twin is None:
+            check(lib().vince_trunk_set_shadow(self._h, None, None))
+        else:
+            check(lib().vince_trunk_set_shadow(self._h, twin._h, ctypes.c_void_p(workspace.data_ptr())))
+
     def set_stem_event(self, event):
         """torch.cuda.Event (already recorded once, so its handle exists) or None: see include/vince_hip.h vince_trunk_set_stem_event."""
         check(lib().vince_trunk_set_stem_event(self._h, None if event is None else ctypes.c_void_p(event.cuda_event)))

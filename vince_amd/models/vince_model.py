@@ -288,6 +288,10 @@ class VinceModel(BaseModel):
         self._trunks = {}
         self._saved_ws = None
         self._wcache = None
+        # compute_dtype "x3f", train mode: the backward runs on a bf16 TWIN engine over bf16 copies the x3 forward leaves in the twin's
+        # workspace (engine.Trunk.set_shadow); VINCE_X3F_HYBRID=0: the fp32-tensor backward with single bfloat16 products instead
+        self._twins, self._saved_ws_bf, self._wcache_bf, self._wcache_bf_version = {}, None, None, 0
+        self.x3f_hybrid = self.conv_x3f and os.environ.get("VINCE_X3F_HYBRID", "1") != "0"
         self._saved = None
         self._fwd_generation = 0
         self._param_version, self._wcache_version = 1, 0
@@ -371,6 +375,7 @@ class VinceModel(BaseModel):
                 nbt.append(node.num_batches_tracked)
             self._bn_running_ptrs, self._bn_nbt_ptrs = pointer_table(run), pointer_table(nbt)
         self._trunks, self._saved_ws, self._wcache, self._saved = {}, None, None, None
+        self._twins, self._saved_ws_bf, self._wcache_bf, self._wcache_bf_version = {}, None, None, 0
         self._touch()
 
     def _apply(self, fn, *a, **k):
@@ -509,12 +514,28 @@ class VinceModel(BaseModel):
         else:
             trunk = self._trunk(n, h, w)
         self._ensure_weights(trunk)
+        twin = None
         if save:
             if self._saved_ws is None or self._saved_ws.numel() < trunk.ws_bytes:
                 self._saved_ws = None
                 self._saved_ws = torch.empty(trunk.ws_bytes, dtype=torch.uint8, device=self._flat.device)
             ws = self._saved_ws
             self._fwd_generation += 1
+            if self.x3f_hybrid and self.training:
+                # x3f: this forward also writes bf16 copies of what backward reads into the workspace of a bf16 twin engine
+                key = (trunk.N, trunk.H, trunk.W)
+                twin = self._twins.get(key)
+                if twin is None:
+                    twin = self._twins[key] = Trunk(self.feature_extractor.arch, trunk.N, trunk.H, trunk.W, torch.bfloat16)
+                if self._saved_ws_bf is None or self._saved_ws_bf.numel() < twin.ws_bytes:
+                    self._saved_ws_bf = None
+                    self._saved_ws_bf = torch.empty(twin.ws_bytes, dtype=torch.uint8, device=self._flat.device)
+                if self._wcache_bf is None:
+                    self._wcache_bf = torch.empty(twin.wc_bytes, dtype=torch.uint8, device=self._flat.device)
+                if self._wcache_bf_version != self._param_version:     # the bf16 weight copies its input / weight gradients multiply with
+                    twin.prepare_weights(self._param_ptrs, self._wcache_bf)
+                    self._wcache_bf_version = self._param_version
+                trunk.set_shadow(twin, self._saved_ws_bf)
         else:
             ws = nograd_workspace(self._flat.device, trunk.ws_bytes)
         nt = trunk.N
@@ -532,8 +553,12 @@ class VinceModel(BaseModel):
             self._ensure_folded_weights(trunk)
             trunk.forward_folded(self._wcache_folded, data, ws, pooled, jigsaw_src=(h, w) if jigsaw else None)
         else:
-            trunk.forward(self._param_ptrs, self._wcache, self._bn_running_ptrs, self._bn_nbt_ptrs, data, ws, pooled,
-                          train_bn=self.training, jigsaw_src=(h, w) if jigsaw else None, save=bool(save))
+            try:
+                trunk.forward(self._param_ptrs, self._wcache, self._bn_running_ptrs, self._bn_nbt_ptrs, data, ws, pooled,
+                              train_bn=self.training, jigsaw_src=(h, w) if jigsaw else None, save=bool(save))
+            finally:
+                if twin is not None:
+                    trunk.set_shadow(None, None)
             if self.training:
                 self._bn_version += 1   # running statistics moved
         # `spatial_features` is a copy by default: the workspace it lives in is rewritten by the next forward.  A caller that
@@ -553,7 +578,7 @@ class VinceModel(BaseModel):
         # (detached aliases: `pooled` and `pre` are also RETURNED through _EncodeFn, whose autograd node holds the model -- saving the
         # returned objects themselves would close a cycle model -> _saved -> tensor -> grad_fn -> ctx.model that Python's collector
         # cannot see through, and every discarded model would keep its workspaces: tens of GB per solver at the benchmark size)
-        saved = dict(trunk=trunk, pooled=pooled.detach(), jigsaw=jigsaw)
+        saved = dict(trunk=trunk, twin=twin, pooled=pooled.detach(), jigsaw=jigsaw)
         if with_head:
             hx3 = head_x3() and self.compute_dtype == torch.bfloat16
 
@@ -621,14 +646,16 @@ class VinceModel(BaseModel):
             return
         self._touched["trunk"] = True
         # data parallel: the reducer's hook runs inside the engine call, right after each bucket's event is recorded
-        s["trunk"].set_bucket_callback(self._bucket_hook if self._bucket_events else None)
+        # x3f: the bf16 twin runs the backward on the bf16 copies the forward left in ITS workspace, with its own bf16 weight cache
+        bt = s["twin"] if s.get("twin") is not None else s["trunk"]
+        bwc, bws = (self._wcache_bf, self._saved_ws_bf) if s.get("twin") is not None else (self._wcache, self._saved_ws)
+        bt.set_bucket_callback(self._bucket_hook if self._bucket_events else None)
         defer = self.defer_stem_join      # (with gradient buckets too: dp.GradientReducer.reduce_after_backward holds the last bucket back)
         if defer and self._stem_event is None:
             self._stem_event = torch.cuda.Event()
             self._stem_event.record()            # (torch creates the hipEvent lazily; the engine needs a live handle)
-        s["trunk"].set_stem_event(self._stem_event if defer else None)
-        s["trunk"].backward(self._param_ptrs, self._wcache, self._saved_ws, dpool_total.contiguous(), self._grad_ptrs,
-                            bucket_events=self._bucket_events)
+        bt.set_stem_event(self._stem_event if defer else None)
+        bt.backward(self._param_ptrs, bwc, bws, dpool_total.contiguous(), self._grad_ptrs, bucket_events=self._bucket_events)
         self._stem_pending = defer
 
     def finish_stem_grad(self):
