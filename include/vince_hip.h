@@ -178,6 +178,13 @@ typedef struct vince_conv_epi {
      * same NHWC element offsets, every stored value also written rounded to bfloat16 (8 bytes per 16-byte chunk).  What the mixed mode
      * "x3f" saves for its bf16 backward (vince_trunk_set_shadow).  NULL = none.  (ABI 11) */
     void* out2;
+    /* Forward residual join (out_scale / id_scale epilogue) of an fp32-store launch, for the same purpose: raw2 = bfloat16 of the RAW
+     * convolution output minus raw2_mean[c] (the centred input of the BatchNorm this epilogue applies: what a backward over the shadow
+     * reads, see vince_bn_train.y_centred_bf16), and mask2 = the ReLU bits of the stored value in the bf16 tensors' format (one byte per
+     * 8 channels).  out2 is allowed there too (the bf16 copy of the joined output).  raw2 and raw2_mean come together.  (ABI 11) */
+    void* raw2;
+    const float* raw2_mean;
+    uint8_t* mask2;
 } vince_conv_epi;
 
 /* in/w/out have element type `dtype`.  epi may be NULL (plain store). */

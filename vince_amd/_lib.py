@@ -31,7 +31,8 @@ class BnReduce(ctypes.Structure):
 class ConvEpi(ctypes.Structure):
     _fields_ = [("flags", c_int32), ("bias", c_void_p), ("stats", c_void_p), ("acc_mask", c_void_p),
                 ("bnred", BnReduce), ("replicas", c_int32),
-                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p), ("out_mask", c_void_p), ("in2", c_void_p), ("in2_channels", c_int32), ("out2", c_void_p)]
+                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p), ("out_mask", c_void_p), ("in2", c_void_p), ("in2_channels", c_int32), ("out2", c_void_p),
+                ("raw2", c_void_p), ("raw2_mean", c_void_p), ("mask2", c_void_p)]
 
 
 class BnTrain(ctypes.Structure):

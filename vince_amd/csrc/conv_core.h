@@ -130,6 +130,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
             ish_v[e] = (id_affine && cvalid) ? p.e.id_shift[cbase + e] : 0.f;
         }
     }
+    float rmu_v[CH];
+    if constexpr (sizeof(T) == 4 && JOIN) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) rmu_v[e] = (p.e.raw2 && cvalid) ? p.e.raw2_mean[cbase + e] : 0.f;
+    }
     float ssum[CH], ssq[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) ssum[e] = ssq[e] = 0.f;
@@ -197,6 +202,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
             if (!ok[u]) continue;
             const int row = row0 + (rb + u) * RPP;
             uint4 v = *(const uint4*)(smem + row * CRS + chunk * 16);
+            if constexpr (sizeof(T) == 4 && JOIN) {
+                if (p.e.raw2) {   // (uniform) the raw convolution output, centred, as bfloat16: the backward's view of the BatchNorm applied below
+                    *(uint2*)((bf16_t*)p.e.raw2 + off[u]) =
+                        make_uint2(pack_bf16x2(__uint_as_float(v.x) - rmu_v[0], __uint_as_float(v.y) - rmu_v[1]),
+                                   pack_bf16x2(__uint_as_float(v.z) - rmu_v[2], __uint_as_float(v.w) - rmu_v[3]));
+                }
+            }
             if (touch) {
                 float f[CH];
                 Chunk<T>::unpack(v, f);
@@ -228,13 +240,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
                         for (int e = 0; e < CH; ++e) f[e] = ((om[u] >> e) & 1u) ? f[e] : 0.f;
                     }
                 }
+                if constexpr (sizeof(T) == 4 && JOIN) {
+                    if (p.e.mask2) {   // (uniform) ReLU bits in the bf16 tensors' format: one byte per 8 channels = two neighbouring chunks
+                        uint32_t b = 0;
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
+                        const uint32_t hi = __shfl_xor(b, 1, 64);      // (chunks c, c ^ 1 of one row sit in neighbouring lanes: CPR is even)
+                        if ((chunk & 1) == 0) p.e.mask2[off[u] >> 3] = (uint8_t)(b | (hi << 4));
+                    }
+                }
                 if (flags & VINCE_EPI_RELU) {
 #pragma unroll
                     for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
                 }
                 v = Chunk<T>::pack(f);
             }
-            if constexpr (sizeof(T) == 4 && MODE == 0) {
+            if constexpr (sizeof(T) == 4 && (MODE == 0 || JOIN)) {
                 if (p.e.out2) {   // (uniform) bfloat16 shadow of the stored value: what the mixed mode's bf16 backward reads
                     *(uint2*)((bf16_t*)p.e.out2 + off[u]) =
                         make_uint2(pack_bf16x2(__uint_as_float(v.x), __uint_as_float(v.y)), pack_bf16x2(__uint_as_float(v.z), __uint_as_float(v.w)));

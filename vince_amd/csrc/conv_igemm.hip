@@ -34,9 +34,15 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     VINCE_CHECK_ARG(!e.out_mask || (!e.out_scale && !e.id_scale && !e.bnred.y), VINCE_E_ARG,
                     "vince_conv_igemm: out_mask belongs to the gradient epilogue and excludes bnred / the forward join");
     VINCE_CHECK_ARG(!e.id_scale == !e.id_shift, VINCE_E_ARG, "vince_conv_igemm: id_scale and id_shift come together");
-    VINCE_CHECK_ARG(!e.out2 || ((dtype == VINCE_F32 || dtype == VINCE_F32X3H) && !(e.flags & VINCE_EPI_ACCUMULATE) && !e.bnred.y && !e.out_mask &&
-                                !e.out_scale && !e.id_scale && ((uintptr_t)e.out2 & 15) == 0), VINCE_E_ARG,
-                    "vince_conv_igemm: out2 belongs to the forward epilogue of fp32-store launches");
+    {
+        const bool fwd_join = e.out_scale || e.id_scale;
+        VINCE_CHECK_ARG(!(e.out2 || e.raw2 || e.mask2) ||
+                        ((dtype == VINCE_F32 || dtype == VINCE_F32X3H) && !e.bnred.y && !e.out_mask && !e.acc_mask && ((uintptr_t)e.out2 & 15) == 0 &&
+                         ((uintptr_t)e.raw2 & 15) == 0 && (fwd_join || !(e.flags & VINCE_EPI_ACCUMULATE)) && dd->Co % 8 == 0), VINCE_E_ARG,
+                        "vince_conv_igemm: the bf16 shadows (out2 / raw2 / mask2) belong to the forward epilogues of fp32-store launches");
+        VINCE_CHECK_ARG((!e.raw2 && !e.mask2) || fwd_join, VINCE_E_ARG, "vince_conv_igemm: raw2 / mask2 belong to the forward residual join");
+        VINCE_CHECK_ARG(!e.raw2 == !e.raw2_mean, VINCE_E_ARG, "vince_conv_igemm: raw2 and raw2_mean come together");
+    }
     VINCE_CHECK_ARG((!e.out_scale && !e.id_scale) || ((e.flags & VINCE_EPI_ACCUMULATE) && !e.acc_mask && !e.bnred.y && !e.stats), VINCE_E_ARG,
                     "vince_conv_igemm: out_scale / id_scale need VINCE_EPI_ACCUMULATE and exclude acc_mask, bnred and stats");
     VINCE_CHECK_ARG(!e.bnred.mask_scale == !e.bnred.mask_shift, VINCE_E_ARG,

@@ -541,6 +541,17 @@ struct Ctx {
 
 #define RC(expr) do { int _rc = (expr); if (_rc != VINCE_OK) return _rc; } while (0)
 
+// scale / shift / mean / invstd of a BatchNorm -> what a backward over the CENTRED bf16 shadow of its input needs: scale, beta, 0, invstd
+__global__ void centre_consts_kernel(const float* __restrict__ src, float* __restrict__ dst, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = src[c], sh = src[C + c], mu = src[2 * C + c];
+    dst[c] = sc;
+    dst[C + c] = sh + mu * sc;
+    dst[2 * C + c] = 0.f;
+    dst[3 * C + c] = src[3 * C + c];
+}
+
 // The twin's constants of one BatchNorm (float[4][C]: scale, shift, mean, invstd in ITS workspace), and a verbatim copy of this handle's
 // (the BatchNorms whose bf16 shadow is the RAW convolution output: the stem's and the downsample branches').
 float* twin_consts(vince_trunk* S, void* sw, const BnL& sbn) { return (float*)at(sw, S->off_consts) + sbn.consts; }
@@ -1084,7 +1095,11 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     const bool gram_train = gram_env && xjoin_env && (alg_fwd || (vince_knob_live("gram_train", 0) == 1)) &&
                             train_bn && save && !ds_side && c.dtype == VINCE_BF16;
     if (save) t->fwd_alg = alg_fwd;
-    const bool gram_on = gram_nograd || gram_train;
+    // Mixed mode (shadow S): the grad-enabled forward takes the no-grad Gram route too -- conv3 + bn3 + join in one launch, IN PLACE on the
+    // fp32 identity (nothing reads it again: the twin holds its bf16 copy) -- with the twin's copies (conv3's output centred, the block
+    // output, the ReLU bits) written by that epilogue.  `gram_shadow=0`: the separate passes (cross-check switch).
+    const bool gram_shadow = gram_env && train_bn && save && S != nullptr && !ds_side && vince_knob_live("gram_shadow", 1) != 0;
+    const bool gram_on = gram_nograd || gram_train || gram_shadow;
     const bool gram_fused = vince_knob_live("gram_fused", 1) != 0;
     if (gram_on && t->gram_bytes)
         RC(vince_zero_async(at(workspace, t->off_gram), t->gram_bytes, stream));
@@ -1103,7 +1118,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
         const bool xj_ok = xjoin_env && c.dtype == VINCE_BF16 && b.nconv == 3 && (b.c[2].Ci == 64 || b.c[2].Ci == 128) &&
                            b.c[2].Co % 256 == 0 &&
                            (unsigned long long)t->cfg.N * b.c[2].Hi * b.c[2].Wi * b.c[2].Ci * 2 < 0x7ff00000ull;   // 31-bit descriptor offsets
-        const bool gram_blk = b.gram != NONE && ((gram_nograd && bi + 1 < t->blocks.size()) || (gram_train && xj_ok));
+        const bool gram_blk = b.gram != NONE && (((gram_nograd || gram_shadow) && bi + 1 < t->blocks.size()) || (gram_train && xj_ok));
         if (b.has_ds && ds_side) {
             Ctx cd = c;
             cd.stream = (void*)t->ds_stream;
@@ -1157,12 +1172,22 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             e.bias = c.consts(bn, 1);
             size_t idn = x_in, out = x_in;     // no-grad, identity blocks: the join lands on the block input, in place
             if (b.has_ds) {                    // stage entry: on the downsample conv's raw output, read through its BatchNorm affine
-                RC(conv_bn_fwd(c, b.cd, b.bd, x_in, b.yd, bn_running, bn_nbt, train_bn, true));
+                RC(conv_bn_fwd(c, b.cd, b.bd, x_in, b.yd, bn_running, bn_nbt, train_bn, true, nullptr, sb ? at(sw, sb->yd) : nullptr));
+                if (sb) RC(copy_consts(c, b.bd, S, sw, sb->bd));
                 e.id_scale = c.consts(b.bd, 0);
                 e.id_shift = c.consts(b.bd, 1);
                 idn = out = b.yd;
             }
-            if (save) out = b.z;               // backward reads the identity tensors again: nothing in place
+            if (save && !gram_shadow) out = b.z;   // backward reads the identity tensors again: nothing in place
+            if (gram_shadow) {                 // the twin's view of this block's tail (its backward runs the separate BatchNorm-backward passes)
+                e.out2 = at(sw, sb->z);
+                e.raw2 = at(sw, sb->y[L]);
+                e.raw2_mean = c.consts(bn, 2);
+                e.mask2 = (uint8_t*)at(sw, sb->zmask);
+                hipLaunchKernelGGL(centre_consts_kernel, dim3((bn.C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                                   (const float*)c.consts(bn, 0), twin_consts(S, sw, sb->b[L]), bn.C);
+                VINCE_CHECK_LAUNCH();
+            }
             // bf16 at K = 64 / 128: the persistent streaming kernel (csrc/conv_xjoin.hip); otherwise the implicit-GEMM kernel's join
             // epilogue (fp32, or VINCE_XJOIN=0 as a cross-check; no-grad forwards only)
             const Blk* nb = bi + 1 < t->blocks.size() ? &t->blocks[bi + 1] : nullptr;
