@@ -22,7 +22,13 @@ Extra legs (rank 0, N=1 only unless --no-extras):
   x3_step / fp32_step   the same step with fp32 tensors: convolutions as split-half products (compute_dtype "x3": the mode
                 that meets the reference's 1e-3 bar, priced against 2.5 PF / 3 -- three half-precision MFMAs per product)
                 and as exact fp32 MFMAs (157 TF/s); each with its own forward + InfoNCE time (dtype-matched roofs).
-  c2_step / c5_step     BASELINE config 2 and config 5's per-GPU work.
+  x3f_step      the x3 forward (the same bar on embeddings and loss) with a mixed-precision backward: the bf16 engine on bfloat16
+                copies of the saved tensors (compute_dtype "x3f", round 6); priced against 2.5 PF / 2.
+  c2_step / c2_x3_step / c2_x3f_step / c5_step     BASELINE config 2 and config 5's per-GPU work.
+  blocks / steady_state   per-block ms per step of 5 x 20 steps (device events at the block boundaries): min / median / max.
+  launches_per_step       kernel launches of the library per step, counted by the library over the timed loop.
+  dp_forced_single_rank   the step through the data-parallel path on one GPU (single-rank RCCL group), engine side streams 1 / 2,
+                and one traced step's gradient-bucket communication slots relative to the start of backward.
   cpu_baseline  the CPU oracle (oracle/vince_oracle.py, a torch-CPU restatement pinned to the reference) timed on the
                 host cores at B=16 for a few steps.
 """
@@ -663,7 +669,7 @@ def main():
             with contextlib.redirect_stdout(sys.stderr):
                 s2 = VinceSolver(a2)
                 s2.reset_epoch()
-            for _ in range(2):
+            for _ in range(3):
                 s2.run_train_iteration()
             barrier()
             t2 = time.perf_counter()
@@ -774,7 +780,7 @@ def main():
                 out["dp_forced_single_rank"] = {"error": repr(e)}
         if opt.fp32_steps > 0 and opt.dtype not in ("x3", "x3f") and is_c3:
             try:
-                out["x3_step"] = dict(step_leg(opt.fp32_steps, gflop_backbone=opt.backbone, fwd_too=True, compute_dtype="x3"),
+                out["x3_step"] = dict(step_leg(max(10, opt.fp32_steps), gflop_backbone=opt.backbone, fwd_too=True, compute_dtype="x3"),
                                       what="fp32 tensors, convolutions as split-half products (f16 hi/lo forward, bf16 hi/lo gradients): the "
                                            "parity mode -- embeddings and loss within 1e-3 of the fp32 reference (tests at the bar: G3, G9, "
                                            "G11c, G12); mfma_frac against 2.5 PF / 3")
@@ -782,7 +788,7 @@ def main():
                 out["x3_step"] = {"error": repr(e)}
         if opt.fp32_steps > 0 and opt.dtype not in ("x3", "x3f") and is_c3:
             try:
-                out["x3f_step"] = dict(step_leg(opt.fp32_steps, gflop_backbone=opt.backbone, compute_dtype="x3f"),
+                out["x3f_step"] = dict(step_leg(max(10, opt.fp32_steps), gflop_backbone=opt.backbone, compute_dtype="x3f"),
                                        what="mixed precision: the x3 forward (embeddings, keys and loss at the reference's 1e-3 bar -- the same "
                                             "forward kernels, bit-identical trunk features) also leaves bfloat16 copies of what backward reads "
                                             "(BatchNorm inputs centred) in the workspace of a bf16 twin engine, which runs the backward: the "
@@ -812,6 +818,12 @@ def main():
                                                   "the fp32 MFMA rate; mfma_frac against 2.5 PF / 3")
             except Exception as e:
                 out["c2_x3_step"] = {"error": repr(e)}
+            try:
+                out["c2_x3f_step"] = dict(step_leg(opt.config_steps, gflop_backbone="ResNet18", backbone="ResNet18", compute_dtype="x3f",
+                                                   vince_queue_size=4096, vince_embedding_size=64, vince_temperature=0.07),
+                                          workload="BASELINE config 2 in the mixed mode: x3 forward (fp32-grade embeddings and loss: G14), bf16 twin backward")
+            except Exception as e:
+                out["c2_x3f_step"] = {"error": repr(e)}
             try:
                 random.seed(1234 + rank)
                 out["c5_step"] = dict(step_leg(opt.config_steps, frames=4, gflop_backbone=opt.backbone, num_frames=4, inter_batch_comparison=True,

@@ -33,10 +33,14 @@ cat $O/pmc_summary.txt | head -12
 bash tools/aug_profile.sh > /dev/null 2>&1; cp gpurun_out/aug_kstats.txt $O/input_stage_kernel_stats.txt
 timeout 300 python bench.py --no-extras --input u8aug > $O/bench_u8aug.json 2>/dev/null
 timeout 20 python tools/bench_brief.py $O/bench_u8aug.json u8aug
-# ---- round 4: the split-half mode (x3), the forward-only PMC pass, the copy ceilings
-bash tools/x3_profile.sh final_x3 > /dev/null 2>&1; cp gpurun_out/final_x3/kernel_stats_serialised.txt $O/x3_kernel_stats_serialised.txt; cp gpurun_out/final_x3/bench.json $O/x3_bench.json
-# (round 5: the x3 step profiled like the product -- per-layer roofline against 2.5 PF / 3, HBM bytes per step and family by PMC)
+# ---- the split-half modes: x3 (strict parity) and x3f (x3 forward + bf16 twin backward), each profiled like the product
+bash tools/x3_profile.sh final_x3 x3 > /dev/null 2>&1; cp gpurun_out/final_x3/kernel_stats_serialised.txt $O/x3_kernel_stats_serialised.txt; cp gpurun_out/final_x3/bench.json $O/x3_bench.json
 cp gpurun_out/final_x3/layer_roofline.txt $O/x3_layer_roofline.txt; cp gpurun_out/final_x3/pmc_summary.txt $O/x3_pmc_summary.txt
+bash tools/x3_profile.sh final_x3f x3f > /dev/null 2>&1; cp gpurun_out/final_x3f/kernel_stats_serialised.txt $O/x3f_kernel_stats_serialised.txt; cp gpurun_out/final_x3f/bench.json $O/x3f_bench.json
+cp gpurun_out/final_x3f/layer_roofline.txt $O/x3f_layer_roofline.txt; cp gpurun_out/final_x3f/pmc_summary.txt $O/x3f_pmc_summary.txt
+timeout 900 python tools/x3f_check.py g9 g12 g14 2>&1 | cut -c1-420 > $O/x3f_gradients_vs_reference.txt
+X3_MODES=x3,x1,bf16 X3_OPS=dgrad,wgrad timeout 300 python tools/x3_micro.py x1b 2>&1 | grep -v amdgpu > $O/x1b_micro.txt
+./tools/micro/mfma_micro > $O/mfma_micro.txt 2>&1
 timeout 300 python tools/x3_micro.py final > $O/x3_micro.txt 2>&1
 bash tools/fwd_pmc.sh $O/fwd_pmc > /dev/null 2>&1; cp $O/fwd_pmc/fwd_pmc_summary.txt $O/fwd_pmc_summary.txt
 timeout 300 python tools/ceilings.py > $O/ceilings.txt 2>&1
@@ -44,12 +48,14 @@ timeout 120 python tools/strip_dgrad_micro.py > $O/strip_dgrad_micro.txt 2>&1
 timeout 300 python tools/xjoin_micro.py > $O/xjoin_micro.txt 2>&1
 timeout 200 python tools/dgrad_epi_micro.py > $O/dgrad_epi_micro.txt 2>&1
 # the full-size parity fixtures, with what each dtype measured against the reference printed (G9, G12: fp32 / x3 / bf16)
-timeout 1500 python -m pytest tests/test_full_size_gpu.py -q -s -k "g9 or g12" 2>&1 | grep -E "G9|G12|passed|failed" | cut -c1-600 > $O/full_size_parity.txt
+timeout 1800 python -m pytest tests/test_full_size_gpu.py -q -s -k "g9 or g12 or g14 or serialised" 2>&1 | grep -E "G9|G12|G14|serialised vs|passed|failed" | cut -c1-600 > $O/full_size_parity.txt
 # ---- round 5: where the step's time is without a profiler, the grouped-launch bound, the same-box A/B of the round's switches
 timeout 300 python tools/step_phases.py 20 bf16 2>/dev/null | tail -1 > $O/step_phases.txt
 timeout 300 python tools/step_phases.py 10 x3 2>/dev/null | tail -1 >> $O/step_phases.txt
+timeout 300 python tools/step_phases.py 10 x3f 2>/dev/null | tail -1 >> $O/step_phases.txt
 timeout 400 python tools/group_bound.py 256 10 2>/dev/null | tail -2 > $O/group_bound.txt
-timeout 1500 python tools/ab.py 3 40 "BASE" "VINCE_DEFER_STEM=1" "VINCE_KNOBS=xjoin_next=0" "VINCE_KNOBS=bn_nt=0" "VINCE_KNOBS=xjoin_next=0,bn_nt=0" "VINCE_DEFER_STEM=0" "VINCE_HEAD_X3=0" > $O/ab.txt 2>&1
+timeout 900 python tools/ab.py 3 40 "VINCE_DEFER_STEM=1" "VINCE_DEFER_STEM=0" "VINCE_KNOBS=xjoin_next=0" > $O/ab.txt 2>&1
+AB_ARGS="--dtype x3f" timeout 900 python tools/ab.py 2 20 "VINCE_KNOBS=" "VINCE_KNOBS=gram_shadow=0" "VINCE_X3F_HYBRID=0" >> $O/ab.txt 2>&1
 export VINCE_GIT_HEAD=${VINCE_GIT_HEAD:-unknown}
 # the bench line once more, now that profiles/pmc_conv_igemm.json of THIS build exists (traffic_stale false)
 cp $O/pmc_conv_igemm.json profiles/pmc_conv_igemm.json
