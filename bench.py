@@ -90,14 +90,23 @@ class PooledFrames:
 class stdout_to_stderr:
     """RCCL prints a version banner on the C-level stdout when a communicator is created: keep fd 1 clean for the one JSON line."""
 
+    @staticmethod
+    def _flush_c():
+        try:
+            ctypes.CDLL(None).fflush(None)      # RCCL printf()s into the C library's buffer: it must drain while fd 1 still points away
+        except Exception:
+            pass
+
     def __enter__(self):
         sys.stdout.flush()
+        self._flush_c()
         self.saved = os.dup(1)
         os.dup2(2, 1)
         return self
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        self._flush_c()
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False

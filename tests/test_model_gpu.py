@@ -1524,3 +1524,14 @@ def test_x3f_mixed_mode_forward_is_x3s_and_backward_runs_on_the_bf16_twin(monkey
     mo, eo, go = run("x3f")
     assert not mo.x3f_hybrid and not mo._twins and torch.equal(eo, e3)      # (no twin, no shadow: x3's own grad-enabled forward)
     assert rel(go[n], g3[n]) < 3e-2
+
+
+def test_backward_through_an_eval_mode_forward_is_refused():
+    """The engine's BatchNorm backward is the train-mode one; through an eval-mode (running-statistics) forward it would be the wrong
+    function (and overflows on unnormalised inputs: found in round 6).  Refused loudly; the head alone (detached features) still trains."""
+    _, model = build("ResNet18", 64, "fp32", 12)
+    model.eval()
+    x = vo.structured_frames(4, 64, 64, seed=5).to(DEV)
+    o = model.get_embeddings({"data": x})
+    with pytest.raises(RuntimeError, match="eval-mode trunk forward"):
+        o["embeddings"].sum().backward()

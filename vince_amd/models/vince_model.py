@@ -455,12 +455,16 @@ class VinceModel(BaseModel):
         if self._wcache is None or not self._trunks or os.environ.get("VINCE_EARLY_PREP", "1") == "0":   # (=0: A/B measurements)
             return False
         next(iter(self._trunks.values())).prepare_weights(self._param_ptrs, self._wcache, part=part)
+        if self._twins and self._wcache_bf is not None:      # x3f: the bf16 twin's cache (what its backward multiplies with) in the same two parts
+            next(iter(self._twins.values())).prepare_weights(self._param_ptrs, self._wcache_bf, part=part)
         return True
 
     def weights_current(self):
         self._head_t = _TransposedHeads(self._head_params)
         self._head_c = _HeadCopies(self._head_params)
         self._wcache_version = self._param_version
+        if self._twins and self._wcache_bf is not None:
+            self._wcache_bf_version = self._param_version
 
     def _ensure_folded_weights(self, trunk):
         """Inference cache: BatchNorms folded into the conv weights (eval mode only).  Rebuilt when parameters change
@@ -578,7 +582,7 @@ class VinceModel(BaseModel):
         # (detached aliases: `pooled` and `pre` are also RETURNED through _EncodeFn, whose autograd node holds the model -- saving the
         # returned objects themselves would close a cycle model -> _saved -> tensor -> grad_fn -> ctx.model that Python's collector
         # cannot see through, and every discarded model would keep its workspaces: tens of GB per solver at the benchmark size)
-        saved = dict(trunk=trunk, twin=twin, pooled=pooled.detach(), jigsaw=jigsaw)
+        saved = dict(trunk=trunk, twin=twin, pooled=pooled.detach(), jigsaw=jigsaw, train_bn=bool(self.training))
         if with_head:
             hx3 = head_x3() and self.compute_dtype == torch.bfloat16
 
@@ -644,6 +648,13 @@ class VinceModel(BaseModel):
             dpool_total = dp if dpool_total is None else dpool_total + dp
         if dpool_total is None:
             return
+        if not s.get("train_bn", True):
+            # The engine's BatchNorm backward is the TRAIN-mode one (batch statistics: dy = s (g - mean g - xhat mean(g xhat))); through an
+            # eval-mode forward (running statistics) autograd's is dy = s g.  Found in round 6: the train-mode formula on unnormalised
+            # inputs overflows within a few layers.  Outside the hot path (the reference trains in train mode, solvers/vince_solver.py:386):
+            # refused, not approximated.
+            raise RuntimeError("VinceModel: backward through an eval-mode trunk forward is not supported (BatchNorm backward with running "
+                               "statistics); call model.train() before the forward, or detach the features")
         self._touched["trunk"] = True
         # data parallel: the reducer's hook runs inside the engine call, right after each bucket's event is recorded
         # x3f: the bf16 twin runs the backward on the bf16 copies the forward left in ITS workspace, with its own bf16 weight cache
