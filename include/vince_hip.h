@@ -124,6 +124,11 @@ typedef struct vince_conv_desc {
 /* epilogue flags */
 #define VINCE_EPI_ACCUMULATE 1 /* out = result + out (residual-gradient add); with acc_mask: out = result + out*mask */
 #define VINCE_EPI_RELU 2       /* max(.,0) last */
+/* VINCE_F32X3H launches only: `in` holds its elements as stored IEEE-half PAIRS (vince_bn_train.out_half_pairs writes that format) --
+ * per 16 consecutive channels (64 bytes) four 16-byte chunks [hi e0-3,e8-11][hi e4-7,e12-15][lo e0-3,e8-11][lo e4-7,e12-15] of
+ * x * 2^4, the very halves the kernel would split the fp32 element into -- so the main loop multiplies them as they are: no split
+ * instructions (15-17 % of a 3x3 layer), bit-identical results.  Ci multiple of 16; direct-to-LDS kernels only.  (ABI 11) */
+#define VINCE_EPI_IN_HALF_PAIRS 8
 
 /* Optional fused BatchNorm-backward reduction: when the tensor a dgrad launch writes is the gradient dz that a
  * BatchNorm(+ReLU) backward consumes next, the epilogue also accumulates that BatchNorm's (sum g, sum g*xhat) over the
@@ -319,6 +324,10 @@ typedef struct vince_bn_train {
      * 8 significand bits of the deviation itself.  Both NULL or both set. */
     void* y_centred_bf16;
     float* shadow_consts;
+    /* fp32 launches, C multiple of 16: `out` is written as stored IEEE-half pairs (the layout of VINCE_EPI_IN_HALF_PAIRS) instead of
+     * fp32 -- for a tensor whose ONLY reader is a split-half convolution (a bottleneck's bn1 output in front of its 3x3).  The shadows
+     * and out_sum are still made from the fp32 values. */
+    int32_t out_half_pairs;
 } vince_bn_train;
 int vince_bn_train_apply(int dtype, const void* y, const vince_bn_train* bt, const void* identity, const float* id_scale,
                          const float* id_shift, void* out, uint8_t* mask_out, int64_t rows, int32_t C, int relu,

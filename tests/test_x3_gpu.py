@@ -172,3 +172,37 @@ def test_x1b_single_product_gradients_vs_fp64(cfg):
     assert res["1"][0] < 6e-3 and res["1"][1] < 6e-3
     assert res["b"][0] < 1e-4 and res["b"][1] < 1e-4
     assert res["1"][0] > 10 * res["b"][0]        # (the single-product launches really are a different arithmetic)
+
+
+@pytest.mark.parametrize("cfg", [(2, 14, 14, 64, 64, 3, 1, 1), (2, 15, 15, 128, 128, 3, 2, 1), (3, 14, 14, 256, 256, 3, 1, 1), (3, 9, 11, 64, 256, 1, 1, 0)])
+def test_x3h_stored_half_pairs_equal_the_in_loop_split(cfg):
+    """A BatchNorm pass that writes its output as stored IEEE-half pairs (vince_bn_train.out_half_pairs) followed by a split-half
+    convolution that multiplies the pairs as they are (VINCE_EPI_IN_HALF_PAIRS) computes, bit for bit, what the fp32 output followed by
+    the in-loop split computes: the stored halves ARE the halves the kernel would make (round 6: bn1 -> 3x3 of every block in the
+    forwards whose activations no fp32 reader needs)."""
+    ops = _ops()
+    N, H, W, Ci, Co, k, s, p = cfg
+    y = to_nhwc(rnd(N, Ci, H, W, seed=11) * 3.0 + 0.5, torch.float32)          # the raw output of the convolution in front
+    rows = N * H * W
+    stats = torch.zeros(ops.STATS_REPLICAS, Ci, 2, device=DEV, dtype=torch.float64)
+    yf = y.reshape(rows, Ci).double()
+    stats[0, :, 0], stats[0, :, 1] = yf.sum(0), (yf * yf).sum(0)
+    gamma = (1.0 + 0.1 * rnd(Ci, seed=12)).to(DEV)
+    beta = (0.1 * rnd(Ci, seed=13)).to(DEV)
+    a32 = ops.bn_train_apply(y, stats, rows, gamma, beta)[0]
+    ahp = ops.bn_train_apply(y, stats, rows, gamma, beta, half_pairs=True)[0]
+    assert not torch.equal(a32, ahp)                                            # (another byte layout altogether)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k)) ** 0.5)
+    wk3, _ = weights_krsc(w, torch.float32, x3=True)
+    d = ops.conv_desc(N, H, W, Ci, Co, k, s, p)
+    out32 = torch.empty(N, d.Ho, d.Wo, Co, device=DEV)
+    outhp = torch.full_like(out32, float("nan"))
+    st32 = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
+    sthp = torch.zeros_like(st32)
+    ops.conv_igemm(d, a32, wk3, out32, stats=st32, x3="h")
+    ops.conv_igemm(d, ahp, wk3, outhp, stats=sthp, flags=ops.EPI_IN_HALF_PAIRS, x3="h")
+    assert torch.equal(out32, outhp), float((out32 - outhp).abs().max())
+    assert float(out32.abs().max()) > 0.1
+    # refused where it cannot work: other dtypes
+    with pytest.raises(RuntimeError):
+        ops.conv_igemm(d, ahp, wk3, outhp, flags=ops.EPI_IN_HALF_PAIRS, x3="b")

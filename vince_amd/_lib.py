@@ -13,6 +13,7 @@ VINCE_F32X3 = VINCE_F32X3H
 # fp32 tensors, single bfloat16 products (op level: gradient launches); trunk cfg: x3 forward + single-product gradients ("x3f")
 VINCE_F32X1B, VINCE_F32X3F = 4, 5
 EPI_ACCUMULATE, EPI_RELU = 1, 2
+EPI_IN_HALF_PAIRS = 8     # VINCE_F32X3H launches: the input tensor holds stored IEEE-half pairs (vince_bn_train.out_half_pairs)
 
 c_void_p, c_int, c_int32, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,
                                                         ctypes.c_float, ctypes.c_size_t)
@@ -40,7 +41,8 @@ class BnTrain(ctypes.Structure):
                 ("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p),
                 ("momentum", c_float), ("eps", c_float), ("scale", c_void_p), ("shift", c_void_p),
                 ("save_mean", c_void_p), ("save_invstd", c_void_p), ("out_sum", c_void_p), ("out_sum_replicas", c_int32),
-                ("out_bf16", c_void_p), ("mask_bf16", c_void_p), ("y_centred_bf16", c_void_p), ("shadow_consts", c_void_p)]
+                ("out_bf16", c_void_p), ("mask_bf16", c_void_p), ("y_centred_bf16", c_void_p), ("shadow_consts", c_void_p),
+                ("out_half_pairs", c_int32)]
 
 
 class InfoNCEDesc(ctypes.Structure):

@@ -272,7 +272,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
                 for (int e = 0; e < CH; ++e) f[e] = fmaxf(f[e], 0.f);
             }
-            const uint4 pv = Chunk<T>::pack(f);
+            uint4 pv = Chunk<T>::pack(f);
+            if constexpr (sizeof(T) == 4) {
+                if (fin.out_half_pairs) {
+                    // (uniform) stored IEEE-half pairs: this lane's four floats become (hi, lo) dwords; the four lanes of a 16-channel group
+                    // then trade them so that lane q stores chunk q of [hi e0-3,e8-11][hi e4-7,e12-15][lo e0-3,e8-11][lo e4-7,e12-15]
+                    uint32_t h0, h1, l0, l1;
+                    x3_split_pair<x3h_t, false>(f[0], f[1], h0, l0);
+                    x3_split_pair<x3h_t, false>(f[2], f[3], h1, l1);
+                    // quad_perm [0,1,0,1] = 0x44: lane q reads lane (q & 1); [2,3,2,3] = 0xEE: lane (q & 1) + 2
+                    const uint32_t ha0 = __builtin_amdgcn_update_dpp(0, h0, 0x44, 0xf, 0xf, false), ha1 = __builtin_amdgcn_update_dpp(0, h1, 0x44, 0xf, 0xf, false);
+                    const uint32_t hb0 = __builtin_amdgcn_update_dpp(0, h0, 0xEE, 0xf, 0xf, false), hb1 = __builtin_amdgcn_update_dpp(0, h1, 0xEE, 0xf, 0xf, false);
+                    const uint32_t la0 = __builtin_amdgcn_update_dpp(0, l0, 0x44, 0xf, 0xf, false), la1 = __builtin_amdgcn_update_dpp(0, l1, 0x44, 0xf, 0xf, false);
+                    const uint32_t lb0 = __builtin_amdgcn_update_dpp(0, l0, 0xEE, 0xf, 0xf, false), lb1 = __builtin_amdgcn_update_dpp(0, l1, 0xEE, 0xf, 0xf, false);
+                    const bool lo_chunk = (col & 2) != 0;
+                    pv = lo_chunk ? make_uint4(la0, la1, lb0, lb1) : make_uint4(ha0, ha1, hb0, hb1);
+                }
+            }
             st16<(NT & 2) != 0>(out + off, pv);
             if constexpr (sizeof(T) == 4) {
                 if (fin.out_bf16)      // (uniform) bfloat16 shadow of what was just stored
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             }
             if (want_sum) {   // sum what a reader of `out` will see (the rounded values)
                 float q[CH];
-                Chunk<T>::unpack(pv, q);
+                Chunk<T>::unpack(Chunk<T>::pack(f), q);
 #pragma unroll
                 for (int e = 0; e < CH; ++e) osum[e] += q[e];
             }
@@ -1052,6 +1068,8 @@ extern "C" int vince_bn_train_apply(int dtype, const void* y, const vince_bn_tra
                     (dtype == VINCE_F32 && C % 8 == 0 && ((uintptr_t)bt->out_bf16 & 15) == 0 && ((uintptr_t)bt->y_centred_bf16 & 15) == 0), VINCE_E_ARG,
                     "vince_bn_train_apply: the bf16 shadows belong to an fp32 launch with C a multiple of 8");
     VINCE_CHECK_ARG(!bt->y_centred_bf16 == !bt->shadow_consts, VINCE_E_ARG, "vince_bn_train_apply: y_centred_bf16 and shadow_consts come together");
+    VINCE_CHECK_ARG(!bt->out_half_pairs || (dtype == VINCE_F32 && C % 16 == 0 && !identity && !bt->out_sum), VINCE_E_ARG,
+                    "vince_bn_train_apply: out_half_pairs is for a plain fp32 BatchNorm + ReLU pass with C a multiple of 16");
     vince_bn_train fin = *bt;
     if (fin.replicas <= 0 || fin.replicas > VINCE_STATS_REPLICAS) fin.replicas = VINCE_STATS_REPLICAS;
     RowWalk w = make_rowwalk(rows, C, CH_OF(dtype), bn_target_blocks());

@@ -13,6 +13,7 @@ struct ConvParams {
     int kt_per_split;   // > 0: split-K (grid.y splits, fp32 atomics into a zeroed output; f32 only)
     int kt_per_tap;     // conv_m8: K tiles of 64 elements per tap (Ci / 64)
     int ktpt_mask, log2_ktpt;
+    int presplit;  // split-half forward launches: the activation operand is stored IEEE-half pairs (VINCE_EPI_IN_HALF_PAIRS): no split in the loop
     int variant;   // host side: which kernel the launcher picked (0 = 128-pixel tile, 1 = 256-pixel tile, 2 = register-staged)
     uint32_t tb_mul;
     FastDiv div_howo, div_wo;

@@ -101,6 +101,9 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     p.cs2 = e.in2_channels;
     p.in2_bytes = 0;
     p.kt_per_split = 0;
+    p.presplit = (e.flags & VINCE_EPI_IN_HALF_PAIRS) ? 1 : 0;
+    VINCE_CHECK_ARG(!p.presplit || (dtype == VINCE_F32X3H && d.Cs == 0 && d.Ci % 16 == 0), VINCE_E_ARG,
+                    "vince_conv_igemm: VINCE_EPI_IN_HALF_PAIRS needs dtype VINCE_F32X3H, plain taps and Ci a multiple of 16");
     p.ablate = 0;
 #ifdef VINCE_MEASURE
     static int ablate = VINCE_MEASURE_KNOB("conv_ablate", 0);

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
                 }
 #pragma unroll
                 for (int i = 0; i < PI; ++i) {
-                    if (IG_ABL(256)) {   // (measurement build: the activation operand taken as stored half pairs -- timing only)
+                    if (p.presplit) {   // (uniform) stored half pairs: chunk h = hi, chunk 2 + h = lo of this lane's eight K elements, as the weights
                         xh[i] = *(const uint4*)(xs + i * 32 * KB + slot0);
                         xl[i] = *(const uint4*)(xs + i * 32 * KB + slot1);
                     } else
@@ -681,6 +681,10 @@ int launch_x3(ConvParams& p, hipStream_t stream) {
     if (!p.uniform_taps || p.in2) {
         vince_set_error("vince_conv_igemm: the split-half types need Ci to be a multiple of 16 (the split weight layout) and take no in2");
         return VINCE_E_SHAPE;
+    }
+    if (p.presplit && !(X3<T>::half && p.in_bytes && p.w_bytes)) {
+        vince_set_error("vince_conv_igemm: VINCE_EPI_IN_HALF_PAIRS is for VINCE_F32X3H launches on the direct-to-LDS kernels (tensors < 2 GiB)");
+        return VINCE_E_UNSUPPORTED;
     }
     const dim3 grid(p.ptiles * p.ctiles);
     if (p.in_bytes && p.w_bytes) {

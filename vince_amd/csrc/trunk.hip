@@ -565,12 +565,14 @@ int copy_consts(Ctx& c, const BnL& bn, vince_trunk* S, void* sw, const BnL& sbn)
 // where the consumer of scale / shift is not vince_bn_train_apply (the stem's pool, the downsample branch's identity
 // affine); everywhere else the finalize rides in the prologue of the apply pass (bn_apply_fwd below).
 int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_off, float* const* bn_running,
-                int64_t* const* bn_nbt, int train_bn, bool finalize_now, const vince_conv_desc* desc = nullptr, void* y2 = nullptr) {
+                int64_t* const* bn_nbt, int train_bn, bool finalize_now, const vince_conv_desc* desc = nullptr, void* y2 = nullptr,
+                bool in_half_pairs = false) {
     vince_conv_desc d = desc ? *desc : fwd_desc(c.t, cv);
     vince_conv_epi e;
     memset(&e, 0, sizeof(e));
     e.stats = train_bn ? c.stats(bn) : nullptr;
     e.replicas = bn.R;
+    if (in_half_pairs) e.flags |= VINCE_EPI_IN_HALF_PAIRS;     // (its input was written as stored half pairs: bn_apply_fwd(..., half_pairs))
     e.out2 = y2;       // (fp32-tensor handles only: the bf16 twin's copy of this raw output, vince_trunk_set_shadow)
     // layer1's expand convolutions (64 -> 256, stride 1: conv3 of every block and the downsample conv) are pure HBM streams that
     // write 4x what they read: the persistent streaming kernel runs them at 4.2 TB/s (122 us) against the implicit-GEMM
@@ -606,7 +608,8 @@ int conv_bn_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t in_off, size_t y_
 // out = relu(bn(y) [+ identity affine]); in train mode the BatchNorm's finalize is fused into the same launch
 int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const void* idn, const float* ids, const float* idt,
                  void* out, uint8_t* mask_out, float* const* bn_running, int64_t* const* bn_nbt, int train_bn,
-                 double* out_sum = nullptr, void* out2 = nullptr, uint8_t* mask2 = nullptr, void* y2c = nullptr, float* consts2 = nullptr) {
+                 double* out_sum = nullptr, void* out2 = nullptr, uint8_t* mask2 = nullptr, void* y2c = nullptr, float* consts2 = nullptr,
+                 bool half_pairs = false) {
     const int64_t rows = (int64_t)c.t->cfg.N * cv.Ho * cv.Wo;
     static const bool fuse_fin = (VINCE_MEASURE_KNOB("fuse_finalize", 1) != 0);
     if (!train_bn)
@@ -641,6 +644,7 @@ int bn_apply_fwd(Ctx& c, const ConvL& cv, const BnL& bn, size_t y_off, const voi
     bt.mask_bf16 = mask2;
     bt.y_centred_bf16 = y2c;
     bt.shadow_consts = consts2;
+    bt.out_half_pairs = half_pairs ? 1 : 0;
     return vince_bn_train_apply(c.dtype, at(c.ws, y_off), &bt, idn, ids, idt, out, mask_out, rows, cv.Co, 1, c.stream);
 }
 
@@ -1129,8 +1133,14 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
         }
         const int nplain = gram_blk ? b.nconv - 1 : b.nconv;   // convs that run with their own statistics epilogue
         bool gram_done = false;
+        // Split-half forwards whose activations no fp32 reader needs afterwards (no-grad forwards; grad-enabled ones with a bf16 twin):
+        // bn1's output -- read by the block's 3x3 and by nothing else -- is written as stored IEEE-half pairs and the 3x3 multiplies the
+        // pairs as they are (VINCE_EPI_IN_HALF_PAIRS): the in-register split is 15-17 % of a split-half 3x3.  `x3_half_pairs=0`: off.
+        const bool hp = t->cf == VINCE_F32X3H && train_bn && (!save || S != nullptr) && b.nconv >= 2 && b.c[1].k == 3 && b.c[0].Co % 16 == 0 &&
+                        (unsigned long long)N * b.c[0].Ho * b.c[0].Wo * b.c[0].Co * 4 < 0x7ff00000ull && vince_knob_live("x3_half_pairs", 1) != 0;
         for (int ci = 0; ci < nplain; ++ci) {
-            if (!(ci == 0 && skip_conv1)) RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, false));
+            if (!(ci == 0 && skip_conv1))
+                RC(conv_bn_fwd(c, b.c[ci], b.b[ci], in, b.y[ci], bn_running, bn_nbt, train_bn, false, nullptr, nullptr, hp && ci == 1));
             if (ci < b.nconv - 1) {
                 // (the pass that writes conv3's input also sums it per channel when the Gram path follows -- and, for the bf16
                 // K = 64 / 128 blocks, multiplies what it writes into the Gram matrix itself: csrc/bn_gram.hip, `gram_fused=0` restores the
@@ -1143,7 +1153,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
                 } else
                 RC(bn_apply_fwd(c, b.c[ci], b.b[ci], b.y[ci], nullptr, nullptr, nullptr, at(workspace, b.a[ci]), nullptr,
                                 bn_running, bn_nbt, train_bn, osum, sb ? at(sw, sb->a[ci]) : nullptr, nullptr,
-                                sb ? at(sw, sb->y[ci]) : nullptr, sb ? twin_consts(S, sw, sb->b[ci]) : nullptr));
+                                sb ? at(sw, sb->y[ci]) : nullptr, sb ? twin_consts(S, sw, sb->b[ci]) : nullptr, hp && ci == 0 && !osum));
                 in = b.a[ci];
             }
         }

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import BnReduce, BnTrain, ConvDesc, ConvEpi, InfoNCEDesc, VINCE_BF16, VINCE_F32, VINCE_F32X1B, VINCE_F32X3B, VINCE_F32X3H, check, lib
 
-EPI_ACCUMULATE, EPI_RELU = _lib.EPI_ACCUMULATE, _lib.EPI_RELU
+EPI_ACCUMULATE, EPI_RELU, EPI_IN_HALF_PAIRS = _lib.EPI_ACCUMULATE, _lib.EPI_RELU, _lib.EPI_IN_HALF_PAIRS
 STATS_REPLICAS = 16   # VINCE_STATS_REPLICAS in include/vince_hip.h
 
 
@@ -371,7 +371,7 @@ def bn_apply(y, scale, shift, identity=None, id_scale=None, id_shift=None, relu=
 
 
 def bn_train_apply(y, stats, count, gamma, beta, running_mean=None, running_var=None, nbt=None, identity=None, id_scale=None,
-                   id_shift=None, relu=True, want_mask=False, replicas=0, momentum=0.1, eps=1e-5, out_sum=None):
+                   id_shift=None, relu=True, want_mask=False, replicas=0, momentum=0.1, eps=1e-5, out_sum=None, half_pairs=False):
     """Train-mode finalize + apply in one launch.  Returns (out, mask or None, scale, shift, mean, invstd).
     out_sum: optional zeroed double[R][C] -- per-channel sums of the stored output are accumulated into it."""
     require_gpu(y, stats, gamma, beta, running_mean, running_var, nbt, identity, id_scale, id_shift, out_sum)
@@ -390,6 +390,7 @@ def bn_train_apply(y, stats, count, gamma, beta, running_mean=None, running_var=
     bt.scale, bt.shift, bt.save_mean, bt.save_invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
     if out_sum is not None:
         bt.out_sum, bt.out_sum_replicas = out_sum.data_ptr(), out_sum.shape[0]
+    bt.out_half_pairs = int(bool(half_pairs))     # `out` as stored IEEE-half pairs (conv_igemm(..., flags=EPI_IN_HALF_PAIRS, x3="h") reads them)
     check(lib().vince_bn_train_apply(dtype_code(y), _ptr(y), ctypes.byref(bt), _ptr(identity), _ptr(id_scale), _ptr(id_shift),
                                      _ptr(out), _ptr(mask), y.numel() // C, C, int(relu), stream_ptr()))
     return out, mask, scale, shift, mean, invstd
