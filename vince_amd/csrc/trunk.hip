@@ -1103,6 +1103,9 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
     // fp32 identity (nothing reads it again: the twin holds its bf16 copy) -- with the twin's copies (conv3's output centred, the block
     // output, the ReLU bits) written by that epilogue.  `gram_shadow=0`: the separate passes (cross-check switch).
     const bool gram_shadow = gram_env && train_bn && save && S != nullptr && !ds_side && vince_knob_live("gram_shadow", 1) != 0;
+    // ... and where the twin's backward can take the BatchNorm-backward algebra (alg_block: K = 64 / 128) it gets the Gram sums instead of
+    // a copy of conv3's output.  `x3f_alg=0`: centred copies everywhere (cross-check switch).
+    const bool twin_alg = gram_shadow && alg_env() && vince_knob_live("x3f_alg", 1) != 0;
     const bool gram_on = gram_nograd || gram_train || gram_shadow;
     const bool gram_fused = vince_knob_live("gram_fused", 1) != 0;
     if (gram_on && t->gram_bytes)
@@ -1189,14 +1192,25 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
                 idn = out = b.yd;
             }
             if (save && !gram_shadow) out = b.z;   // backward reads the identity tensors again: nothing in place
-            if (gram_shadow) {                 // the twin's view of this block's tail (its backward runs the separate BatchNorm-backward passes)
+            if (gram_shadow) {                 // the twin's view of this block's tail
                 e.out2 = at(sw, sb->z);
-                e.raw2 = at(sw, sb->y[L]);
-                e.raw2_mean = c.consts(bn, 2);
                 e.mask2 = (uint8_t*)at(sw, sb->zmask);
-                hipLaunchKernelGGL(centre_consts_kernel, dim3((bn.C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                                   (const float*)c.consts(bn, 0), twin_consts(S, sw, sb->b[L]), bn.C);
-                VINCE_CHECK_LAUNCH();
+                if (twin_alg && alg_block(S, bi)) {
+                    // its backward takes the BatchNorm-backward algebra (csrc/bn_algebra.hip): no copy of conv3's output at all -- the Gram
+                    // matrix and column sums of conv3's input (adjacent in both workspaces) and bn3's constants as they are
+                    VINCE_CHECK_ARG(sb->gram != NONE && sb->colsum == sb->gram + (b.colsum - b.gram), VINCE_E_ARG,
+                                    "vince_trunk_forward: the twin's Gram scratch is laid out differently");
+                    VINCE_CHECK_HIP(hipMemcpyAsync(at(sw, sb->gram), at(workspace, b.gram),
+                                                   (b.colsum - b.gram) + (size_t)GRAM_R * cv.Ci * sizeof(double), hipMemcpyDeviceToDevice,
+                                                   (hipStream_t)stream));
+                    RC(copy_consts(c, bn, S, sw, sb->b[L]));
+                } else {                       // the separate BatchNorm-backward passes: conv3's output centred, constants to match
+                    e.raw2 = at(sw, sb->y[L]);
+                    e.raw2_mean = c.consts(bn, 2);
+                    hipLaunchKernelGGL(centre_consts_kernel, dim3((bn.C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                                       (const float*)c.consts(bn, 0), twin_consts(S, sw, sb->b[L]), bn.C);
+                    VINCE_CHECK_LAUNCH();
+                }
             }
             // bf16 at K = 64 / 128: the persistent streaming kernel (csrc/conv_xjoin.hip); otherwise the implicit-GEMM kernel's join
             // epilogue (fp32, or VINCE_XJOIN=0 as a cross-check; no-grad forwards only)
@@ -1243,7 +1257,7 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
         cur = b.z;
     }
     RC(vince_avgpool_fwd(c.dtype, at(workspace, t->blocks.back().z), pooled, N, t->outH * t->outW, t->outC, stream));
-    if (S) S->fwd_alg = false;     // its backward takes the separate BatchNorm-backward passes: conv3's (centred) raw outputs are all there
+    if (S) S->fwd_alg = twin_alg;  // (elsewhere its backward takes the separate BatchNorm-backward passes over conv3's centred outputs)
     return VINCE_OK;
 }
 
