@@ -59,7 +59,7 @@ const char* vince_last_error(void);
 /* Bumped whenever an exported signature, a struct layout or a dtype code changes.  vince_abi_version() returns the value the library
  * was BUILT with; a binding compares it at load (vince_amd/_lib.py: a stale .so behind VINCE_HIP_LIB would otherwise be called with
  * shifted arguments). */
-#define VINCE_ABI_VERSION 11
+#define VINCE_ABI_VERSION 12
 int vince_abi_version(void);
 
 /* Measurement aid (bench.py): while enabled, every conv_igemm / conv_wgrad launch is bracketed by a hipEvent pair on
@@ -176,9 +176,13 @@ typedef struct vince_conv_epi {
     /* A reduction split over TWO input tensors: the LAST tap (index TA*TB - 1; needs TA*TB >= 2) reads in2 -- same N x Hi x Wi, with
      * in2_channels <= Ci channels per pixel (its own row stride) -- instead of `in`; the weights stay [Co][WT][Ci] with only the
      * first in2_channels entries of that tap's block used.  With all tap displacements zero this is  out = W1 in + W2 in2  in one
-     * launch (the input gradient of the BatchNorm-backward algebra: da = wd g + nq a, csrc/bn_algebra.hip).  Direct-to-LDS kernels only. */
+     * launch (the input gradient of the BatchNorm-backward algebra: da = wd g + nq a, csrc/bn_algebra.hip).  Direct-to-LDS kernels only.
+     * in2_repeat > 1 (ABI 12): the in2 row is read in2_repeat times over -- the tap's reduction is in2_repeat * in2_channels <= Ci long,
+     * with consecutive weight blocks of in2_channels entries each: out = W1 in + (W2a + W2b + ...) in2, the way a weight matrix split
+     * into bfloat16 hi + lo parts multiplies the same tensor (in2_channels / 8 a power of two).  0 / 1: once. */
     const void* in2;
     int32_t in2_channels;
+    int32_t in2_repeat;
     /* Forward epilogue of fp32-store launches only (VINCE_F32 / VINCE_F32X3H, no split reduction): a bfloat16 SHADOW of `out` -- the
      * same NHWC element offsets, every stored value also written rounded to bfloat16 (8 bytes per 16-byte chunk).  What the mixed mode
      * "x3f" saves for its bf16 backward (vince_trunk_set_shadow).  NULL = none.  (ABI 11) */
@@ -360,19 +364,30 @@ int vince_bn_gram_finalize(int dtype, const float* gram, const double* colsum, i
 /* BatchNorm backward THROUGH a bottleneck's last 1x1 convolution, without that convolution's output (csrc/bn_algebra.hip; autograd of
  * resnet.py:123-133 with BatchNorm2d in train mode).  y = W a is linear and pointwise, so with g = the gradient of the block output
  * gated by its ReLU, R = g^T a (vince_conv_wgrad with dy := g) and the per-channel sums of g:
- *   coef[4][Co] = s = gamma*invstd, c1 = mean g, c2 = mean g*xhat = invstd (<W[c,:], R[c,:]> - mean sum g) / count, t = s*c2*invstd
+ *   coef[5][Co] = s = gamma*invstd, c1 = mean g, c2 = mean g*xhat = invstd (<W[c,:], R[c,:]> - mean sum g) / count, t = s*c2*invstd,
+ *                 and the mean those formulas used (row 4: pass it to vince_bn3_bwd_finish_dw)
  *   dgamma += count*c2, dbeta += count*c1
  *   wd [K][Co] bf16 = W^T diag(s)  and  nq [K][K] bf16 = -W^T diag(t) W  (row strides wd_ld / nq_ld in elements): the weights of
  *                     da = wd g + nq a + nr -- ONE launch when interleaved as the two taps [K][2][Co] of vince_conv_epi.in2
  *   nr [K]     f32  = -sum_c W[c][k] (s c1 - t mean)
- * w is the bf16 [Co][K] copy the forward multiplied with; gsums double[replicas][Co][2] (first of each pair = sum of g). K <= 128. */
+ * w is the bf16 [Co][K] copy the forward multiplied with; gsums double[replicas][Co][2] (first of each pair = sum of g). K <= 128.
+ * colsum (double[colsum_replicas][K], the column sums of a; may be NULL): the algebra is then self-consistent on the IMPLIED y = w a --
+ * the mean is sum_k w[c][k] colsum[k] / count instead of `mean` (they differ when the forward multiplied with other weights than w: the
+ * mixed mode's fp32 masters) and nr is formed from the ROUNDED wd / nq, nr = -wd_r c1 - nq_r colsum / count, so that the pixel sums of da
+ * vanish to fp32 rounding as they do behind a stored dy (ABI 12).
+ * w_dtype (ABI 12): VINCE_BF16, or VINCE_F32 -- `w_bf16` then points at the fp32 master weights [Co][K] (the mixed mode: the forward
+ * multiplied with those).  wd_lo / nq_lo (both or neither; same row strides as wd / nq): the bfloat16 remainders wd - wd_hi, nq - nq_hi
+ * -- 16 mantissa bits for the input gradient's weights, multiplied as two more reduction blocks (taps [wd | wd_lo] on g,
+ * vince_conv_epi.in2_repeat = 2 over [nq | nq_lo] on a): what keeps the masked pixel sums the BatchNorm below reduces at the
+ * separate passes' accuracy (csrc/bn_algebra.hip). */
 int vince_bn3_bwd_prepare(const float* R, const void* w_bf16, const double* gsums, int32_t replicas, const float* mean,
                           const float* invstd, const float* gamma, int64_t count, int32_t Co, int32_t K, float* coef, void* wd,
-                          int32_t wd_ld, void* nq, int32_t nq_ld, float* nr, float* dgamma, float* dbeta, void* stream);
+                          int32_t wd_ld, void* nq, int32_t nq_ld, float* nr, float* dgamma, float* dbeta, const double* colsum,
+                          int32_t colsum_replicas, int32_t w_dtype, void* wd_lo, void* nq_lo, void* stream);
 /* ... and the weight gradient, in place of R:  dW = diag(s) (R - c1 A^T - diag(c2 invstd) (W G - mean A^T)),  G = a^T a (float[K][K], the
  * Gram matrix the forward's statistics came from, vince_bn_gram_finalize), A = column sums of a (double[colsum_replicas][K]). */
 int vince_bn3_bwd_finish_dw(float* RdW, float* dw_accum, const void* w_bf16, const float* gram, const double* colsum, int32_t colsum_replicas,
-                            const float* coef, const float* mean, const float* invstd, int32_t Co, int32_t K, void* stream);
+                            const float* coef, const float* mean, const float* invstd, int32_t Co, int32_t K, int32_t w_dtype, void* stream);
 /* dw_accum NULL: in place (R becomes dW).  dw_accum non-NULL: R is left untouched and the finished gradient is ADDED into dw_accum -- R then
  * lives in scratch and the gradient buffer keeps the accumulate-into contract of vince_conv_wgrad (gradient accumulation over several
  * backward passes without zero_grad). */

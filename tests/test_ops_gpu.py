@@ -1180,6 +1180,57 @@ def test_nonfinite_loss_latch():
     VinceSolver.check_loss_latch(types.SimpleNamespace(_loss_latch=torch.zeros(2, dtype=torch.int64, device=DEV)))
 
 
+def test_bn3_algebra_masked_pixel_sums_at_engine_scale():
+    """What the BatchNorm BELOW the algebra reduces are sums of the input gradient over ITS ReLU mask (a > 0): cancellations of a few
+    hundred to one, in which anything that is the same at every pixel shows.  At the engine's size (28 x 28 x 256 pixels, w = 64, correlated
+    activations, an upstream gradient with a per-channel mean) against fp64: the mixed mode's form (fp32 master weights, matrices in
+    bfloat16 hi + lo parts, the constant on the fp32 accumulators) is as good as the separate passes (3.6e-3 emulated); single bf16
+    matrices are not (5e-2), and the constant added to the staged bf16 value was 1.6e-1 (rounds 3-5; tools/alg_op_probe.py)."""
+    ops = _ops()
+    from vince_amd._lib import ConvDesc
+    rows, w = 200704, 64
+    Co = 4 * w
+    g0 = torch.Generator(device=DEV).manual_seed(3)
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=g0, device=DEV)
+    a = torch.relu(rn(rows, 16) @ (rn(16, w) * 0.5) + 0.5 * rn(rows, w) + 0.3)
+    W = rn(Co, w) * (2.0 / w) ** 0.5
+    gamma, beta = torch.rand(Co, generator=g0, device=DEV) + 0.5, rn(Co) * 0.2
+    ident, G = rn(rows, Co), rn(rows, Co) * 0.1 + 0.02
+    a64, W64 = a.double(), W.double()
+    y = a64 @ W64.t()
+    mu, var = y.mean(0), y.var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    xhat = (y - mu) * invstd
+    gb = (G * ((xhat * gamma.double() + beta.double() + ident.double()) > 0)).bfloat16()
+    g = gb.double()
+    s = gamma.double() * invstd
+    da_true = (s * (g - g.mean(0) - xhat * (g * xhat).mean(0))) @ W64
+    m2 = (a64 > 0).double()
+    ref = (da_true * m2).sum(0)
+    ab = a.bfloat16()
+    R = torch.zeros(Co, 1, w, device=DEV)
+    ops.conv_wgrad(ops.conv_desc(1, rows, 1, w, Co, 1, 1, 0), ab.view(1, rows, 1, w), gb.view(1, rows, 1, Co), R)
+    colsum = torch.zeros(4, w, device=DEV, dtype=torch.float64)
+    colsum[0] = a64.sum(0)
+    gs = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
+    gs[0, :, 0] = g.sum(0)
+    err = {}
+    for name, wt, split in (("single", W.bfloat16(), False), ("split", W, True)):
+        coef, w2, nr = ops.bn3_bwd_prepare(R.view(Co, w), wt.contiguous(), gs, mu.float(), invstd.float(), gamma, rows,
+                                           torch.zeros(Co, device=DEV), torch.zeros(Co, device=DEV), colsum=colsum, split=split)
+        taps = 3 if split else 2
+        dd = ConvDesc(N=1, Hi=rows, Wi=1, Ci=Co, Ho=rows, Wo=1, Co=w, sh=1, sw=1, TA=1, TB=taps, dh0=0, dhs=1, dw0=0, dws=0, wt0=0, wta=0,
+                      wtb=1, WT=taps, OH=rows, OW=1, osh=1, osw=1, oh0=0, ow0=0)
+        da = torch.empty(rows, w, device=DEV, dtype=torch.bfloat16)
+        ops.conv_igemm(dd, gb.view(1, rows, 1, Co), w2, da.view(1, rows, 1, w), bias=nr, in2=ab.view(1, rows, 1, w), in2_repeat=2 if split else 0)
+        err[name] = float(((da.double() * m2).sum(0) - ref).abs().max() / ref.abs().max())
+        assert float((da.double() - da_true).norm() / da_true.norm()) < 5e-3
+    print("bn3 algebra at 200704 x 64: masked pixel sums vs fp64 %.2e (fp32 weights, hi + lo matrices) %.2e (single bf16 matrices)" % (err["split"], err["single"]))
+    assert err["split"] < 6e-3 and err["single"] < 1.2e-1
+
+
 @pytest.mark.parametrize("w,rows", [(64, 3000), (128, 1111)])
 def test_bn3_backward_algebra_vs_autograd(w, rows):
     """csrc/bn_algebra.hip: BatchNorm backward THROUGH a bottleneck's last 1x1 convolution without that convolution's output
@@ -1243,7 +1294,24 @@ def test_bn3_backward_algebra_vs_autograd(w, rows):
     gs[1, :, 0] = gb.double().sum(0)
     dgam, dbet = torch.zeros(Co, device=DEV), torch.zeros(Co, device=DEV)
     mean32, invstd32 = mu.detach().float().to(DEV), invstd.detach().float().to(DEV)
-    coef, w2, nr = ops.bn3_bwd_prepare(R.view(Co, w), Wb, gs, mean32, invstd32, gamma.to(DEV), rows, dgam, dbet)
+    # (first the form of rounds 3-5 -- the forward's mean, nr from the unrounded coefficients -- for the pixel-sum comparison below)
+    _, w2_old, nr_old = ops.bn3_bwd_prepare(R.view(Co, w), Wb, gs, mean32, invstd32, gamma.to(DEV), rows, torch.zeros_like(dgam), torch.zeros_like(dbet))
+    # the engine's form: colsum given -> the implied mean W colsum / n (here W and a ARE what the forward multiplied, so it equals mu to
+    # rounding) and nr formed from the rounded wd / nq
+    coef, w2, nr = ops.bn3_bwd_prepare(R.view(Co, w), Wb, gs, mean32, invstd32, gamma.to(DEV), rows, dgam, dbet, colsum=colsum)
+    assert coef.shape == (5, Co) and float((coef[4].cpu() - mu.detach().float()).abs().max()) < 1e-5 * float(mu.detach().abs().max()) + 1e-6
+    assert float((w2.float() - w2_old.float()).abs().max()) <= 2.0 ** -7 * float(w2_old.float().abs().max())   # (the mean moved in its last bits)
+    mean32 = coef[4].contiguous()
+    # sum over pixels of da = wd_r G + nq_r A + n nr: BatchNorm backward hands conv3 a dy whose pixel sums vanish, so this is 0 in exact
+    # arithmetic; with nr formed from the ROUNDED matrices it is 0 to fp32 rounding, with the unrounded form the bf16 residue (the same
+    # sign at every pixel) stays -- and lands in the bias gradient of the BatchNorm below
+    Gs, As = gb.double().sum(0).cpu(), ab.double().sum(0).cpu()
+    wd64, nq64 = w2[:, 0].double().cpu(), w2[:, 1, :w].double().cpu()
+    scale = (wd64.abs() @ Gs.abs() + nq64.abs() @ As.abs())
+    resid = ((wd64 @ Gs + nq64 @ As + rows * nr.double().cpu()).abs() / scale).max()
+    resid_old = ((wd64 @ Gs + nq64 @ As + rows * nr_old.double().cpu()).abs() / scale).max()
+    print("bn3 algebra w=%d: pixel-sum residue of da relative to its terms: %.2e (nr from the unrounded coefficients: %.2e)" % (w, resid, resid_old))
+    assert resid < 2e-6 and resid_old > 10 * resid
     # the accumulate-into form (what the engine uses: R stays scratch, the finished gradient is ADDED to a buffer that already holds one)
     R0 = R.clone()
     acc = torch.full((Co, w), 0.5, device=DEV)
@@ -1270,3 +1338,48 @@ def test_bn3_backward_algebra_vs_autograd(w, rows):
     assert relerr(da.float(), da2.float().double().cpu()) < 1.2e-2
     e_da = relerr(da.float(), a64.grad)
     assert e_da < 2e-2, e_da
+    # ---- the mixed mode's form (round 6): fp32 master weights, both matrices of the input gradient in bfloat16 hi + lo parts, reduced as
+    # [wd_hi | wd_lo] g + [nq_hi | nq_lo] a (vince_conv_epi.in2_repeat).  What it is for: the sums the BatchNorm below takes over ITS ReLU
+    # mask (a > 0) -- heavy cancellations in which the single-bf16 matrices' rounding, the same sign at every pixel, shows.
+    dg3, db3 = torch.zeros(Co, device=DEV), torch.zeros(Co, device=DEV)
+    coef3, w3, nr3 = ops.bn3_bwd_prepare(R0.view(Co, w), W.to(DEV), gs, mean32, invstd32, gamma.to(DEV), rows, dg3, db3, colsum=colsum, split=True)
+    assert w3.shape == (w, 3, Co) and relerr(dg3, g64.grad) < 2e-3 and relerr(db3, b64.grad) < 2e-3
+    hi, lo = w3[:, 0].float(), w3[:, 1].float()
+    assert float(lo.abs().max()) <= 2.0 ** -8 * float(hi.abs().max()) and float(lo.abs().max()) > 0      # a remainder, not a copy
+    wd_exact = (W * coef3[0].cpu()[:, None]).t()
+    assert relerr(hi + lo, wd_exact.double()) < 2.0 ** -15
+    Rf = R0.clone()
+    ops.bn3_bwd_finish_dw(Rf.view(Co, w), W.to(DEV), gram.view(w, w), colsum, coef3, coef3[4].contiguous(), invstd32)
+    assert relerr(Rf.view(Co, w), W64.grad) < 5e-3
+    da3 = torch.empty(rows, w, device=DEV, dtype=torch.bfloat16)
+    dd3 = ConvDesc(N=1, Hi=rows, Wi=1, Ci=Co, Ho=rows, Wo=1, Co=w, sh=1, sw=1, TA=1, TB=3, dh0=0, dhs=1, dw0=0, dws=0, wt0=0, wta=0,
+                   wtb=1, WT=3, OH=rows, OW=1, osh=1, osw=1, oh0=0, ow0=0)
+    ops.conv_igemm(dd3, gb.view(1, rows, 1, Co), w3, da3.view(1, rows, 1, w), bias=nr3, in2=ab.view(1, rows, 1, w), in2_repeat=2)
+    # (the same reduction as three plain launches: wd_hi g + nr, += wd_lo g, += (nq_hi + nq_lo) a)
+    w3f = w3.float()
+    want3 = (gb.float() @ (w3f[:, 0] + w3f[:, 1]).t() + ab.float() @ (w3f[:, 2, :w] + w3f[:, 2, w:2 * w]).t() + nr3).double().cpu()
+    assert relerr(da3.float(), want3) < 6e-3            # (one bf16 rounding of the stored value)
+    e_da3 = relerr(da3.float(), a64.grad)
+    m2 = (a > 0).double()
+
+    def masked(dax):
+        got, ref = (dax.double().cpu() * m2).sum(0), (a64.grad * m2).sum(0)
+        return float((got - ref).abs().max() / ref.abs().max())
+    print("bn3 algebra w=%d: input gradient vs fp64 %.2e (split) %.2e (single); masked pixel sums %.2e (split) %.2e (single)"
+          % (w, e_da3, e_da, masked(da3.float()), masked(da.float())))
+    assert e_da3 < 1.2e-2
+    # the engine fuses the reduction of the BatchNorm BELOW (bn2: its own ReLU mask from its input) into this launch: the sums must be those
+    # of the stand-alone reduction over the stored gradient, bias and second tensor included
+    y2 = torch.randn(rows, w, generator=g).bfloat16().to(DEV)
+    m2c, i2c = (torch.randn(w, generator=g) * 0.1).to(DEV), (torch.rand(w, generator=g) + 0.5).to(DEV)
+    msc, msh = (torch.rand(w, generator=g) + 0.5).to(DEV), (torch.randn(w, generator=g) * 0.3).to(DEV)
+    for desc, wts, nrr, rep in ((dd, w2, nr, 0), (dd3, w3, nr3, 2)):
+        sums = torch.zeros(ops.STATS_REPLICAS, w, 2, device=DEV, dtype=torch.float64)
+        out = torch.empty(rows, w, device=DEV, dtype=torch.bfloat16)
+        br = ops.bn_reduce_arg(y2.view(1, rows, 1, w), m2c, i2c, sums, mask_scale=msc, mask_shift=msh)
+        ops.conv_igemm(desc, gb.view(1, rows, 1, Co), wts, out.view(1, rows, 1, w), bias=nrr, in2=ab.view(1, rows, 1, w), in2_repeat=rep, bnred=br,
+                       replicas=4)
+        assert torch.equal(out, da3 if rep else da)
+        want = ops.bn_bwd_reduce(out.view(1, rows, 1, w), y2.view(1, rows, 1, w), m2c, i2c, mask_scale=msc, mask_shift=msh)
+        got = sums.sum(0)
+        assert float((got - want).abs().max()) / (float(want.abs().max()) + 1e-6) < 1e-5, ("fused reduce behind the algebra's launch", rep)

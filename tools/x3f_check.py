@@ -36,3 +36,6 @@ for fx in (sys.argv[1:] or ["g9", "g12", "g14"]):
                  _rel(d["queue_embeddings"], g["queue_embeddings"]), float(np.median(list(ratios.values()))), max(ratios.values()),
                  max(ratios, key=ratios.get).replace("feature_extractor.model.", ""), float(np.median(list(rows.values()))),
                  max(rows.values()), max(rows, key=rows.get).replace("feature_extractor.model.", ""), min(cos.values())), flush=True)
+        if os.environ.get("X3F_CHECK_TOP"):
+            top = sorted(ratios, key=ratios.get, reverse=True)[:int(os.environ["X3F_CHECK_TOP"])]
+            print("    worst sum|g|: " + "  ".join("%s %.1e" % (n.replace("feature_extractor.model.", ""), ratios[n]) for n in top), flush=True)

@@ -32,7 +32,7 @@ class BnReduce(ctypes.Structure):
 class ConvEpi(ctypes.Structure):
     _fields_ = [("flags", c_int32), ("bias", c_void_p), ("stats", c_void_p), ("acc_mask", c_void_p),
                 ("bnred", BnReduce), ("replicas", c_int32),
-                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p), ("out_mask", c_void_p), ("in2", c_void_p), ("in2_channels", c_int32), ("out2", c_void_p),
+                ("out_scale", c_void_p), ("id_scale", c_void_p), ("id_shift", c_void_p), ("out_mask", c_void_p), ("in2", c_void_p), ("in2_channels", c_int32), ("in2_repeat", c_int32), ("out2", c_void_p),
                 ("raw2", c_void_p), ("raw2_mean", c_void_p), ("mask2", c_void_p)]
 
 
@@ -75,9 +75,10 @@ PROTOTYPES = {
     "vince_conv_expand_dgrad_masked": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_void_p, c_void_p,
                                                c_void_p, c_int32, c_void_p]),
     "vince_bn3_bwd_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
-                                      c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
+                                      c_void_p, c_void_p]),
     "vince_bn3_bwd_finish_dw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
-                                        c_void_p]),
+                                        c_int32, c_void_p]),
     "vince_conv_expand_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_void_p, P(BnReduce),
                                         c_int32, c_void_p]),
     "vince_conv_wgrad_det": (c_int, [P(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
@@ -179,7 +180,7 @@ _LIB = None
 
 
 # include/vince_hip.h VINCE_ABI_VERSION (tests/test_abi_cpu.py holds the two together)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 def lib():

@@ -53,6 +53,10 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     VINCE_CHECK_ARG(!e.in2 || (dd->TA * dd->TB >= 2 && dd->Cs == 0 && e.in2_channels > 0 && e.in2_channels <= dd->Ci &&
                                e.in2_channels % (f32_store ? 4 : 8) == 0 && ((uintptr_t)e.in2 & 15) == 0), VINCE_E_ARG,
                     "vince_conv_igemm: in2 is the input of the last of at least two taps, in2_channels <= Ci, 16-byte aligned");
+    const int in2_rep = (e.in2 && e.in2_repeat > 1) ? e.in2_repeat : 1;
+    VINCE_CHECK_ARG(in2_rep == 1 || (!f32_store && e.in2_channels * in2_rep <= dd->Ci && e.in2_channels % 32 == 0 &&
+                                     ((e.in2_channels / 8) & (e.in2_channels / 8 - 1)) == 0), VINCE_E_ARG,
+                    "vince_conv_igemm: in2_repeat needs bf16, in2_repeat * in2_channels <= Ci and in2_channels / 8 a power of two >= 4");
     const vince_conv_desc& d = *dd;
     const int CH = f32_store ? 4 : 8;
     VINCE_CHECK_ARG(d.N > 0 && d.Hi > 0 && d.Wi > 0 && d.Ho > 0 && d.Wo > 0 && d.Co > 0 && d.Ci > 0, VINCE_E_SHAPE,
@@ -88,7 +92,15 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
         p.cpt_mask = cpt - 1;
     }
     p.total_chunks = T * cpt;
-    if (e.in2) p.total_chunks = (T - 1) * cpt + e.in2_channels / CH;   // the last tap reads the (narrower) second tensor
+    if (e.in2) p.total_chunks = (T - 1) * cpt + e.in2_channels * in2_rep / CH;   // the last tap reads the (narrower) second tensor
+    p.log2_cpt2 = 31;
+    p.cpt2_mask = 0x7fffffff;
+    if (in2_rep > 1) {
+        int l = 0;
+        while ((1 << l) < e.in2_channels / CH) ++l;
+        p.log2_cpt2 = l;
+        p.cpt2_mask = e.in2_channels / CH - 1;
+    }
     p.nkt = (p.total_chunks + 3) / 4;
     p.M = d.N * d.Ho * d.Wo;
     p.tb_mul = (65536 + d.TB - 1) / d.TB;

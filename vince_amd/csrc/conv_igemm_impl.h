@@ -269,11 +269,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
         const bool qv = q < p.total_chunks;       // also false for kt >= nkt: the whole tile is zero filled
         src2 = __builtin_amdgcn_readfirstlane(tap) == tap2;    // (every lane of a tile is in the same tap here: uniform_taps)
         const uint32_t cs = src2 ? (uint32_t)p.cs2 : (uint32_t)p.cs;
+        const int ccx = src2 ? (cc & p.cpt2_mask) : cc;        // (in2_repeat: the second tensor's row is read again from its start)
 #pragma unroll
         for (int e = 0; e < XROWS; ++e) {
             const int hi = hb[e] + dh, wi = wb[e] + dw;
             const bool ok = rv[e] && qv && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
-            offx[e] = ok ? ((nb[e] + (uint32_t)(hi * d.Wi + wi)) * cs + (uint32_t)cc * CH) * (uint32_t)sizeof(T) : OOB;
+            offx[e] = ok ? ((nb[e] + (uint32_t)(hi * d.Wi + wi)) * cs + (uint32_t)ccx * CH) * (uint32_t)sizeof(T) : OOB;
         }
 #pragma unroll
         for (int e = 0; e < WROWS; ++e) {
@@ -284,7 +285,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     };
     auto issue_tile = [&](int kt, int buf) {
         if (p.uniform_taps) {
-            const int tap = kt >= p.nkt ? 0x7fffff : ((kt * KC) >> p.log2_cpt);   // wave-uniform
+            int tap = kt >= p.nkt ? 0x7fffff : ((kt * KC) >> p.log2_cpt);   // wave-uniform
+            // (in2_repeat: every pass over the second tensor's row starts like a new tap -- the offsets are made afresh, not advanced)
+            if (p.in2) tap = (tap << 6) | (((kt * KC) & p.cpt_mask) >> p.log2_cpt2);
             if (tap != cur_tap) {
                 compute_offsets(kt * KC + c_log);
                 cur_tap = tap;

@@ -101,6 +101,7 @@ struct vince_trunk {
     // the last grad-enabled forward took the Gram join WITHOUT storing conv3's output for the eligible blocks (alg_block): its
     // backward must run the BatchNorm-backward algebra for exactly those blocks
     bool fwd_alg = false;
+    bool is_twin = false;      // a bf16 handle that some fp32-tensor handle shadows into (vince_trunk_set_shadow): its forward never runs
     // host callback of vince_trunk_backward: invoked right after bucket event e has been recorded (vince_trunk_set_bucket_callback)
     void (*bucket_cb)(int32_t, void*) = nullptr;
     void* bucket_cb_user = nullptr;
@@ -362,7 +363,7 @@ extern "C" int vince_trunk_create(const vince_trunk_cfg* cfg, vince_trunk_t* out
         if (b.gram != NONE) {
             const size_t w = b.c[2].Ci, co = b.c[2].Co;
             b.alg = P.ws;
-            P.ws = align_up(P.ws + align_up(4 * co * sizeof(float)) + align_up(w * 2 * co * 2) + align_up(w * sizeof(float)));
+            P.ws = align_up(P.ws + align_up(5 * co * sizeof(float)) + align_up(w * 3 * co * 2) + align_up(w * sizeof(float)));
         }
     }
     // the raw weight gradients R = g^T a of the algebra blocks (float[Co][K] each, one contiguous region zeroed once per backward):
@@ -469,6 +470,7 @@ extern "C" int vince_trunk_set_shadow(vince_trunk_t t, vince_trunk_t sh, void* s
                     "vince_trunk_set_shadow: the twin must be created for the same architecture and input shape");
     t->shadow = sh;
     t->shadow_ws = shadow_workspace;
+    sh->is_twin = true;
     return VINCE_OK;
 }
 extern "C" int vince_trunk_stem_join(vince_trunk_t t, void* stream) {
@@ -686,13 +688,14 @@ bool alg_block(const vince_trunk* t, size_t bi) {
            (b.c[2].Ci == 64 || b.c[2].Ci == 128) && b.c[2].Co % 256 == 0 && b.c[2].k == 1 && b.c[2].stride == 1 &&
            (unsigned long long)t->cfg.N * b.c[2].Hi * b.c[2].Wi * b.c[2].Ci * 2 < 0x7ff00000ull;
 }
-struct AlgPtrs { float* coef; void* w2; float* nr; };   // w2: bf16 [w][2][4w] -- tap 0 = wd, tap 1 = nq in its first w entries
+struct AlgPtrs { float* coef; void* w2; float* nr; };   // w2: bf16 [w][2][4w] -- tap 0 = wd, tap 1 = nq in its first w entries -- or, split into
+                                                        // hi + lo parts, [w][3][4w]: wd_hi, wd_lo, [nq_hi | nq_lo] in the first 2w entries of the third
 AlgPtrs alg_ptrs(void* ws, const Blk& b) {
     const size_t w = b.c[2].Ci, co = b.c[2].Co;
     unsigned char* base = (unsigned char*)at(ws, b.alg);
     AlgPtrs a;
-    a.coef = (float*)base; base += align_up(4 * co * sizeof(float));
-    a.w2 = base; base += align_up(w * 2 * co * 2);
+    a.coef = (float*)base; base += align_up(5 * co * sizeof(float));
+    a.w2 = base; base += align_up(w * 3 * co * 2);
     a.nr = (float*)base;
     return a;
 }
@@ -1383,8 +1386,14 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             const ConvL& cv = b.c[L];
             const BnL& bn = b.b[L];
             const void* a_in = at(workspace, b.a[L - 1]);
-            const void* wk = at((void*)wcache, cv.wk);
+            // A twin (mixed mode: the forward multiplied with the fp32 masters) derives the coefficients from the MASTER weights and takes the
+            // input gradient's two matrices in bf16 hi + lo parts -- what keeps the masked sums the BatchNorm below reduces at the separate
+            // passes' accuracy (csrc/bn_algebra.hip; `alg_split=0`: single bf16 matrices from the bf16 cache, as the bf16 mode has them)
+            const bool split = t->is_twin && vince_knob_live("alg_split", 1) != 0;
+            const void* wk = split ? (const void*)params[cv.param] : at((void*)wcache, cv.wk);      // ([Co][1][1][Ci] = the same [Co][K] rows)
+            const int wdt = split ? VINCE_F32 : VINCE_BF16, taps = split ? 3 : 2;
             const AlgPtrs ap = alg_ptrs(workspace, b);
+            unsigned char* const w2b = (unsigned char*)ap.w2;
             // R = g^T a into this block's scratch (on this stream: the algebra below needs it before the dgrad); the finished weight
             // gradient is then ADDED into the gradient buffer like every other one
             float* const R = (float*)at(workspace, b.algR);
@@ -1393,8 +1402,9 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                 RC(wgrad_launch(t, workspace, t->cb, dw, a_in, Z, R, cv.Ci, 0, stream));
             }
             RC(vince_bn3_bwd_prepare(R, wk, c.sums(bn), bn.R, c.consts(bn, 2), c.consts(bn, 3), params[bn.gamma], rows_out,
-                                     cv.Co, cv.Ci, ap.coef, ap.w2, 2 * cv.Co, (unsigned char*)ap.w2 + (size_t)cv.Co * 2, 2 * cv.Co, ap.nr,
-                                     grads[bn.gamma], grads[bn.beta], stream));
+                                     cv.Co, cv.Ci, ap.coef, ap.w2, taps * cv.Co, w2b + (size_t)(taps - 1) * cv.Co * 2, taps * cv.Co, ap.nr,
+                                     grads[bn.gamma], grads[bn.beta], (const double*)at(workspace, b.colsum), GRAM_R, wdt,
+                                     split ? w2b + (size_t)cv.Co * 2 : nullptr, split ? w2b + ((size_t)2 * cv.Co + cv.Ci) * 2 : nullptr, stream));
             // the finished weight gradient is nobody's input but the optimiser's: on the weight-gradient stream, behind the coefficients
             // (ev_alg), off the chain of launches the input gradient below waits for
             if (overlap) {
@@ -1402,7 +1412,7 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                 VINCE_CHECK_HIP(hipStreamWaitEvent(t->side, t->ev_alg, 0));
             }
             RC(vince_bn3_bwd_finish_dw(R, grads[cv.param], wk, (const float*)at(workspace, b.gram), (const double*)at(workspace, b.colsum),
-                                       GRAM_R, ap.coef, c.consts(bn, 2), c.consts(bn, 3), cv.Co, cv.Ci,
+                                       GRAM_R, ap.coef, ap.coef + 4 * (size_t)cv.Co, c.consts(bn, 3), cv.Co, cv.Ci, wdt,
                                        overlap ? (void*)t->side : stream));
             // da = (W^T diag(s)) g + nq a + nr in ONE launch: the reduction runs over g's 4w channels (tap 0) and then over a's w
             // channels (tap 1 = vince_conv_epi.in2), with the fused reduction of the BatchNorm below as the plain dgrad has it
@@ -1414,13 +1424,14 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
                     return VINCE_E_UNSUPPORTED;
                 }
                 vince_conv_desc dq = ds1[0];
-                dq.TA = 1; dq.TB = 2; dq.dh0 = dq.dw0 = 0; dq.dhs = 1; dq.dws = 0;
-                dq.wt0 = 0; dq.wta = 0; dq.wtb = 1; dq.WT = 2;
+                dq.TA = 1; dq.TB = taps; dq.dh0 = dq.dw0 = 0; dq.dhs = 1; dq.dws = 0;
+                dq.wt0 = 0; dq.wta = 0; dq.wtb = 1; dq.WT = taps;
                 vince_conv_epi e1;
                 memset(&e1, 0, sizeof(e1));
                 e1.bias = ap.nr;
                 e1.in2 = a_in;
                 e1.in2_channels = cv.Ci;
+                e1.in2_repeat = split ? 2 : 0;
                 if (fuse_red) e1.bnred = bn_reduce_of(c, b.b[L - 1], nullptr, true, b.y[L - 1]);
                 e1.replicas = b.b[L - 1].R;
                 RC(vince_conv_igemm(&dq, c.dtype, Z, ap.w2, DA, &e1, stream));

@@ -128,7 +128,7 @@ def _conv_dtype(x, x3):
 
 
 def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, bnred=None, replicas=0, out_scale=None,
-               id_scale=None, id_shift=None, out_mask=None, in2=None, x3=None):
+               id_scale=None, id_shift=None, out_mask=None, in2=None, x3=None, in2_repeat=0):
     """vince_conv_igemm with the epilogue options of vince_conv_epi."""
     require_gpu(x, w, out, bias, stats, acc_mask, out_scale, id_scale, id_shift, out_mask, in2)
     e = ConvEpi()
@@ -144,7 +144,7 @@ def conv_igemm(desc, x, w, out, bias=None, stats=None, flags=0, acc_mask=None, b
     e.id_shift = None if id_shift is None else id_shift.data_ptr()
     e.out_mask = None if out_mask is None else out_mask.data_ptr()
     if in2 is not None:     # the last tap reads this tensor (vince_conv_epi.in2)
-        e.in2, e.in2_channels = in2.data_ptr(), in2.shape[-1]
+        e.in2, e.in2_channels, e.in2_repeat = in2.data_ptr(), in2.shape[-1], in2_repeat
     check(lib().vince_conv_igemm(ctypes.byref(desc), _conv_dtype(x, x3), _ptr(x), _ptr(w), _ptr(out), ctypes.byref(e),
                                  stream_ptr()))
     return out
@@ -242,20 +242,27 @@ def conv_expand_dgrad_masked(dy, wt, out, out_mask, gsums, accumulate=False, acc
     return out
 
 
-def bn3_bwd_prepare(R, w, gsums, mean, invstd, gamma, count, dgamma, dbeta):
+def bn3_bwd_prepare(R, w, gsums, mean, invstd, gamma, count, dgamma, dbeta, colsum=None, split=False):
     """vince_bn3_bwd_prepare (csrc/bn_algebra.hip): R float[Co][K] = g^T a, w bf16 [Co][K], gsums double[replicas][Co][2].
-    Returns coef float[4][Co], w2 bf16 [K][2][Co] -- tap 0 = wd = W^T diag(s), tap 1 = nq = -W^T diag(t) W in its first K entries: the
-    weights of the one-launch input gradient da = wd g + nq a + nr (conv_igemm(..., in2=a)) -- and nr float[K]; dgamma / dbeta are
-    accumulated in place."""
-    require_gpu(R, w, gsums, mean, invstd, gamma, dgamma, dbeta)
+    Returns coef float[5][Co] (row 4: the mean the formulas used -- what bn3_bwd_finish_dw takes), w2 bf16 [K][2][Co] -- tap 0 = wd =
+    W^T diag(s), tap 1 = nq = -W^T diag(t) W in its first K entries: the weights of the one-launch input gradient da = wd g + nq a + nr
+    (conv_igemm(..., in2=a)) -- and nr float[K]; dgamma / dbeta are accumulated in place.  colsum (double[replicas][K], column sums of
+    a): the self-consistent form (implied mean, nr from the rounded matrices) the engine uses.  w: bf16, or the fp32 master weights.
+    split: w2 is [K][3][Co] -- taps wd_hi, wd_lo, and [nq_hi | nq_lo] in the first 2K entries of the third (conv_igemm(..., in2=a,
+    in2_repeat=2)): the mixed mode's form."""
+    require_gpu(R, w, gsums, mean, invstd, gamma, dgamma, dbeta, colsum)
     Co, K = w.shape[0], w.shape[-1]
     dev = w.device
-    coef = torch.empty(4, Co, device=dev, dtype=torch.float32)
-    w2 = torch.zeros(K, 2, Co, device=dev, dtype=torch.bfloat16)
+    taps = 3 if split else 2
+    coef = torch.empty(5, Co, device=dev, dtype=torch.float32)
+    w2 = torch.zeros(K, taps, Co, device=dev, dtype=torch.bfloat16)
     nr = torch.empty(K, device=dev, dtype=torch.float32)
+    base, ld = w2.data_ptr(), taps * Co
     check(lib().vince_bn3_bwd_prepare(_ptr(R), _ptr(w), _ptr(gsums), gsums.shape[0], _ptr(mean), _ptr(invstd), _ptr(gamma), int(count),
-                                      Co, K, _ptr(coef), w2.data_ptr(), 2 * Co, w2.data_ptr() + 2 * Co, 2 * Co, _ptr(nr), _ptr(dgamma),
-                                      _ptr(dbeta), stream_ptr()))
+                                      Co, K, _ptr(coef), base, ld, base + 2 * (taps - 1) * Co, ld, _ptr(nr), _ptr(dgamma),
+                                      _ptr(dbeta), _ptr(colsum), 0 if colsum is None else colsum.shape[0],
+                                      VINCE_F32 if w.dtype == torch.float32 else VINCE_BF16,
+                                      base + 2 * Co if split else None, base + 2 * (2 * Co + K) if split else None, stream_ptr()))
     return coef, w2, nr
 
 
@@ -265,7 +272,8 @@ def bn3_bwd_finish_dw(RdW, w, gram, colsum, coef, mean, invstd, dw_accum=None):
     require_gpu(RdW, w, gram, colsum, coef, mean, invstd, dw_accum)
     Co, K = w.shape[0], w.shape[-1]
     check(lib().vince_bn3_bwd_finish_dw(_ptr(RdW), _ptr(dw_accum), _ptr(w), _ptr(gram), _ptr(colsum), colsum.shape[0], _ptr(coef), _ptr(mean),
-                                        _ptr(invstd), Co, K, stream_ptr()))
+                                        _ptr(invstd), Co, K, VINCE_F32 if w.dtype == torch.float32 else VINCE_BF16,
+                                        stream_ptr()))
     return RdW if dw_accum is None else dw_accum
 
 
