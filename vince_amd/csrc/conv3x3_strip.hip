@@ -60,7 +60,7 @@ struct XsParams {
     const float* br_invstd;
     const float* br_msc;
     const float* br_msh;
-    // BIAS (the BatchNorm-folded inference forward): out = bf16([relu](conv + bias[co])) -- on the fp32 accumulators, one rounding -- as
+    // BIAS (the BatchNorm-folded inference forward): out = [relu](conv + bias[co]) applied to the bf16-rounded convolution output, as
     // vince_conv_igemm's epilogue does; no statistics
     const float* bias;
     int relu;
@@ -198,15 +198,6 @@ __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParam
                 v[e] = __uint_as_float(r[0]);
                 v[4 + e] = __uint_as_float(r[1]);
             }
-            if constexpr (BIAS) {   // (the chunk holds channels 32 j + 8 (2 gp + khalf) ...: bias and ReLU on the fp32 values, ONE rounding --
-                                    // vince_conv_igemm's order since round 6)
-                const float* const bt = ctab + j * 32 + (2 * gp + khalf) * 8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v[e] += bt[e];
-                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
-                }
-            }
             opk[j][gp] = Chunk<bf16_t>::pack(v);
         };
         auto epi_write = [&](int pass) {                    // chunks of MFMA tile `pass` (32 channels) into the buffer
@@ -235,8 +226,17 @@ __global__ __launch_bounds__(XS_THREADS) void conv3x3_strip_kernel(const XsParam
         auto epi_store = [&](int u, int pass, int sidx) {
             const int prow = lane / 4 + 16 * sidx, c = lane % 4;
             const size_t off = (size_t)(ppix0 + (uint32_t)(32 * u + prow)) * XS_C + (size_t)(pass * 32 + c * 8);
-            if constexpr (BIAS) {   // (bias and ReLU went onto the fp32 accumulators in epi_pack)
-                *(uint4*)(out + off) = tval;
+            if constexpr (BIAS) {   // a lane stores the same 8 channels for the whole launch: their bias sits in the LDS table
+                float f[8], bv[8];
+                Chunk<bf16_t>::unpack(tval, f);
+                *(float4*)&bv[0] = *(const float4*)(ctab + pass * 32 + c * 8);
+                *(float4*)&bv[4] = *(const float4*)(ctab + pass * 32 + c * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f[e] += bv[e];
+                    if (p.relu) f[e] = fmaxf(f[e], 0.f);
+                }
+                *(uint4*)(out + off) = Chunk<bf16_t>::pack(f);
                 return;
             }
             if constexpr (!(XS_ABLATE & 2)) *(uint4*)(out + off) = tval;
@@ -459,7 +459,7 @@ extern "C" int vince_conv3x3_strip(int dtype, const void* x, const void* w, int3
 }
 
 // The same convolution with the epilogue of the BatchNorm-folded inference forward: out = [relu](conv(x, w) + bias[co]) -- bias and ReLU
-// applied to the fp32 accumulators before the one rounding, exactly as vince_conv_igemm's epilogue does (bit-identical to it); bias may be NULL.
+// applied to the bf16-rounded convolution output exactly as vince_conv_igemm's epilogue does (bit-identical to it); bias may be NULL.
 extern "C" int vince_conv3x3_strip_bias(int dtype, const void* x, const void* w, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                                         const float* bias, int32_t relu, void* out, void* stream) {
     const XsBias b{bias, relu};

@@ -2,6 +2,8 @@
 // 256 x 256 tile): launch parameters, the MFMA wrapper and the epilogue (accumulators -> LDS -> coalesced NHWC stores with the
 // fused bias / ReLU / BatchNorm-statistics / residual-join / BatchNorm-backward-reduction options of vince_conv_epi).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace vince_conv {
@@ -25,6 +27,7 @@ struct ConvParams {
     uint32_t in2_bytes;
     int cs2;
     int log2_cpt2, cpt2_mask;   // in2 read several times over (vince_conv_epi.in2_repeat): 16-byte chunks per in2 row (31 / 0x7fffffff: once)
+    int log2_tapid;             // K chunks per stretch of linearly advancing offsets: log2_cpt, or log2_cpt2 with in2_repeat
     vince_conv_epi e;   // epilogue options (bias, statistics, residual join, fused BatchNorm forward / backward-reduce)
 };
 
@@ -93,38 +96,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     constexpr bool BWD = MODE == 1, JOIN = MODE == 2;
     const vince_conv_desc& d = p.d;
     // ---- epilogue: accumulators -> LDS [pixel][channel] as T -> coalesced 16-byte stores --------------------
-    // A plain bias (everything but the residual join, whose bias follows a scale) goes onto the fp32 ACCUMULATORS, before the one
-    // rounding to T.  Added to the staged 16-bit value instead (rounds 1-5), a bias that cancels most of the accumulator -- the constant
-    // of the BatchNorm-backward algebra's input gradient, csrc/bn_algebra.hip -- leaves the sum on the coarse grid of the LARGER number,
-    // and where the spread of the result is a few of those steps the rounding error stops averaging out over pixels: the per-channel
-    // sums the BatchNorm below reduces were 1e-1 off (round 6, tools/alg_op_probe.py: 1.6e-1 -> 6e-4 with this and the hi + lo matrices).
-    const bool bias_first = !JOIN && p.e.bias != nullptr && blockIdx.y == 0;
+    // The bias of a 16-bit GRADIENT launch goes onto the fp32 ACCUMULATORS, before the one rounding to T.  Added to the staged 16-bit value
+    // instead (rounds 3-5), a bias that cancels most of the accumulator -- the constant of the BatchNorm-backward algebra's input gradient,
+    // csrc/bn_algebra.hip, the one gradient launch with a bias -- leaves the sum on the coarse grid of the LARGER number, and where the
+    // spread of the result is a few of those steps the rounding error stops averaging out over pixels: the per-channel sums the BatchNorm
+    // below reduces were 1e-1 off (round 6, tools/alg_op_probe.py: 1.6e-1 -> 2e-3 with this and the hi + lo matrices).  Forward launches
+    // (the folded inference path's bias + ReLU, bit-compatible with the streaming kernels) and fp32 tensors (no second rounding) keep theirs.
+    constexpr bool BIAS_FIRST = BWD && sizeof(T) == 2;
+    const bool bias_first = BIAS_FIRST && p.e.bias != nullptr && blockIdx.y == 0;
+    auto stage = [&](auto with_bias) {
 #pragma unroll
-    for (int j = 0; j < CJ; ++j)
+        for (int j = 0; j < CJ; ++j)
 #pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            const int pix = wp * (PTL / WP) + i * 32 + (lane & 31);
+            for (int i = 0; i < PI; ++i) {
+                const int pix = wp * (PTL / WP) + i * 32 + (lane & 31);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch = wc * (CT / WN) + j * 32 + 8 * g + 4 * (lane >> 5);
-                unsigned char* dst = smem + pix * CRS + ch * (int)sizeof(T);
-                float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-                if (bias_first) {   // (uniform)
-                    const int cg = c0 + ch;
-                    b0 = cg < d.Co ? p.e.bias[cg] : 0.f;
-                    b1 = cg + 1 < d.Co ? p.e.bias[cg + 1] : 0.f;
-                    b2 = cg + 2 < d.Co ? p.e.bias[cg + 2] : 0.f;
-                    b3 = cg + 3 < d.Co ? p.e.bias[cg + 3] : 0.f;
-                }
-                if constexpr (sizeof(T) == 4) {
-                    *(float4*)dst = make_float4(acc[j][i][4 * g] + b0, acc[j][i][4 * g + 1] + b1, acc[j][i][4 * g + 2] + b2,
-                                                acc[j][i][4 * g + 3] + b3);
-                } else {
-                    *(uint2*)dst = make_uint2(pack_bf16x2(acc[j][i][4 * g] + b0, acc[j][i][4 * g + 1] + b1),
-                                              pack_bf16x2(acc[j][i][4 * g + 2] + b2, acc[j][i][4 * g + 3] + b3));
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = wc * (CT / WN) + j * 32 + 8 * g + 4 * (lane >> 5);
+                    unsigned char* dst = smem + pix * CRS + ch * (int)sizeof(T);
+                    float v0 = acc[j][i][4 * g], v1 = acc[j][i][4 * g + 1], v2 = acc[j][i][4 * g + 2], v3 = acc[j][i][4 * g + 3];
+                    if constexpr (decltype(with_bias)::value) {
+                        const int cg = c0 + ch;
+                        v0 += cg < d.Co ? p.e.bias[cg] : 0.f;
+                        v1 += cg + 1 < d.Co ? p.e.bias[cg + 1] : 0.f;
+                        v2 += cg + 2 < d.Co ? p.e.bias[cg + 2] : 0.f;
+                        v3 += cg + 3 < d.Co ? p.e.bias[cg + 3] : 0.f;
+                    }
+                    if constexpr (sizeof(T) == 4) *(float4*)dst = make_float4(v0, v1, v2, v3);
+                    else *(uint2*)dst = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                 }
             }
-        }
+    };
+    if constexpr (BIAS_FIRST) {
+        if (bias_first) stage(std::true_type{});       // (uniform; the launches without a bias keep the plain loop)
+        else stage(std::false_type{});
+    } else {
+        stage(std::false_type{});
+    }
     __syncthreads();
 
     constexpr int CPR = CT * (int)sizeof(T) / 16;   // 16-byte chunks per tile row
@@ -134,7 +142,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     const bool cvalid = cbase < d.Co;
     float bias_v[CH];
 #pragma unroll
-    for (int e = 0; e < CH; ++e) bias_v[e] = (JOIN && p.e.bias && cvalid && blockIdx.y == 0) ? p.e.bias[cbase + e] : 0.f;
+    for (int e = 0; e < CH; ++e) bias_v[e] = (!BIAS_FIRST && p.e.bias && cvalid && blockIdx.y == 0) ? p.e.bias[cbase + e] : 0.f;
     // residual join with known BatchNorm constants (MODE 2): conv * osc + bias + (old * isc + ish)
     float osc_v[CH], isc_v[CH], ish_v[CH];
     const bool id_affine = JOIN && p.e.id_scale != nullptr;
@@ -160,7 +168,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, unsigned char
     // BWD (compile time): the gradient epilogues -- residual join (ACCUMULATE, acc_mask) and the fused BatchNorm-backward
     // reduction (bnred).  Forward launches take the lean instantiation.
     const bool accum = (BWD || JOIN) && (flags & VINCE_EPI_ACCUMULATE) != 0;
-    const bool touch = (JOIN && p.e.bias) || accum || (flags & VINCE_EPI_RELU) || (BWD && p.e.out_mask);
+    const bool touch = (!BIAS_FIRST && p.e.bias) || accum || (flags & VINCE_EPI_RELU) || (BWD && p.e.out_mask);
     const T* __restrict__ br_y = BWD ? (const T*)p.e.bnred.y : nullptr;
     float br_mu[CH], br_is[CH], br_sc[CH], br_sh[CH];
     if constexpr (BWD) {

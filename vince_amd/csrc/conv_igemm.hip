@@ -95,11 +95,13 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
     if (e.in2) p.total_chunks = (T - 1) * cpt + e.in2_channels * in2_rep / CH;   // the last tap reads the (narrower) second tensor
     p.log2_cpt2 = 31;
     p.cpt2_mask = 0x7fffffff;
+    p.log2_tapid = p.log2_cpt;
     if (in2_rep > 1) {
         int l = 0;
         while ((1 << l) < e.in2_channels / CH) ++l;
         p.log2_cpt2 = l;
         p.cpt2_mask = e.in2_channels / CH - 1;
+        p.log2_tapid = l;
     }
     p.nkt = (p.total_chunks + 3) / 4;
     p.M = d.N * d.Ho * d.Wo;
@@ -151,7 +153,8 @@ extern "C" int vince_conv_igemm(const vince_conv_desc* dd, int dtype, const void
         vince_profile_set_dims(tok, p.M, d.Co, T * d.Ci, T, d.sh * 10 + d.osh, e.flags);
     }
     int rc;
-    const bool bwd = (e.flags & VINCE_EPI_ACCUMULATE) || e.bnred.y || e.out_mask;   // gradient epilogue instantiation
+    // gradient epilogue instantiation (in2: the BatchNorm-backward algebra's input gradient -- its bias goes onto the fp32 accumulators there)
+    const bool bwd = (e.flags & VINCE_EPI_ACCUMULATE) || e.bnred.y || e.out_mask || e.in2;
     const bool join = e.out_scale || e.id_scale;   // forward residual join with known BatchNorm constants
     // The 8-wavefront 256 x 256 core (conv_m8.hip) takes the long bf16 reductions with 256-channel output tiles: the 3x3 and wide
     // 1x1 convolutions of layer3 / layer4 and their input gradients.  VINCE_M8=0 keeps everything on this file's tiles (the

@@ -285,9 +285,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_dlds_kernel(const ConvPa
     };
     auto issue_tile = [&](int kt, int buf) {
         if (p.uniform_taps) {
-            int tap = kt >= p.nkt ? 0x7fffff : ((kt * KC) >> p.log2_cpt);   // wave-uniform
-            // (in2_repeat: every pass over the second tensor's row starts like a new tap -- the offsets are made afresh, not advanced)
-            if (p.in2) tap = (tap << 6) | (((kt * KC) & p.cpt_mask) >> p.log2_cpt2);
+            // (log2_tapid = log2_cpt, except with in2_repeat: the chunks of one in2 row -- every pass over the second tensor's row then starts
+            // like a new tap, the offsets made afresh instead of advanced; the other taps just recompute theirs a few times more)
+            const int tap = kt >= p.nkt ? 0x7fffff : ((kt * KC) >> p.log2_tapid);   // wave-uniform
             if (tap != cur_tap) {
                 compute_offsets(kt * KC + c_log);
                 cur_tap = tap;

@@ -52,7 +52,7 @@ struct XjParams {
     const void* w2;       // [64][256] bf16
     void* y2;             // [rows][64] bf16: the next conv1's raw output
     double* stats2;       // double[replicas2][64][2]: (sum, sum of squares) of the stored y2
-    const float* bias2;   // optional (folded inference): y2 = bf16( [relu]( conv + bias2[c] ) ), as vince_conv_igemm's bias epilogue rounds (round 6: once)
+    const float* bias2;   // optional (folded inference): y2 = [relu]( bf16(conv) + bias2[c] ), as vince_conv_igemm's bias epilogue rounds
     int relu2;
     uint32_t w2_bytes;
     int replicas2;
@@ -488,12 +488,15 @@ __global__ __launch_bounds__(XJ_THREADS) void conv_xjoin_kernel(const XjParams p
         // C[pixel][channel]: lane = channel column, register r = pixel row (r & 3) + 8 (r >> 2) + 4 khalf: 32 lanes store 64 consecutive bytes
         const uint32_t pix0 = (uint32_t)(first + t * step) * XJ_PX + (uint32_t)(wp * 64 + i * 32);
         bf16_t* __restrict__ y2 = (bf16_t*)p.y2 + (size_t)(c1t * 32 + (lane & 31));
-        if (p.bias2) {                                      // (uniform) the implicit-GEMM epilogue's order: the bias onto the fp32 accumulator, ReLU, ONE rounding
+        if (p.bias2) {                                      // (uniform) the implicit-GEMM epilogue's order: round, add the bias, ReLU, round
             const float b2 = p.bias2[c1t * 32 + (lane & 31)];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                c2[r] += b2;
-                if (p.relu2) c2[r] = fmaxf(c2[r], 0.f);
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t u0 = pack_bf16x2(c2[r], c2[r + 1]);
+                float f0 = __uint_as_float(u0 << 16) + b2, f1 = __uint_as_float(u0 & 0xffff0000u) + b2;
+                if (p.relu2) { f0 = fmaxf(f0, 0.f); f1 = fmaxf(f1, 0.f); }
+                c2[r] = f0;
+                c2[r + 1] = f1;
             }
         }
 #pragma unroll
