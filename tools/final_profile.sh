@@ -55,7 +55,9 @@ timeout 300 python tools/step_phases.py 10 x3 2>/dev/null | tail -1 >> $O/step_p
 timeout 300 python tools/step_phases.py 10 x3f 2>/dev/null | tail -1 >> $O/step_phases.txt
 timeout 400 python tools/group_bound.py 256 10 2>/dev/null | tail -2 > $O/group_bound.txt
 timeout 900 python tools/ab.py 3 40 "VINCE_DEFER_STEM=1" "VINCE_DEFER_STEM=0" "VINCE_KNOBS=xjoin_next=0" > $O/ab.txt 2>&1
-AB_ARGS="--dtype x3f" timeout 900 python tools/ab.py 2 20 "VINCE_KNOBS=" "VINCE_KNOBS=gram_shadow=0" "VINCE_X3F_HYBRID=0" >> $O/ab.txt 2>&1
+AB_ARGS="--dtype x3f" timeout 900 python tools/ab.py 2 20 "VINCE_KNOBS=" "VINCE_KNOBS=gram_shadow=0" "VINCE_KNOBS=x3f_alg=0" "VINCE_KNOBS=alg_split=0" "VINCE_X3F_HYBRID=0" >> $O/ab.txt 2>&1
+# the BatchNorm-backward algebra's input gradient at engine scale: masked pixel sums vs fp64, single bf16 matrices against hi + lo parts
+(timeout 200 python tools/alg_op_probe.py 200704 64 0.02; timeout 200 python tools/alg_op_probe.py 200704 128 0.1) 2>&1 | grep -v amdgpu > $O/alg_op_probe.txt
 export VINCE_GIT_HEAD=${VINCE_GIT_HEAD:-unknown}
 # the bench line once more, now that profiles/pmc_conv_igemm.json of THIS build exists (traffic_stale false)
 cp $O/pmc_conv_igemm.json profiles/pmc_conv_igemm.json
