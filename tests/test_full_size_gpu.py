@@ -236,8 +236,8 @@ def _rel(a, b):
 def _x3f_gradients(tag, r, g, sampled):
     """compute_dtype "x3f": the x3 forward (held to the north-star bars by the caller, like x3) with a MIXED-PRECISION backward -- the bf16
     engine on bfloat16 copies of the saved tensors (BatchNorm inputs stored centred).  Its gradients are AMP-grade, not fp32-grade, and are
-    held to their own bounds, 1.5 x the worst measured over G9 / G12 / G14 on MI355X: every tensor's sum |g| within 2.5e-2 (worst measured
-    1.6e-2; x3: 1e-2), sampled rows within 0.14 of the largest entry (9e-2; x3: 2.6e-2), cosine to the reference's rows >= 0.995 (0.998)."""
+    held to their own bounds, 1.5 x the worst measured over G9 / G12 / G14 on MI355X: every tensor's sum |g| within 3.2e-2 (worst measured:
+    the stem's bn1.weight on G12, 1.7e-2 ... 2.1e-2 from run to run -- fp32 atomics order -- everything else <= 1.4e-2; x3: 1e-2, 3e-2 stem-adjacent), sampled rows within 0.14 of the largest entry (9e-2; x3: 2.6e-2), cosine to the reference's rows >= 0.995 (0.998)."""
     gn = list(g["grad_names"])
     ratios = {n: abs(r["grad_checksums"][i][2] / g["grad_checksums"][gn.index(n)][2] - 1) for i, n in enumerate(r["grad_names"])}
     rows, cos = {}, {}
@@ -250,7 +250,7 @@ def _x3f_gradients(tag, r, g, sampled):
           % (tag, float(np.median(list(ratios.values()))), max(ratios.values()), max(ratios, key=ratios.get), max(rows.values()),
              max(rows, key=rows.get), min(cos.values()), min(cos, key=cos.get)))
     assert sorted(r["grad_names"]) == sorted(gn)
-    assert max(ratios.values()) < 2.5e-2, max(ratios, key=ratios.get)
+    assert max(ratios.values()) < 3.2e-2, max(ratios, key=ratios.get)
     assert max(rows.values()) < 0.14 and min(cos.values()) > 0.995, (rows, cos)
 
 
