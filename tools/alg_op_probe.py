@@ -64,18 +64,21 @@ colsum[0] = a64.sum(0)
 gs = torch.zeros(ops.STATS_REPLICAS, Co, 2, device=DEV, dtype=torch.float64)
 gs[0, :, 0] = g.sum(0)
 for name, wt, split in (("algebra, bf16 W, single matrices", W.bfloat16(), False), ("algebra, fp32 W, single matrices", W, False),
-                        ("algebra, bf16 W, hi + lo", W.bfloat16(), True), ("algebra, fp32 W, hi + lo", W, True)):
+                        ("algebra, bf16 W, hi + lo", W.bfloat16(), True), ("algebra, fp32 W, nq alone hi + lo", W, "nq"),
+                        ("algebra, fp32 W, hi + lo", W, True)):
     dg, db = torch.zeros(Co, device=DEV), torch.zeros(Co, device=DEV)
     coef, w2, nr = ops.bn3_bwd_prepare(R.view(Co, w), wt.contiguous(), gs, mu.float(), invstd.float(), gamma, rows, dg, db, colsum=colsum, split=split)
-    taps = 3 if split else 2
+    taps = 3 if split is True else 2
     dd = ConvDesc(N=1, Hi=rows, Wi=1, Ci=Co, Ho=rows, Wo=1, Co=w, sh=1, sw=1, TA=1, TB=taps, dh0=0, dhs=1, dw0=0, dws=0, wt0=0, wta=0,
                   wtb=1, WT=taps, OH=rows, OW=1, osh=1, osw=1, oh0=0, ow0=0)
     da = torch.empty(rows, w, device=DEV, dtype=torch.bfloat16)
     ops.conv_igemm(dd, gb.view(1, rows, 1, Co), w2, da.view(1, rows, 1, w), bias=nr, in2=ab.view(1, rows, 1, w), in2_repeat=2 if split else 0)
     score(name, da)
     w2f = w2.double()
-    if split:
+    if split is True:
         full = g @ (w2f[:, 0] + w2f[:, 1]).t() + ab.double() @ (w2f[:, 2, :w] + w2f[:, 2, w:2 * w]).t() + nr.double()
+    elif split:
+        full = g @ w2f[:, 0].t() + ab.double() @ (w2f[:, 1, :w] + w2f[:, 1, w:2 * w]).t() + nr.double()
     else:
         full = g @ w2f[:, 0].t() + ab.double() @ w2f[:, 1, :w].t() + nr.double()
     score("   ... the same, unrounded da", full)

@@ -210,8 +210,8 @@ extern "C" int vince_bn3_bwd_prepare(const float* R, const void* w_bf16, const d
                                      const double* colsum, int32_t colsum_replicas, int32_t w_dtype, void* wd_lo, void* nq_lo, void* stream) {
     VINCE_CHECK_ARG(R && w_bf16 && gsums && mean && invstd && gamma && coef && wd && nq && nr && dgamma && dbeta, VINCE_E_ARG,
                     "vince_bn3_bwd_prepare: null pointer");
-    VINCE_CHECK_ARG((w_dtype == VINCE_BF16 || w_dtype == VINCE_F32) && !wd_lo == !nq_lo, VINCE_E_ARG,
-                    "vince_bn3_bwd_prepare: w_dtype %d (bf16 or fp32); wd_lo and nq_lo come together", w_dtype);
+    VINCE_CHECK_ARG((w_dtype == VINCE_BF16 || w_dtype == VINCE_F32) && (!wd_lo || nq_lo), VINCE_E_ARG,
+                    "vince_bn3_bwd_prepare: w_dtype %d (bf16 or fp32); wd_lo needs nq_lo", w_dtype);
     VINCE_CHECK_ARG(count > 0 && Co > 0 && Co <= ALG_MAX_CO && (K == 64 || K == 128 || K == 256), VINCE_E_SHAPE,
                     "vince_bn3_bwd_prepare: K=%d (64, 128 or 256), Co=%d (at most %d)", K, Co, ALG_MAX_CO);
     VINCE_CHECK_ARG(K <= Co && (!colsum || colsum_replicas > 0), VINCE_E_SHAPE, "vince_bn3_bwd_prepare: K=%d > Co=%d, or colsum without replicas", K, Co);

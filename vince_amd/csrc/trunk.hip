@@ -1387,11 +1387,14 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             const BnL& bn = b.b[L];
             const void* a_in = at(workspace, b.a[L - 1]);
             // A twin (mixed mode: the forward multiplied with the fp32 masters) derives the coefficients from the MASTER weights and takes the
-            // input gradient's two matrices in bf16 hi + lo parts -- what keeps the masked sums the BatchNorm below reduces at the separate
+            // input gradient's matrices in bf16 hi + lo parts -- what keeps the masked sums the BatchNorm below reduces at the separate
             // passes' accuracy (csrc/bn_algebra.hip; `alg_split=0`: single bf16 matrices from the bf16 cache, as the bf16 mode has them)
-            const bool split = t->is_twin && vince_knob_live("alg_split", 1) != 0;
+            // (`alg_split`: 2 = nq in two parts, the default -- its rounding residue multiplies a, which is zero exactly where bn2's mask is;
+            // 1 = wd as well, +0.25 ms: 3x closer on synthetic data, tools/alg_op_probe.py, no measurable difference on G9 / G12; 0 = neither)
+            const int split_mode = t->is_twin ? (int)vince_knob_live("alg_split", 2) : 0;
+            const bool split = split_mode != 0, split_wd = split_mode == 1;
             const void* wk = split ? (const void*)params[cv.param] : at((void*)wcache, cv.wk);      // ([Co][1][1][Ci] = the same [Co][K] rows)
-            const int wdt = split ? VINCE_F32 : VINCE_BF16, taps = split ? 3 : 2;
+            const int wdt = split ? VINCE_F32 : VINCE_BF16, taps = split_wd ? 3 : 2;
             const AlgPtrs ap = alg_ptrs(workspace, b);
             unsigned char* const w2b = (unsigned char*)ap.w2;
             // R = g^T a into this block's scratch (on this stream: the algebra below needs it before the dgrad); the finished weight
@@ -1404,7 +1407,8 @@ extern "C" int vince_trunk_backward(vince_trunk_t t, const float* const* params,
             RC(vince_bn3_bwd_prepare(R, wk, c.sums(bn), bn.R, c.consts(bn, 2), c.consts(bn, 3), params[bn.gamma], rows_out,
                                      cv.Co, cv.Ci, ap.coef, ap.w2, taps * cv.Co, w2b + (size_t)(taps - 1) * cv.Co * 2, taps * cv.Co, ap.nr,
                                      grads[bn.gamma], grads[bn.beta], (const double*)at(workspace, b.colsum), GRAM_R, wdt,
-                                     split ? w2b + (size_t)cv.Co * 2 : nullptr, split ? w2b + ((size_t)2 * cv.Co + cv.Ci) * 2 : nullptr, stream));
+                                     split_wd ? w2b + (size_t)cv.Co * 2 : nullptr,
+                                     split ? w2b + ((size_t)(taps - 1) * cv.Co + cv.Ci) * 2 : nullptr, stream));
             // the finished weight gradient is nobody's input but the optimiser's: on the weight-gradient stream, behind the coefficients
             // (ev_alg), off the chain of launches the input gradient below waits for
             if (overlap) {

@@ -248,12 +248,12 @@ def bn3_bwd_prepare(R, w, gsums, mean, invstd, gamma, count, dgamma, dbeta, cols
     W^T diag(s), tap 1 = nq = -W^T diag(t) W in its first K entries: the weights of the one-launch input gradient da = wd g + nq a + nr
     (conv_igemm(..., in2=a)) -- and nr float[K]; dgamma / dbeta are accumulated in place.  colsum (double[replicas][K], column sums of
     a): the self-consistent form (implied mean, nr from the rounded matrices) the engine uses.  w: bf16, or the fp32 master weights.
-    split: w2 is [K][3][Co] -- taps wd_hi, wd_lo, and [nq_hi | nq_lo] in the first 2K entries of the third (conv_igemm(..., in2=a,
-    in2_repeat=2)): the mixed mode's form."""
+    split=True: w2 is [K][3][Co] -- taps wd_hi, wd_lo, and [nq_hi | nq_lo] in the first 2K entries of the third (conv_igemm(..., in2=a,
+    in2_repeat=2)); split="nq": [K][2][Co] with nq alone in two parts, [nq_hi | nq_lo] in the second tap -- the mixed mode's form."""
     require_gpu(R, w, gsums, mean, invstd, gamma, dgamma, dbeta, colsum)
     Co, K = w.shape[0], w.shape[-1]
     dev = w.device
-    taps = 3 if split else 2
+    taps = 3 if split is True else 2
     coef = torch.empty(5, Co, device=dev, dtype=torch.float32)
     w2 = torch.zeros(K, taps, Co, device=dev, dtype=torch.bfloat16)
     nr = torch.empty(K, device=dev, dtype=torch.float32)
@@ -262,7 +262,7 @@ def bn3_bwd_prepare(R, w, gsums, mean, invstd, gamma, count, dgamma, dbeta, cols
                                       Co, K, _ptr(coef), base, ld, base + 2 * (taps - 1) * Co, ld, _ptr(nr), _ptr(dgamma),
                                       _ptr(dbeta), _ptr(colsum), 0 if colsum is None else colsum.shape[0],
                                       VINCE_F32 if w.dtype == torch.float32 else VINCE_BF16,
-                                      base + 2 * Co if split else None, base + 2 * (2 * Co + K) if split else None, stream_ptr()))
+                                      base + 2 * Co if split is True else None, base + 2 * ((taps - 1) * Co + K) if split else None, stream_ptr()))
     return coef, w2, nr
 
 
