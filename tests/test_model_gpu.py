@@ -889,15 +889,17 @@ def test_bucketed_allreduce_machinery_single_rank():
     assert not r0 and r1
     # (two steps only: fp32 atomics make weight gradients order-dependent in the last bits and a freshly initialised
     # encoder amplifies that chaotically from the third step on)
-    np.testing.assert_allclose(l1, l0, rtol=1e-4, atol=1e-7)
-    assert rel(p1.cpu(), p0.cpu()) < 2e-3
+    # (bounds: several times the run-to-run spread of the PLAIN step -- tools/dp_x3f_probe.py: 1e-3 of the parameters after two steps of a
+    # freshly initialised encoder; a bucket skipped or read early is an O(1e-1) difference)
+    np.testing.assert_allclose(l1, l0, rtol=1e-3, atol=1e-7)
+    assert rel(p1.cpu(), p0.cpu()) < 1e-2
     # deferred (stem + layer1 bucket stepped last, behind the stem event) against joined, both data parallel: the same parameters
-    np.testing.assert_allclose(l3, l1, rtol=1e-4, atol=1e-7)
-    assert rel(p3.cpu(), p1.cpu()) < 2e-3
+    np.testing.assert_allclose(l3, l1, rtol=1e-3, atol=1e-7)
+    assert rel(p3.cpu(), p1.cpu()) < 1e-2
     # cross-rank shuffle-BN (dp_shuffle_bn): on one rank the key batch is only re-ordered, so the key BatchNorm statistics,
     # the un-permuted keys and hence the losses are unchanged up to summation order
     np.testing.assert_allclose(l2, l0, rtol=1e-3, atol=1e-6)
-    assert rel(p2.cpu(), p0.cpu()) < 5e-3
+    assert rel(p2.cpu(), p0.cpu()) < 2e-2
     np.testing.assert_allclose(l5, l4, rtol=1e-5, atol=1e-7)
     assert rel(p5.cpu(), p4.cpu()) < 1e-4 and rel(g5.cpu(), g4.cpu()) < 6e-2
 
@@ -1441,22 +1443,30 @@ def test_imagenet_side_decoders_train_beside_the_contrastive_loss():
             torch.randn(64, 64, generator=torch.Generator().manual_seed(1)), dim=1))
         solver.reset_epoch()
         w0 = [p.detach().clone() for p in solver.model.imagenet_decoders.parameters()] if use_imagenet else None
-        out = [solver.run_train_iteration() for _ in range(2)]
-        return solver, out, w0
+        out, flat1 = [], None
+        for it in range(2):
+            out.append(solver.run_train_iteration())
+            if it == 0:
+                flat1 = solver.model._flat[:solver.model._n_train].detach().cpu().clone()
+        return solver, out, w0, flat1
 
-    s1, o1, w0 = run(True)
-    s0, o0, _ = run(False)
-    for (l1, m1), (l0, m0) in zip(o1, o0):
+    s1, o1, w0, f1 = run(True)
+    s0, o0, _, f0 = run(False)
+    for it, ((l1, m1), (l0, m0)) in enumerate(zip(o1, o0)):
         assert {"imagenet_loss_0", "imagenet_loss_1"} <= set(l1) and "imagenet_loss_0" not in l0
         assert {"imagenet_accuracy_0", "imagenet_accuracy_1"} <= set(m1)
         for k in ("imagenet_loss_0", "imagenet_loss_1"):
             v = float(l1[k].detach())
             assert np.isfinite(v) and 5.0 < v < 9.0          # ~ln(1000) for an untrained probe
-        assert abs(float(l1["nce_loss"].detach()) - float(l0["nce_loss"].detach())) < 1e-5
+        # (the second loss sits behind one optimiser step of a freshly initialised encoder, which amplifies the fp32 atomics' order
+        # chaotically -- two PLAIN runs differ by as much, tools/dp_x3f_probe.py; one run in three failed at 1e-5 on both iterations)
+        assert abs(float(l1["nce_loss"].detach()) - float(l0["nce_loss"].detach())) < (1e-5 if it == 0 else 1e-3)
     moved = [float((p.detach() - w).abs().max()) for p, w in zip(s1.model.imagenet_decoders.parameters(), w0)]
     assert all(m > 0 for m in moved)
-    # the probes see detached features: encoder parameters evolve exactly as without them
-    assert rel(s1.model._flat[:s1.model._n_train].cpu(), s0.model._flat[:s0.model._n_train].cpu()) < 1e-4
+    # the probes see detached features: encoder parameters evolve exactly as without them -- to atomics-order noise after one step (1e-8
+    # measured), within its amplification after two
+    assert rel(f1, f0) < 1e-5
+    assert rel(s1.model._flat[:s1.model._n_train].cpu(), s0.model._flat[:s0.model._n_train].cpu()) < 2e-2
     assert {"imagenet_loss_0", "imagenet_loss_1"} <= set(s1.model.loss(None)) and "imagenet_accuracy_1" in s1.model.get_metrics(None)
 
 

@@ -1172,8 +1172,13 @@ extern "C" int vince_trunk_forward(vince_trunk_t t, const float* const* params, 
             // Gram matrix of conv3's input through the weight-gradient kernel (in = dy = a): sum over pixels of a a^T
             vince_conv_desc dg = fwd_desc(t, cv);
             dg.Co = cv.Ci;
-            if (!gram_done)
-                RC(wgrad_launch(t, workspace, c.dtype, dg, at(workspace, in), at(workspace, in), (float*)at(workspace, b.gram), cv.Ci, 0, stream));
+            {
+                // (split-half modes: the Gram matrix as split-half products too -- bfloat16 hi + lo parts, three products, 2^-17 per term --
+                // instead of exact fp32 MFMAs at a fifth of the rate: 24 launches, 2.1 ms per step.  `gram_x3=0`: exact fp32, as until round 6.)
+                const int gdt = (t->cf == VINCE_F32X3H && vince_knob_live("gram_x3", 1) != 0) ? VINCE_F32X3B : c.dtype;
+                if (!gram_done)
+                RC(wgrad_launch(t, workspace, gdt, dg, at(workspace, in), at(workspace, in), (float*)at(workspace, b.gram), cv.Ci, 0, stream));
+            }
             // (split-half mode: the cache holds hi / lo half pairs, the finalize reads conv3's fp32 master weights -- [Co][1][1][Ci], the
             // same [Co][K] rows -- instead)
             const void* w3 = t->cf == VINCE_F32X3H ? (const void*)params[cv.param] : (const void*)at((void*)wcache, cv.wk);
