@@ -799,10 +799,10 @@ def main():
             try:
                 out["x3f_step"] = dict(step_leg(max(10, opt.fp32_steps), gflop_backbone=opt.backbone, compute_dtype="x3f"),
                                        what="mixed precision: the x3 forward (embeddings, keys and loss at the reference's 1e-3 bar -- the same "
-                                            "forward kernels, bit-identical trunk features) also leaves bfloat16 copies of what backward reads "
+                                            "forward kernels, trunk features equal to rounding) also leaves bfloat16 copies of what backward reads "
                                             "(BatchNorm inputs centred) in the workspace of a bf16 twin engine, which runs the backward: the "
                                             "arithmetic of an AMP backward (the reference's --use-apex) behind an fp32-grade forward; gradients "
-                                            "against the reference: cosine >= 0.998, sum|g| within 1.6e-2 (tests test_g9/g12/g13/g14[x3f]); "
+                                            "against the reference: cosine >= 0.998, sum|g| within 2.2e-2 (tests test_g9/g12/g13/g14[x3f]); "
                                             "mfma_frac against 2.5 PF / 2 (three MFMAs per product forward, one backward)")
             except Exception as e:
                 out["x3f_step"] = {"error": repr(e)}
