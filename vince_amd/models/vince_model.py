@@ -584,7 +584,7 @@ class VinceModel(BaseModel):
         # cannot see through, and every discarded model would keep its workspaces: tens of GB per solver at the benchmark size)
         saved = dict(trunk=trunk, twin=twin, pooled=pooled.detach(), jigsaw=jigsaw, train_bn=bool(self.training))
         if with_head:
-            hx3 = head_x3() and (self.compute_dtype == torch.bfloat16 or bool(self.conv_x3))     # (the split-half modes too: round 6)
+            hx3 = head_x3() and self.compute_dtype == torch.bfloat16
 
             def lin(x, layer, relu=False):   # one head Linear: split-half products on its prepared copy, or exact fp32 MFMAs
                 if hx3 and _head_x3_shape(layer.weight):
@@ -623,7 +623,7 @@ class VinceModel(BaseModel):
             if d_pre is not None:
                 dpre = d_pre.contiguous().float() if dpre is None else dpre + d_pre
             self._touched["jigsaw" if s["jigsaw"] else "embedding"] = True
-            hx3 = head_x3() and (self.compute_dtype == torch.bfloat16 or bool(self.conv_x3))     # (the split-half modes too: round 6)
+            hx3 = head_x3() and self.compute_dtype == torch.bfloat16
 
             def lbwd(x, layer, dy):          # gradients of one head Linear, on the route its forward took
                 w = layer.weight
