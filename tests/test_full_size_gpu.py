@@ -384,8 +384,10 @@ def test_full_size_backward_serialised_vs_overlapped_streams(tmp_path, dtype):
     # median 2.5e-4
     if dtype == "bf16":
         assert median < 1e-3, median
+    # (entry-wise, bf16: 1.5e-2 ... 2.3e-2 in most runs, 5.4e-2 on the stem's conv1.weight once in a dozen -- single entries at the end of
+    # the chain flip with the rounding of what feeds them; the sums above are the tight check, a race moves entries by O(1))
     for n in sampled:
-        assert rows[n] < (2e-3 if dtype != "bf16" else 5e-2), n
+        assert rows[n] < (2e-3 if dtype != "bf16" else 1.2e-1), n
 
 
 # G12: config 3 at its real size from the CENTRED-HEAD state (oracle/make_golden_g12.py): the 256 embeddings are spread over the sphere
